@@ -1,0 +1,64 @@
+"""Helpers shared by the golden-fixture tests (CPU and GPU): unpack a committed fixture,
+build its index with the oracle's own writer and return paths + expected dump text."""
+import gzip
+import hashlib
+import json
+import os
+
+import oracle_lib as ol
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+MANIFEST = json.load(open(os.path.join(GOLD, "manifest.json")))
+
+
+def read_fasta(path):
+    names, seqs = [], []
+    with open(path) as f:
+        for ln in f:
+            ln = ln.strip()
+            if not ln:
+                continue
+            if ln[0] == ">":
+                names.append(ln[1:].split()[0])
+                seqs.append([])
+            else:
+                seqs[-1].append(ln)
+    return names, ["".join(s).encode() for s in seqs]
+
+
+def read_fastq(path):
+    out = []
+    with open(path, "rb") as f:
+        while True:
+            n = f.readline()
+            if not n:
+                break
+            s = f.readline().rstrip(b"\r\n")
+            f.readline()
+            q = f.readline().rstrip(b"\r\n")
+            out.append((n[1:].split()[0].decode(), s, q))
+    return out
+
+
+def unpack(entry, tmpdir):
+    """-> dict(prefix, fa, fq, expected_dump:str); writes <prefix>.sma/.smi via the oracle."""
+    tag = entry["tag"]
+    paths = {}
+    for ext in ("fa", "fq"):
+        p = os.path.join(str(tmpdir), "%s.%s" % (tag, ext))
+        with gzip.open(os.path.join(GOLD, "%s.%s.gz" % (tag, ext)), "rb") as g, open(p, "wb") as f:
+            f.write(g.read())
+        paths[ext] = p
+    names, seqs = read_fasta(paths["fa"])
+    ix = ol.build_index(seqs, names, entry["k"], entry["s"])
+    prefix = os.path.join(str(tmpdir), tag)
+    assert ol.lib().or_index_write(ix, prefix.encode()) == 0
+    ol.lib().or_index_free(ix)
+    with gzip.open(os.path.join(GOLD, tag + ".refdump.txt.gz"), "rt") as g:
+        expected = g.read()
+    return dict(prefix=prefix, fa=paths["fa"], fq=paths["fq"], expected=expected, names=names, seqs=seqs)
+
+
+def md5(path):
+    return hashlib.md5(open(path, "rb").read()).hexdigest()
