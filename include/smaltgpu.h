@@ -1,0 +1,148 @@
+/* include/smaltgpu.h -- C ABI of libsmaltgpu.so: SMALT's seed-and-extend hot path on MI355X.
+ *
+ * Every entry point below is what the reference's per-read mapping API would bind for this
+ * path (plain pointers and sizes only; no torch / HIP types).  `file:line` citations refer to
+ * the reference tree (SMALT 0.7.6, src/).  INTEGRATION.md shows the rmap.c-side shim.
+ *
+ * All functions return 0 on success or a negative SMALTGPU_E* code; smaltgpu_last_error()
+ * gives a message.  There is NO CPU fallback: without a HIP device every call fails.
+ */
+#ifndef SMALTGPU_H
+#define SMALTGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  SMALTGPU_OK = 0,
+  SMALTGPU_ENODEV = -1,     /* no HIP device / HIP runtime error */
+  SMALTGPU_EFILE = -2,      /* cannot read .smi/.sma (ERRCODE_NOFILE / FILEFORM analogue) */
+  SMALTGPU_EARG = -3,       /* bad argument (ERRCODE_ARGRANGE analogue) */
+  SMALTGPU_ENOMEM = -4,     /* host or device allocation failed (ERRCODE_NOMEM) */
+  SMALTGPU_ECAP = -5,       /* a per-batch work pool overflowed; retry with a smaller batch */
+  SMALTGPU_EINTERNAL = -6   /* device-side assertion (ERRCODE_ASSERT analogue) */
+};
+
+/* RMAP_FLAGS subset honoured on this path (same values as rmap.h:53-65). */
+enum {
+  SMALTGPU_FLG_BEST = 0x02,
+  SMALTGPU_FLG_SEQBYSEQ = 0x10,
+  SMALTGPU_FLG_NOSHRTINFO = 0x20,
+  SMALTGPU_FLG_SENSITIVE = 0x80
+};
+
+typedef struct smaltgpu_index smaltgpu_index;    /* immutable index image resident in HBM */
+typedef struct smaltgpu_mapper smaltgpu_mapper;  /* work buffers + stream; one per host thread */
+
+/* Host-side description of an index: replaces struct _HashTable (hashidx.c:105-146) and the
+ * SeqSet fields the path reads (sequence.c:148-171).  Pointers may be host or device memory
+ * (see `on_device`). */
+typedef struct smaltgpu_index_desc {
+  int32_t k, s;              /* word length, sampling stride (hashidx.c:108-109) */
+  int32_t typ;               /* 0 perfect, 1 hash32mix (hashidx.h:47-50) */
+  int32_t nbits_key, nbits_lo;
+  uint32_t npos, nwords;
+  const uint32_t *idx;       /* 2^nbits_key + 1 */
+  const uint32_t *pos;       /* npos */
+  const uint32_t *wordidx;   /* nwords + 1 (hash32mix only) */
+  const uint32_t *posidx;    /* nwords + 1 (hash32mix only) */
+  int64_t nseq;
+  const uint64_t *sop;       /* nseq + 1 cumulative base offsets; ALWAYS host memory */
+  const uint32_t *packed;    /* totlen/10 + 1 words, 3 bits/base (sequence.c:1360) */
+  int32_t on_device;         /* non-zero: idx/pos/wordidx/posidx/packed are device pointers (adopted, not copied) */
+} smaltgpu_index_desc;
+
+/* Scalar arguments of rmapSingle (rmap.h:127-145) + the score penalties (score.c:41-47). */
+typedef struct smaltgpu_params {
+  int32_t ktuple_maxhit;             /* -H, default 10000 */
+  uint32_t min_cover;                /* covermin_tuple (smalt.c:1113-1126) */
+  int32_t min_swatscor;              /* -m, default k+s-1 (smalt.c:608-615) */
+  int32_t min_swatscor_below_max;    /* -d, default 0 */
+  int32_t min_basqval;               /* -q, default 0 */
+  int32_t target_depth, max_depth;   /* 512, 2048 (smalt.c:60-61) */
+  uint32_t rmapflg;                  /* SMALTGPU_FLG_* */
+  int32_t match, mismatch, gap_init, gap_ext;  /* +1 -2 -4 -3 */
+} smaltgpu_params;
+
+/* One alignment as left by resultSetAddFromAli (results.c:1852) before sorting/MAPQ. */
+typedef struct smaltgpu_result {
+  int32_t swatscor;
+  uint32_t q_start, q_end;     /* 1-based, on the original read */
+  uint64_t s_start, s_end;     /* 1-based, in sequence sidx (concatenated offset if sidx < 0) */
+  int32_t sidx;
+  uint32_t reverse;            /* 1: reverse-complement strand */
+  uint32_t stroffs, strlen;    /* DiffStr bytes in `diffstr`, strlen counts the terminating 0 */
+} smaltgpu_result;
+
+/* Per-read scalars the host post-processing needs (resultSetAlignmentStats rmap.c:1338,
+ * resultSetGetMaxSwat results.c:2163). */
+typedef struct smaltgpu_readstat {
+  int32_t swatscor_max, swatscor_2ndmax;
+  int32_t n_ali_done, n_ali_tot;      /* nseg, nseg_tot */
+  uint32_t n_hits_used, n_hits_tot;
+  int32_t errcode;                    /* 0 or SMALTGPU_E* for this read */
+  uint32_t nres;
+} smaltgpu_readstat;
+
+typedef struct smaltgpu_batch_out {
+  uint32_t nreads;
+  const uint64_t *res_off;            /* nreads + 1 offsets into `res` */
+  const smaltgpu_result *res;
+  const uint8_t *diffstr;
+  const smaltgpu_readstat *stat;      /* nreads */
+} smaltgpu_batch_out;
+
+/* ---- index (replaces hashTableRead hashidx.c:1257 + seqSetReadBinFil sequence.c:2521) ---- */
+int smaltgpu_index_load(smaltgpu_index **out, const char *prefix, int device);
+int smaltgpu_index_create(smaltgpu_index **out, const smaltgpu_index_desc *desc, int device);
+void smaltgpu_index_free(smaltgpu_index *ix);
+int smaltgpu_index_info(const smaltgpu_index *ix, smaltgpu_index_desc *desc_out); /* device pointers */
+void smaltgpu_params_default(smaltgpu_params *p, const smaltgpu_index *ix);
+
+/* ---- mapper (replaces rmapCreate rmap.c:1511 / rmapDelete :1597) ---- */
+int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_index *ix, uint32_t max_batch_reads,
+                           uint32_t max_read_len);
+void smaltgpu_mapper_free(smaltgpu_mapper *m);
+
+/* Map a block of reads (the unit processArgBlock smalt.c:1221 hands to a worker).  `bases`:
+ * concatenated ASCII reads, `quals`: concatenated phred+33 or NULL, `read_off`: nreads+1
+ * offsets.  Replaces nreads calls of rmapSingle (rmap.c:1648) + rmapGetData (:1634).  The
+ * returned arrays are owned by the mapper and valid until its next call. */
+int smaltgpu_map_batch(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals,
+                       const uint64_t *read_off, uint32_t nreads, const smaltgpu_params *par,
+                       smaltgpu_batch_out *out);
+
+/* Same with the inputs already resident in HBM (device pointers); results stay on the device
+ * until smaltgpu_fetch_results().  Used by bench.py so that the timed region starts with the
+ * reads in HBM. */
+int smaltgpu_map_batch_device(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_t *d_quals,
+                              const uint64_t *d_read_off, uint32_t nreads, uint64_t total_bases,
+                              const smaltgpu_params *par);
+int smaltgpu_fetch_results(smaltgpu_mapper *m, smaltgpu_batch_out *out);
+int smaltgpu_synchronize(smaltgpu_mapper *m);
+
+/* Per-kernel device time (ms, HIP events on the mapper's stream) and work counters of the last
+ * batch: names in smaltgpu_timer_name().  For bench.py's roofline object. */
+int smaltgpu_timers(const smaltgpu_mapper *m, double *ms, uint64_t *work, int n);
+const char *smaltgpu_timer_name(int i);
+
+/* Diagnostic: print the per-stage state of read `i` of the last batch in the line format of
+ * oracle/DUMPFORMAT.md into buf (returns bytes needed).  Requires smaltgpu_set_debug(m, 1)
+ * before the batch so that intermediate buffers are retained. */
+int smaltgpu_set_debug(smaltgpu_mapper *m, int level);
+long smaltgpu_dump_read(smaltgpu_mapper *m, uint32_t i, const char *name, char *buf, size_t bufsiz);
+
+/* Stand-alone kernel entry points used by the parity tests (host pointers in, host out). */
+int smaltgpu_sw_full_batch(smaltgpu_mapper *m, const uint8_t *qcodes, const uint32_t *q_off, const uint8_t *rcodes,
+                           const uint32_t *r_off, uint32_t ntask, const smaltgpu_params *par, int32_t *scores);
+
+const char *smaltgpu_last_error(void);
+int smaltgpu_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

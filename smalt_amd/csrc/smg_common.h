@@ -1,0 +1,131 @@
+// smg_common.h -- data layout shared by the host side and the HIP kernels of libsmaltgpu.
+// Names follow the reference's domain (seeds, hits, segments, candidates); `file:line`
+// citations refer to the reference tree (SMALT 0.7.6, src/).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SMG_HD __host__ __device__
+#else
+#define SMG_HD
+#endif
+
+namespace smg {
+
+enum : int { IDX_PERFECT = 0, IDX_HASH32MIX = 1 };
+enum : uint32_t { FLG_BEST = 0x02, FLG_SEQBYSEQ = 0x10, FLG_NOSHRTINFO = 0x20, FLG_SENSITIVE = 0x80 };
+// hit qualifiers per read offset (hashhit.h:57-65)
+enum : uint8_t { HQ_TERM = 0, HQ_NORMHIT = 1, HQ_MULTIHIT = 2, HQ_REPEAT = 3, HQ_NOHIT = 4, HQ_NONSTDNT = 5 };
+// HashHitInfo status bits (hashhit.c:84-92)
+enum : uint32_t { HI_REVERSE = 1, HI_SORTED = 2, HI_RANK = 4 };
+enum : uint8_t { CANDFLG_REVERSE = 1, CANDFLG_MMALI = 4 };                 // segment.h:50-58
+enum : int { SMG_ERR_CAP = -5, SMG_ERR_ASSERT = -6 };   // same values as SMALTGPU_ECAP / EINTERNAL
+enum : uint32_t { RCF_REVERSE = 1, RCF_SCORED = 2, RCF_BANDED = 4, RCF_ERR = 8 };
+
+enum : int {
+  HASH_MAXNHITS = 16 * 1024,       // rmap.c:50
+  NREPEATS = 4,                    // hashhit.c:42
+  MINHIT_PER_TUPLE = 16,           // hashhit.c:43
+  HITLST_MINSIZ = 8192, HITLST_BLKSZ = 16384, HITLST_LOGQLEN_FACT = 32,   // hashhit.c:45-48
+  HITINFO_MINSEEDNUM = 3, HITINFO_MAXCOVER_PERCENT = 80, HITINFO_MINCOVER_KMER = 2, // hashhit.c:53-56
+  HALFBIT = 31,                    // hashhit.h:68
+  SEGMENTING_DIFFSHIFT = 3, MAXIMUM_DEPTH = 8000, DEFAULT_TARGET_DEPTH = 200,
+  EDGE_BAND_FACTOR = 4, MAX_BANDEDGE_2POW = 4,                              // segment.c:119-141
+  MINLEN_QUERY_STRIPED = 32, BWSCAL_QLEN = 48,                              // rmap.c:83-86
+  DIR_COL = 1, DIR_ROW = 2, DIR_DIA = 3,                                    // alignment.c:53-59
+  DIFF_M = 0, DIFF_D = 1, DIFF_I = 2, DIFF_S = 3, DIFF_MAXMISMATCH = 61, DIFF_TYPSHIFT = 6, // diffstr.h:90-107
+  ALILEN_MIN = 5                                                            // alignment.c:50
+};
+
+// Sort key of one k-mer hit: strand(1) | seq(10) | diagonal(33) | q(20).  The low 53 bits are
+// the reference's packed hit word (hashhit.h:67-72: diagonal<<31 | q) with q narrowed to 20 bits.
+enum : int { KEY_QBITS = 20, KEY_DIAGBITS = 33, KEY_SEQBITS = 10 };
+constexpr uint64_t KEY_QMASK = (1ull << KEY_QBITS) - 1;
+constexpr uint64_t KEY_DIAGMASK = (1ull << KEY_DIAGBITS) - 1;
+constexpr uint64_t HALFMASK = 0x7FFFFFFFull;
+constexpr uint64_t SOFFSMASK = 0xFFFFFFFFull;
+
+struct DevIndex {                 // I1 + I2 image in HBM (hashidx.c:105-146, sequence.c:148-171)
+  int32_t k, s, typ, nbits_key, nbits_lo;
+  uint32_t nkeys, npos, nwords;
+  const uint32_t *idx, *pos, *wordidx, *posidx, *packed;
+  const uint64_t *sop;            // nseq+1 base offsets (device copy)
+  const uint32_t *seqlo;          // nseq+1: sop[i]/s, the k-mer serial where sequence i starts
+  int32_t nseq;
+  uint64_t totlen;
+};
+
+struct MapPar {                   // scalar arguments of rmapSingle (rmap.h:127-145)
+  int32_t ncut;
+  uint32_t min_cover;
+  int32_t min_swatscor, below_max, min_basq, target_depth, max_depth;
+  uint32_t flags;
+  int32_t match, mismatch, gap_init, gap_ext;   // signed scores (-4/-3 for gaps)
+};
+
+struct SeedRec { uint32_t posidx, nhits, qoffs; };                 // hashhit.c:148-162
+struct HitInfoHdr {                                                 // hashhit.c:164-213
+  uint32_t n_seeds, seed_rank, status, qlen;
+  uint32_t nhit_rank, nhit_tot, pad0, pad1;
+};
+
+struct SegSeed { uint64_t sqo; int32_t len; int32_t pad; };        // segment.c:162-192
+struct Segment { uint32_t ix; int32_t nseed; uint32_t cover; };    // segment.c:206-215
+struct HitRegion { uint32_t idx; int32_t num; };                   // segment.c:195-203
+
+struct SegCand {                                                    // segment.c:239-263
+  uint32_t qs, qe, rs, re;
+  int16_t shiftoffs, shift2mm, srange;
+  uint8_t flag, pad;
+  uint32_t cover;
+  int32_t nseg;
+  uint32_t hregix;
+  int32_t seqidx;
+};
+
+struct RCand {                                                      // rmap.c:111-126
+  uint64_t rs, re;          // window in sequence sqidx (or concatenated set if sqidx < 0)
+  uint32_t qs, qe;
+  int32_t band_l, band_r;
+  int32_t sqidx;
+  uint32_t flags;           // RCF_*
+  uint32_t cover;
+  int32_t swscor;
+};
+
+struct CandHdr {                                                    // segment.c:267-284 + rmap.c:1333-1338
+  uint32_t ncand, n_sort, n_mincover, max_cover, max2nd_cover;
+  uint32_t cover_deficit[2];
+  uint32_t rc_off;          // first RCand of this read in the pool
+  int32_t err;
+  uint32_t nhits[2];        // collected hits per strand (diagnostic)
+  uint32_t pad;
+};
+
+struct ReadCtl {                                                    // scalars of mapSingleRead (rmap.c:1373-1400)
+  int32_t max1, max2, n_scored;
+  int32_t bandwidth_min, min_swatscor, scorlen_min;
+  int32_t go;               // 1: run the traceback pass
+  int32_t pad;
+};
+
+struct Result {                                                     // results.c:121-160
+  int32_t swatscor;
+  uint32_t q_start, q_end;
+  uint32_t reverse;
+  uint64_t s_start, s_end;
+  int32_t sidx;
+  uint32_t stroffs, strlen;
+  uint32_t pad;
+};
+
+struct ReadStat {
+  int32_t swmax, sw2nd, nseg, nseg_tot;
+  uint32_t nhit, nhit_tot;
+  int32_t err;
+  uint32_t nres;
+  uint64_t res_off;         // first Result of this read in the pool
+  uint64_t dstr_off;
+};
+
+}  // namespace smg

@@ -1,0 +1,100 @@
+// smg_exec.h -- the execution model the per-read stage functions are written against.
+//
+// A read (or read-strand) is owned by ONE 64-lane wavefront (a 64-thread workgroup).  Stage
+// code is written once with the macros below:
+//   SMG_PAR_CHUNKS(base, n)  wave-uniform loop over chunks of SMG_NLANES items; inside, the
+//                            item of this lane is  base + SMG_LANE  (may be >= n)
+//   SMG_LANE0                the sequential sections (one lane; the reference's order matters)
+//   SMG_SYNC()               workgroup barrier + memory visibility between the two
+// On the device SMG_NLANES = 64.  The same source also compiles for the host with
+// SMG_NLANES = 1 (tests/hostemu): that build exists to unit-test this logic on a machine
+// without a GPU and is never part of libsmaltgpu.so.
+#pragma once
+#include <stdint.h>
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <algorithm>
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SMG_LANE ((uint32_t)threadIdx.x)
+#define SMG_NLANES 64u
+#define SMG_SYNC() __syncthreads()
+#else
+#define SMG_LANE 0u
+#define SMG_NLANES 1u
+#define SMG_SYNC() do {} while (0)
+#endif
+
+#define SMG_PAR_CHUNKS(base, n) for (uint32_t base = 0; base < (uint32_t)(n); base += SMG_NLANES)
+#define SMG_LANE0 if (SMG_LANE == 0)
+
+namespace smg {
+
+// Ordered stream compaction: lanes with flag get consecutive slots in lane order.
+// `counter` is wave-uniform.
+SMG_HD inline uint32_t compact_slot(bool flag, uint32_t &counter) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned long long m = __ballot(flag);
+  uint32_t slot = counter + (uint32_t)__popcll(m & ((1ull << SMG_LANE) - 1ull));
+  counter += (uint32_t)__popcll(m);
+  return slot;
+#else
+  uint32_t slot = counter;
+  if (flag) counter++;
+  return slot;
+#endif
+}
+
+SMG_HD inline uint32_t wave_sum_u32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+#else
+  return v;
+#endif
+}
+
+SMG_HD inline bool wave_any(bool f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __ballot(f) != 0ull;
+#else
+  return f;
+#endif
+}
+
+SMG_HD inline uint32_t bcast_lane0(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#else
+  return v;
+#endif
+}
+
+// In-place ascending sort of n 64-bit keys by the whole wave (n need not be a power of two;
+// the caller provides capacity for the next power of two, padded here with ~0).
+SMG_HD inline void wave_sort_u64(uint64_t *a, uint32_t n) {
+  if (n < 2) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t np = 1;
+  while (np < n) np <<= 1;
+  for (uint32_t i = n + SMG_LANE; i < np; i += SMG_NLANES) a[i] = ~0ull;
+  SMG_SYNC();
+  for (uint32_t k = 2; k <= np; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t t = SMG_LANE; t < (np >> 1); t += SMG_NLANES) {
+        uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // index with bit j clear
+        uint32_t p = i | j;
+        uint64_t x = a[i], y = a[p];
+        bool up = ((i & k) == 0);
+        if ((x > y) == up) { a[i] = y; a[p] = x; }
+      }
+      SMG_SYNC();
+    }
+  }
+#else
+  // host build: any correct sort gives the same array (keys are plain integers)
+  std::sort(a, a + n);
+#endif
+}
+
+}  // namespace smg

@@ -1,0 +1,799 @@
+// smg_stages.hpp -- the per-read stages of the seed-and-extend path, each executed by the
+// wavefront that owns the read (see smg_exec.h for the execution model).
+//   stage_seed   S1 + S2   k-mer words of both strands, index lookups, rarity ranking, budget
+//   stage_cands  S3 - S7   hit gather + sort, binning into candidates, ranking, windows/bands
+//   stage_replay O1        sequential control over the scores of the ranked candidates
+//   stage_align  K3        banded Smith-Waterman with traceback, recursive split, result list
+// The wide Smith-Waterman score pass (K2a) is a kernel of its own (smg_sw.hip).
+// `file:line` citations refer to the reference tree (SMALT 0.7.6, src/).
+#pragma once
+#include <math.h>
+#include "smg_common.h"
+#include "smg_exec.h"
+#include "smg_logic.hpp"
+
+namespace smg {
+
+struct Batch {                          // one block of reads resident in HBM
+  uint32_t nreads, qmax;                // qmax: stride of the per-read-strand arrays (>= longest read + 1)
+  const uint8_t *codes;                 // 3-bit codes of all reads, forward orientation, concatenated
+  const uint8_t *codes_rc;              // reverse complement of each read, same offsets
+  const uint8_t *qual;                  // phred+33 or null
+  const uint64_t *read_off;             // nreads + 1
+  // S1/S2 outputs, indexed by rs = 2*read + strand
+  HitInfoHdr *hi;                       // [2*nreads]
+  SeedRec *seeds;                       // [2*nreads][qmax], rank order
+  uint8_t *qmask;                       // [2*nreads][qmax]
+  // S3-S7 outputs
+  CandHdr *ch;                          // [nreads]
+  RCand *rcpool; uint32_t rccap; uint32_t *rc_count;    // bump-allocated ranked candidates
+  // O1
+  ReadCtl *ctl;                         // [nreads]
+  // K3 outputs
+  ReadStat *stat;                       // [nreads]
+  Result *respool; uint64_t rescap; unsigned long long *res_count;
+  uint8_t *dstrpool; uint64_t dstrcap; unsigned long long *dstr_count;
+  int32_t *err_flag;                    // batch-wide first error
+};
+
+SMG_HD inline uint32_t read_len(const Batch &b, uint32_t r) { return (uint32_t)(b.read_off[r + 1] - b.read_off[r]); }
+
+SMG_HD inline uint32_t atomic_add_u32(uint32_t *p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return atomicAdd(p, v);
+#else
+  uint32_t o = *p; *p += v; return o;
+#endif
+}
+SMG_HD inline unsigned long long atomic_add_u64(unsigned long long *p, unsigned long long v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return atomicAdd(p, v);
+#else
+  unsigned long long o = *p; *p += v; return o;
+#endif
+}
+
+// =======================================================================================
+// stage_seed: S1 (hashhit.c:480-657 collectHitInfo) + S2 (hashhit.c:1007-1080)
+// =======================================================================================
+struct SeedScratch {          // per wave; capacity qmax each unless noted
+  uint32_t *vt;               // offsets of k-mers without non-standard / low-quality bases
+  uint64_t *vw;               // their words
+  uint32_t *key, *sidx;       // nhits per seed (offset order, then rarity-sorted) + companion
+  uint32_t *sposidx, *sqoffs; // seeds in offset order
+  uint32_t *qbr;              // read offset by rank
+  uint32_t *frame_cnt;        // [s]
+  uint32_t *frame_rank;       // [s * stride]
+  uint8_t *qbuf;              // [qmax]
+  uint32_t stride;
+};
+
+SMG_HD inline size_t seed_scratch_bytes(uint32_t qmax, int s) {
+  uint32_t stride = qmax / (uint32_t)s + 2;
+  return (size_t)qmax * (4 + 8 + 4 + 4 + 4 + 4 + 4 + 1) + (size_t)s * 4 + (size_t)s * stride * 4 + 64;
+}
+
+SMG_HD inline SeedScratch seed_scratch_carve(uint8_t *base, uint32_t qmax, int s) {
+  SeedScratch x;
+  x.vw = (uint64_t *)base; base += (size_t)qmax * 8;
+  x.vt = (uint32_t *)base; base += (size_t)qmax * 4;
+  x.key = (uint32_t *)base; base += (size_t)qmax * 4;
+  x.sidx = (uint32_t *)base; base += (size_t)qmax * 4;
+  x.sposidx = (uint32_t *)base; base += (size_t)qmax * 4;
+  x.sqoffs = (uint32_t *)base; base += (size_t)qmax * 4;
+  x.qbr = (uint32_t *)base; base += (size_t)qmax * 4;
+  x.stride = qmax / (uint32_t)s + 2;
+  x.frame_cnt = (uint32_t *)base; base += (size_t)s * 4;
+  x.frame_rank = (uint32_t *)base; base += (size_t)s * x.stride * 4;
+  x.qbuf = base;
+  return x;
+}
+
+SMG_HD inline void stage_seed(const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t r, uint32_t st, SeedScratch &x) {
+  const uint32_t rs = 2 * r + st;
+  const uint32_t qlen = read_len(b, r);
+  const uint8_t *codes = b.codes + b.read_off[r];
+  const uint8_t *qual = b.qual ? b.qual + b.read_off[r] : nullptr;
+  uint8_t *qmask = b.qmask + (size_t)rs * b.qmax;
+  SeedRec *out = b.seeds + (size_t)rs * b.qmax;
+  HitInfoHdr &hdr = b.hi[rs];
+  const int k = ix.k, s = ix.s;
+  const bool noshort = (p.flags & FLG_NOSHRTINFO) != 0;
+  const uint32_t ncut = noshort ? 0u : (uint32_t)(p.ncut > 0 ? p.ncut : 0);
+  const int minqval = p.min_basq + 33;
+
+  if (qlen < (uint32_t)k) {          // ERRCODE_SHORTSEQ, swallowed by rmapSingle (rmap.c:1736)
+    SMG_LANE0 { hdr.n_seeds = 0; hdr.seed_rank = 0; hdr.status = st ? HI_REVERSE : 0; hdr.qlen = qlen; hdr.nhit_rank = hdr.nhit_tot = 0; }
+    return;
+  }
+  const uint32_t nk = qlen - (uint32_t)k + 1;
+  const uint64_t wordmask = (1ull << (2 * k)) - 1;
+
+  // (1) words + validity of every k-mer start t; ordered compaction of the valid ones
+  uint32_t nvalid = 0;
+  SMG_PAR_CHUNKS(base, nk) {
+    uint32_t t = base + SMG_LANE;
+    bool valid = false;
+    uint64_t w = 0;
+    if (t < nk) {
+      valid = true;
+      for (int i = 0; i < k; i++) {
+        uint32_t c = codes[t + (uint32_t)i];
+        if ((c & 4) || (qual && qual[t + (uint32_t)i] < minqval)) valid = false;
+        // forward: first base in the top bits; reverse strand: complement of base t+i at bit 2i
+        if (st) w |= ((uint64_t)((c ^ 3u) & 3u)) << (2 * i);
+        else w = (w << 2) | (c & 3u);
+      }
+      w &= wordmask;
+      if (!valid) qmask[t] = HQ_NONSTDNT;
+    }
+    uint32_t slot = compact_slot(valid, nvalid);
+    if (valid) { x.vt[slot] = t; x.vw[slot] = w; }
+  }
+  SMG_PAR_CHUNKS(base, qlen - nk + 1) {           // tail offsets + terminator (hashhit.c:652-653)
+    uint32_t t = nk + base + SMG_LANE;
+    if (t <= qlen && t < b.qmax) qmask[t] = HQ_TERM;
+  }
+  SMG_SYNC();
+
+  // (2) repeat filter over the previous NREPEATS looked-at words (hashhit.c:325-340), then lookup
+  uint32_t nseeds = 0;
+  SMG_PAR_CHUNKS(base, nvalid) {
+    uint32_t j = base + SMG_LANE;
+    bool hit = false;
+    uint32_t t = 0, nh = 0, posidx = 0;
+    if (j < nvalid) {
+      t = x.vt[j];
+      uint64_t w = x.vw[j];
+      bool rep = false;
+      for (uint32_t d = 1; d <= (uint32_t)NREPEATS && d <= j; d++) if (x.vw[j - d] == w) rep = true;
+      if (rep) qmask[t] = HQ_REPEAT;
+      else {
+        nh = index_lookup(ix, w, &posidx);
+        if (nh < 1) qmask[t] = HQ_NOHIT;
+        else if (ncut > 0 && nh > ncut) qmask[t] = HQ_MULTIHIT;
+        else { qmask[t] = HQ_NORMHIT; hit = true; }
+      }
+    }
+    uint32_t slot = compact_slot(hit, nseeds);
+    if (hit) { x.key[slot] = nh; x.sidx[slot] = slot; x.sposidx[slot] = posidx; x.sqoffs[slot] = t; }
+  }
+  SMG_SYNC();
+
+  // (3) rarity ranking + budget: sequential (sort.c:233 tie order; hashhit.c:769)
+  SMG_LANE0 {
+    uint32_t status = st ? HI_REVERSE : 0, seed_rank = 0;
+    if (!noshort) {
+      if (nseeds <= 1) { status |= HI_SORTED; seed_rank = nseeds; }
+      else {
+        sort2_u32((int)nseeds, x.key, x.sidx);
+        status |= HI_SORTED;
+        for (uint32_t i = 0; i < nseeds; i++) x.qbr[i] = x.sqoffs[x.sidx[i]];
+        uint32_t mincover = (uint32_t)(HITINFO_MINCOVER_KMER * k + s);
+        uint32_t maxcover = qlen * HITINFO_MAXCOVER_PERCENT / 100;
+        if (maxcover < (uint32_t)(k + s)) maxcover = (uint32_t)(k + s);
+        else if (maxcover > qlen - (uint32_t)s) maxcover = qlen - (uint32_t)s;
+        if (mincover > maxcover) { mincover = 0; maxcover = qlen; }
+        build_frames(nseeds, x.qbr, s, x.frame_cnt, x.frame_rank, x.stride);
+        seed_rank = seed_max_rank(nseeds, x.key, x.qbr, k, s, qlen, mincover, maxcover, (uint32_t)HASH_MAXNHITS,
+                                  x.frame_cnt, x.frame_rank, x.stride, x.qbuf);
+        status |= HI_RANK;
+      }
+    }
+    uint32_t ns = seed_rank > 0 ? seed_rank : nseeds, nr = 0, i;   // hashhit.c:1200-1219
+    for (i = 0; i < ns; i++) nr += x.key[i];
+    hdr.nhit_rank = nr;
+    for (; i < nseeds; i++) nr += x.key[i];
+    hdr.nhit_tot = nr;
+    hdr.n_seeds = nseeds; hdr.seed_rank = seed_rank; hdr.status = status; hdr.qlen = qlen;
+  }
+  SMG_SYNC();
+  SMG_PAR_CHUNKS(base, nseeds) {
+    uint32_t i = base + SMG_LANE;
+    if (i < nseeds) {
+      uint32_t src = x.sidx[i];
+      SeedRec sr; sr.posidx = x.sposidx[src]; sr.nhits = x.key[i]; sr.qoffs = x.sqoffs[src];
+      out[i] = sr;
+    }
+  }
+}
+
+// =======================================================================================
+// stage_cands: S3 (hashhit.c:1416-1769), S4/S5 (segment.c:396-1223), S6 (:1616), S7 (:1861)
+// =======================================================================================
+struct CandScratch {          // per slot, in HBM
+  uint64_t *keys;             // [hcap]  hit sort keys, then packed hit words grouped by (strand, seq)
+  uint32_t hcap;              // power of two
+  uint32_t *grp_first, *grp_cnt;   // [2 * ngrp]  group = strand * ngrp + seq
+  uint32_t ngrp;              // nseq in sequence-by-sequence mode, else 1
+  FillDecision *dec;          // [2 * ngrp]
+  HitRegion *hreg; SegSeed *sseed; Segment *segm; uint32_t segcap;
+  SegCand *cand; uint32_t candcap;
+  uint32_t *sort_keys, *sort_idx;  // [candcap]
+  uint8_t *mask;              // [qmax]
+  uint8_t *hlmask;            // [2][qmax + 8] hit-list masks of the two strands (concatenated mode)
+  uint32_t *qbr;              // [qmax]
+  uint32_t *frame_cnt, *frame_rank; uint32_t stride;
+  uint8_t *qbuf;              // [qmax]
+};
+
+SMG_HD inline size_t cand_scratch_bytes(uint32_t qmax, int s, uint32_t hcap, uint32_t ngrp, uint32_t segcap, uint32_t candcap) {
+  uint32_t stride = qmax / (uint32_t)s + 2;
+  size_t n = (size_t)hcap * 8 + (size_t)ngrp * 2 * (4 + 4 + sizeof(FillDecision)) + (size_t)segcap * (sizeof(HitRegion) + sizeof(SegSeed) + sizeof(Segment)) +
+             (size_t)candcap * (sizeof(SegCand) + 8) + (size_t)qmax * (1 + 2 + 4 + 1) + 32 + (size_t)s * 4 + (size_t)s * stride * 4;
+  return (n + 255) & ~(size_t)255;
+}
+
+SMG_HD inline CandScratch cand_scratch_carve(uint8_t *base, uint32_t qmax, int s, uint32_t hcap, uint32_t ngrp, uint32_t segcap, uint32_t candcap) {
+  CandScratch x;
+  x.hcap = hcap; x.ngrp = ngrp; x.segcap = segcap; x.candcap = candcap;
+  x.keys = (uint64_t *)base; base += (size_t)hcap * 8;
+  x.sseed = (SegSeed *)base; base += (size_t)segcap * sizeof(SegSeed);
+  x.dec = (FillDecision *)base; base += (size_t)ngrp * 2 * sizeof(FillDecision);
+  x.hreg = (HitRegion *)base; base += (size_t)segcap * sizeof(HitRegion);
+  x.segm = (Segment *)base; base += (size_t)segcap * sizeof(Segment);
+  x.cand = (SegCand *)base; base += (size_t)candcap * sizeof(SegCand);
+  x.sort_keys = (uint32_t *)base; base += (size_t)candcap * 4;
+  x.sort_idx = (uint32_t *)base; base += (size_t)candcap * 4;
+  x.grp_first = (uint32_t *)base; base += (size_t)ngrp * 2 * 4;
+  x.grp_cnt = (uint32_t *)base; base += (size_t)ngrp * 2 * 4;
+  x.qbr = (uint32_t *)base; base += (size_t)qmax * 4;
+  x.stride = qmax / (uint32_t)s + 2;
+  x.frame_cnt = (uint32_t *)base; base += (size_t)s * 4;
+  x.frame_rank = (uint32_t *)base; base += (size_t)s * x.stride * 4;
+  x.mask = base; base += qmax;
+  x.hlmask = base; base += 2 * ((size_t)qmax + 8);
+  x.qbuf = base;
+  return x;
+}
+
+// sequence of k-mer serial number `pos`: largest j with seqlo[j] <= pos (ties: last)
+SMG_HD inline uint32_t seq_of_pos(const uint32_t *seqlo, int nseq, uint32_t pos) {
+  uint32_t lo = 0, hi = (uint32_t)nseq;            // answer in [0, nseq-1]
+  while (hi - lo > 1) { uint32_t m = (lo + hi) >> 1; if (seqlo[m] <= pos) lo = m; else hi = m; }
+  return lo;
+}
+
+SMG_HD inline void stage_cands(const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t r, CandScratch &x) {
+  const uint32_t qlen = read_len(b, r);
+  CandHdr &ch = b.ch[r];
+  const int k = ix.k, s = ix.s;
+  const bool seqbyseq = (p.flags & FLG_SEQBYSEQ) != 0;
+  const uint32_t ngrp = x.ngrp;
+
+  if (qlen < (uint32_t)k) {
+    SMG_LANE0 { ch.ncand = ch.n_sort = ch.n_mincover = ch.max_cover = ch.max2nd_cover = 0; ch.cover_deficit[0] = ch.cover_deficit[1] = 0; ch.rc_off = 0; ch.err = 0; ch.nhits[0] = ch.nhits[1] = 0; }
+    return;
+  }
+  // calcMinKtup (rmap.c:240-247) and the coverage threshold of mapSingleRead (:1283-1289)
+  uint32_t min_cover = p.min_cover;
+  const uint32_t min_ktup = (min_cover >= (uint32_t)(k + s)) ? (min_cover - (uint32_t)k) / (uint32_t)s : 1u;
+  min_cover = (min_ktup - 1) * (uint32_t)s + (uint32_t)k;
+  const int mismatchdiff = p.match - p.mismatch;
+  uint32_t mincov_below_max;
+  if (p.below_max < 0) mincov_below_max = qlen - 1;
+  else {
+    mincov_below_max = ((uint32_t)(p.below_max / mismatchdiff)) * (uint32_t)s;
+    if (mincov_below_max < (uint32_t)k || (p.flags & FLG_BEST)) mincov_below_max = (uint32_t)(k + 2 * (s - 1));
+  }
+  int nhits_alloc, nhits_max;
+  {   // initHitList (hashhit.c:1262-1288); the reference keeps its allocation across reads (it only
+      // grows, in blocks of 16384): this is the stateless value it has when a run has one read length.
+    double t = (double)qlen * log((double)qlen) * HITLST_LOGQLEN_FACT;   // hashhit.c:1266
+    long long target = (long long)t;
+    if (target > 0x7fffffffLL) target = 0x7fffffffLL; else if (target < HITLST_MINSIZ) target = HITLST_MINSIZ;
+    long long alloc = HITLST_BLKSZ;
+    if (target > alloc) alloc = ((target + HITLST_BLKSZ - 1) / HITLST_BLKSZ) * HITLST_BLKSZ;
+    nhits_alloc = (int)alloc; nhits_max = (int)target;
+  }
+  const uint32_t ncut = (uint32_t)(p.ncut > 0 ? p.ncut : 0);
+  int err = 0;
+  uint32_t nkeys = 0;
+
+  // ---- S3: decide which ranked seeds contribute per (strand, sequence), then gather ----
+  for (uint32_t st = 0; st < 2; st++) {
+    const uint32_t rs = 2 * r + st;
+    const HitInfoHdr hdr = b.hi[rs];
+    const SeedRec *seeds = b.seeds + (size_t)rs * b.qmax;
+    uint8_t *qmask = b.qmask + (size_t)rs * b.qmax;
+    const uint32_t n_use = hdr.seed_rank > 0 ? hdr.seed_rank : hdr.n_seeds;
+    // total hits of the usable seeds
+    uint32_t tot = 0;
+    SMG_PAR_CHUNKS(base, n_use) {
+      uint32_t n = base + SMG_LANE;
+      if (n < n_use && !(ncut > 0 && seeds[n].nhits > ncut)) tot += seeds[n].nhits;
+    }
+    tot = wave_sum_u32(tot);
+    FillDecision *dec = x.dec + st * ngrp;
+    if (seqbyseq) {
+      if (tot <= (uint32_t)nhits_alloc) {
+        SMG_PAR_CHUNKS(base, ngrp) { uint32_t g = base + SMG_LANE; if (g < ngrp) { dec[g].n_used = n_use; dec[g].m_final = ncut; } }
+        SMG_PAR_CHUNKS(base, n_use) {     // hashhit.c:1472-1481: over-cut seeds are flagged (-x mode only)
+          uint32_t n = base + SMG_LANE;
+          if (n < n_use && ncut > 0 && seeds[n].nhits > ncut) qmask[seeds[n].qoffs] = HQ_MULTIHIT;
+        }
+      } else {
+        // rare: replay the allocation-boundary retry protocol per sequence (one lane each)
+        SMG_PAR_CHUNKS(base, ngrp) {
+          uint32_t g = base + SMG_LANE;
+          if (g < ngrp) {
+            uint64_t lo = ix.sop[g] / (uint64_t)s, hi = ix.sop[g + 1] / (uint64_t)s;
+            if (hi > 0xFFFFFFFFull) hi = 0xFFFFFFFFull;
+            dec[g] = fill_decide(ix, seeds, n_use, (uint32_t)lo, (uint32_t)hi, ncut, nhits_alloc, qmask);
+          }
+        }
+      }
+    } else {
+      // hashCollectHitsUsingCutoff (hashhit.c:1593-1689): ceiling retry on the summed hits
+      SMG_LANE0 {
+        uint32_t m = ncut, n_used = 0;
+        for (;;) {
+          uint32_t total = 0, i;
+          bool ceiling = false;
+          uint8_t *hlmask = x.hlmask + (size_t)st * (b.qmax + 8);
+          for (uint32_t q = 0; q < qlen; q++) hlmask[q] = HQ_NOHIT;
+          hlmask[qlen] = 0;
+          for (i = 0; i < n_use; i++) {
+            uint32_t nh = seeds[i].nhits;
+            if (nh < 1) continue;
+            if (m > 0 && nh > m) { hlmask[seeds[i].qoffs] = HQ_MULTIHIT; continue; }
+            if ((int)(total + nh) > nhits_max) { ceiling = true; break; }
+            hlmask[seeds[i].qoffs] = HQ_NORMHIT;
+            total += nh;
+          }
+          n_used = i;
+          uint32_t mf = m;
+          m /= 2;
+          if (!(ceiling && m > (uint32_t)MINHIT_PER_TUPLE)) { dec[0].n_used = n_used; dec[0].m_final = mf; break; }
+        }
+      }
+    }
+    SMG_SYNC();
+    // gather: lanes stride over the position list of one seed at a time (coalesced pos[] reads)
+    const uint32_t key_first = nkeys;
+    for (uint32_t n = 0; n < n_use; n++) {
+      const SeedRec sd = seeds[n];
+      const uint32_t *posp;
+      const uint32_t nh = index_positions(ix, sd.posidx, &posp);
+      if (!seqbyseq) {
+        if (n >= dec[0].n_used || (dec[0].m_final > 0 && sd.nhits > dec[0].m_final) || sd.nhits < 1) continue;
+        if (nkeys + nh > x.hcap) { err = SMG_ERR_CAP; break; }
+        SMG_PAR_CHUNKS(base, nh) {
+          uint32_t i = base + SMG_LANE;
+          if (i < nh) x.keys[nkeys + i] = ((uint64_t)st << 63) | (hit_diag(st != 0, posp[i], sd.qoffs, s) << KEY_QBITS) | sd.qoffs;
+        }
+        nkeys += nh;
+      } else {
+        if (ncut > 0 && sd.nhits > ncut) continue;
+        uint32_t cnt = 0;
+        SMG_PAR_CHUNKS(base, nh) {
+          uint32_t i = base + SMG_LANE;
+          bool take = false;
+          uint64_t key = 0;
+          if (i < nh) {
+            uint32_t pos = posp[i];
+            uint32_t g = seq_of_pos(ix.seqlo, ix.nseq, pos);
+            const FillDecision d = dec[g];
+            take = n < d.n_used && !(d.m_final > 0 && sd.nhits > d.m_final) && pos < ix.seqlo[ix.nseq];
+            key = ((uint64_t)st << 63) | ((uint64_t)g << (KEY_DIAGBITS + KEY_QBITS)) | (hit_diag(st != 0, pos, sd.qoffs, s) << KEY_QBITS) | sd.qoffs;
+          }
+          uint32_t slot = compact_slot(take && nkeys + cnt < x.hcap, cnt);
+          if (take && nkeys + slot < x.hcap) x.keys[nkeys + slot] = key;
+          else if (take) err = SMG_ERR_CAP;
+        }
+        nkeys += cnt;
+      }
+    }
+    SMG_LANE0 { ch.nhits[st] = nkeys - key_first; }
+    SMG_SYNC();
+  }
+  if (wave_any(err != 0)) err = SMG_ERR_CAP;
+  // ---- sort by (strand, seq, diagonal, q): only the multiset matters (sort.c:415 sorts plain words)
+  wave_sort_u64(x.keys, nkeys);
+  SMG_SYNC();
+  // group table + conversion to the reference's packed hit word (diagonal << 31 | q)
+  SMG_PAR_CHUNKS(base, 2 * ngrp) { uint32_t g = base + SMG_LANE; if (g < 2 * ngrp) { x.grp_first[g] = 0; x.grp_cnt[g] = 0; } }
+  SMG_SYNC();
+  SMG_PAR_CHUNKS(base, nkeys) {
+    uint32_t i = base + SMG_LANE;
+    if (i < nkeys) {
+      uint64_t key = x.keys[i];
+      uint32_t g = (uint32_t)(key >> (KEY_DIAGBITS + KEY_QBITS));     // strand * 1024 + seq
+      uint32_t gi = (g >> KEY_SEQBITS) * ngrp + (g & ((1u << KEY_SEQBITS) - 1));
+      bool first = (i == 0) || ((uint32_t)(x.keys[i - 1] >> (KEY_DIAGBITS + KEY_QBITS)) != g);
+      bool last = (i + 1 == nkeys) || ((uint32_t)(x.keys[i + 1] >> (KEY_DIAGBITS + KEY_QBITS)) != g);
+      if (first) x.grp_first[gi] = i;
+      if (last) x.grp_cnt[gi] = i + 1;     // end index for now
+    }
+  }
+  SMG_SYNC();
+  SMG_PAR_CHUNKS(base, nkeys) {
+    uint32_t i = base + SMG_LANE;
+    if (i < nkeys) {
+      uint64_t key = x.keys[i];
+      x.keys[i] = (((key >> KEY_QBITS) & KEY_DIAGMASK) << HALFBIT) | (key & KEY_QMASK);
+    }
+  }
+  SMG_PAR_CHUNKS(base, 2 * ngrp) {
+    uint32_t g = base + SMG_LANE;
+    if (g < 2 * ngrp && x.grp_cnt[g]) x.grp_cnt[g] -= x.grp_first[g];
+  }
+  SMG_SYNC();
+
+  // ---- S4-S6 on one lane: the candidate order feeds an unstable sort and must be the reference's ----
+  SMG_LANE0 {
+    CandSet cs; cs.cand = x.cand; cs.ncand = 0; cs.cap = x.candcap; cs.max_cover = cs.max2nd_cover = 0;
+    SegLst sl; sl.hreg = x.hreg; sl.seed = x.sseed; sl.segm = x.segm; sl.cap = x.segcap; sl.nhreg = sl.nseed = sl.nsegm = 0;
+    for (uint32_t st = 0; st < 2 && !err; st++) {
+      for (uint32_t g = 0; g < ngrp && !err; g++) {
+        uint32_t cnt = x.grp_cnt[st * ngrp + g];
+        if (!cnt && seqbyseq) continue;
+        const uint64_t *dat = x.keys + x.grp_first[st * ngrp + g];
+        if (seglst_fill(sl, min_ktup, dat, (int)cnt, qlen, seqbyseq ? nullptr : x.hlmask + (size_t)st * (b.qmax + 8), k, s)) { err = SMG_ERR_CAP; break; }
+        int rv = cands_add_fast(cs, x.mask, sl, qlen, k, s, st != 0, min_cover, seqbyseq ? (int32_t)g : -1);
+        if (rv) { err = (rv == -2) ? SMG_ERR_CAP : SMG_ERR_ASSERT; break; }
+      }
+    }
+    // cover deficits (hashhit.c:1096) need the frames of each strand
+    uint32_t cdf[2] = {0, 0};
+    for (uint32_t st = 0; st < 2; st++) {
+      const uint32_t rs = 2 * r + st;
+      const HitInfoHdr hdr = b.hi[rs];
+      const SeedRec *seeds = b.seeds + (size_t)rs * b.qmax;
+      if (hdr.status & HI_RANK) {
+        for (uint32_t i = 0; i < hdr.n_seeds; i++) x.qbr[i] = seeds[i].qoffs;
+        build_frames(hdr.n_seeds, x.qbr, s, x.frame_cnt, x.frame_rank, x.stride);
+      }
+      cdf[st] = cover_deficit(hdr.status, hdr.seed_rank, qlen, b.qmask + (size_t)rs * b.qmax, x.qbr, k, s, x.frame_cnt,
+                              x.frame_rank, x.stride, x.qbuf);
+    }
+    uint32_t n_mincover = 0, n_sort = 0;
+    if (!err && cands_stats(cs, cdf[0], s, mincov_below_max, (uint32_t)p.target_depth, (uint32_t)p.max_depth,
+                            (p.flags & FLG_SENSITIVE) != 0, x.sort_keys, x.sort_idx, &n_mincover, &n_sort)) err = SMG_ERR_ASSERT;
+    ch.ncand = cs.ncand; ch.n_sort = err ? 0 : n_sort; ch.n_mincover = n_mincover;
+    ch.max_cover = cs.max_cover; ch.max2nd_cover = cs.max2nd_cover;
+    ch.cover_deficit[0] = cdf[0]; ch.cover_deficit[1] = cdf[1];
+    ch.err = err;
+    ch.rc_off = atomic_add_u32(b.rc_count, ch.n_sort);
+    if (ch.rc_off + ch.n_sort > b.rccap) { ch.err = SMG_ERR_CAP; ch.n_sort = 0; }
+  }
+  SMG_SYNC();
+  // ---- S7: windows and bands of the ranked candidates ----
+  const uint32_t n_sort = ch.n_sort, rc_off = ch.rc_off;
+  SMG_PAR_CHUNKS(base, n_sort) {
+    uint32_t i = base + SMG_LANE;
+    if (i < n_sort) {
+      RCand c;
+      if (cand_offsets(c, x.cand[x.sort_idx[i]], ix, qlen)) { c.flags |= RCF_ERR; c.rs = c.re = 0; c.qs = c.qe = 0; c.band_l = c.band_r = 0; }
+      b.rcpool[rc_off + i] = c;
+    }
+  }
+}
+
+// =======================================================================================
+// K2b on one lane: alignSmiWatBandFast (alignment.c:1029-1233) over a window read straight
+// from the packed reference.  Hp/Ep: q_totlen + 2 ints each.  NB unlike K3 the left band
+// edge never advances once it starts clipped at q_left (delta_band_start is not decremented).
+// =======================================================================================
+SMG_HD inline int band_fast_scalar(const Band &bp, const uint8_t *q, const uint32_t *packed, uint64_t rbase,
+                                   const int8_t *M /* [8][8] */, int gi, int ge, int *Hp, int *Ep) {
+  int delta_start, j_start, j_len, currH = 0, best = 0;
+  if (bp.q_left > bp.l_edge) { delta_start = bp.q_left - bp.l_edge; j_start = bp.q_left; }
+  else { delta_start = 0; j_start = bp.l_edge; }
+  j_len = bp.r_edge + 1;
+  for (int j = j_start; j < bp.q_len; j++) Hp[j] = Ep[j] = 0;
+  for (int i = bp.s_left; i < bp.s_len; i++) {
+    const int8_t *w = M + 8 * ref_code(packed, rbase + (uint64_t)i);
+    int F = 0;
+    for (int j = j_start; j < j_len; j++) {
+      int H = currH + w[q[j] & 7];
+      currH = Hp[j];
+      bool cand;
+      cell_update(Hp[j], Ep[j], F, H, gi, ge, cand);
+      if (cand && H > best) best = H;
+    }
+    if (delta_start > 0) currH = 0;
+    else { currH = Hp[j_start]; j_start++; }
+    if (j_len < bp.q_len) j_len++;
+  }
+  return best;
+}
+
+// K2a on one lane (fallback for reads the DPP kernel does not cover): textbook Gotoh maximum
+// (swsimd.c:868).  H/E: qlen ints each.
+SMG_HD inline int sw_full_scalar(const uint8_t *q, uint32_t qlen, const uint32_t *packed, uint64_t rbase, uint32_t rlen,
+                                 const int8_t *M, int gi, int ge, int *H, int *E) {
+  int best = 0;
+  for (uint32_t j = 0; j < qlen; j++) H[j] = E[j] = 0;
+  for (uint32_t i = 0; i < rlen; i++) {
+    const int8_t *w = M + 8 * ref_code(packed, rbase + i);
+    int diag = 0, F = 0;
+    for (uint32_t j = 0; j < qlen; j++) {
+      int h = diag + w[q[j] & 7];
+      if (h < 0) h = 0;
+      if (h > best) best = h;
+      if (E[j] > h) h = E[j];
+      if (F > h) h = F;
+      diag = H[j];
+      H[j] = h;
+      int t = h - gi;
+      int e = E[j] - ge; if (e < t) e = t; if (e < 0) e = 0; E[j] = e;
+      F -= ge; if (F < t) F = t; if (F < 0) F = 0;
+    }
+  }
+  return best;
+}
+
+SMG_HD inline void score_matrix(int8_t *M /* [8][8] */, int match, int mismatch) {   // score.c:138-173
+  for (int i = 0; i < 8; i++)
+    for (int j = 0; j < 8; j++) {
+      int v;
+      if (i >= 6 || j >= 6 || i == 5 || j == 5) v = 0;          // alphabet "ACGTXN": N rows/cols 0
+      else if (i == 4 || j == 4) v = mismatch - match;          // X
+      else v = (i == j) ? match : mismatch;
+      M[i * 8 + j] = (int8_t)v;
+    }
+}
+
+// =======================================================================================
+// stage_replay: O1 for one read (one THREAD per read)
+// =======================================================================================
+SMG_HD inline void stage_replay(const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t r) {
+  const CandHdr ch = b.ch[r];
+  ReadCtl ctl;
+  ctl.pad = 0;
+  replay_scores(ctl, b.rcpool + ch.rc_off, ch.n_sort, ch.cover_deficit, p, ix.s, ix.k, read_len(b, r));
+  if (ch.err) ctl.go = 0;
+  b.ctl[r] = ctl;
+}
+
+// =======================================================================================
+// stage_align: alignRMAPCANDFull (rmap.c:790-928) -> aliSmiWatInBand (alignment.c:1548) ->
+// alignSmiWatBandRecursive (:1300) -> alignSmiWatBand (:788) + makeMetaFromTrack (:628) ->
+// resultSetAddFromAli (results.c:1852).
+// =======================================================================================
+struct AlignScratch {
+  int *Hp, *Ep;               // [qmax + 2]
+  uint8_t *win; uint32_t wincap;
+  uint8_t *dir; uint64_t dircap;
+  uint8_t *dtmp; uint32_t dtmpcap;      // reversed DiffStr of the current traceback
+  Result *res; uint32_t rescap;
+  uint8_t *dstr; uint32_t dstrcap;
+  int *ivstack;               // [2 * 64] pending reference intervals
+  int32_t *state;             // [8] lane-0 state visible to the wave
+};
+
+SMG_HD inline size_t align_scratch_bytes(uint32_t qmax, uint32_t wincap, uint64_t dircap, uint32_t rescap, uint32_t dstrcap) {
+  size_t n = ((size_t)qmax + 2) * 8 + wincap + dircap + ((size_t)qmax + wincap + 16) + (size_t)rescap * sizeof(Result) + dstrcap + 128 * 4 + 64 + 256;
+  return (n + 255) & ~(size_t)255;
+}
+
+SMG_HD inline AlignScratch align_scratch_carve(uint8_t *base, uint32_t qmax, uint32_t wincap, uint64_t dircap, uint32_t rescap, uint32_t dstrcap) {
+  AlignScratch x;
+  x.res = (Result *)base; base += (size_t)rescap * sizeof(Result); x.rescap = rescap;
+  x.Hp = (int *)base; base += ((size_t)qmax + 2) * 4;
+  x.Ep = (int *)base; base += ((size_t)qmax + 2) * 4;
+  x.ivstack = (int *)base; base += 128 * 4;
+  x.state = (int32_t *)base; base += 64;
+  x.win = base; base += wincap; x.wincap = wincap;
+  x.dtmpcap = qmax + wincap + 16;
+  x.dtmp = base; base += x.dtmpcap;
+  x.dstr = base; base += dstrcap; x.dstrcap = dstrcap;
+  x.dir = base; x.dircap = dircap;
+  return x;
+}
+
+// alignSmiWatBand (alignment.c:788-1027) on one lane; returns max score, sets max_i/max_j
+SMG_HD inline int band_track_scalar(const Band &bp, const uint8_t *q, const uint8_t *win, const int8_t *M, int gi, int ge,
+                                    int *Hp, int *Ep, uint8_t *dir, int *max_i, int *max_j) {
+  int delta_start, delta_end = 0, j_start, j_len, currH = 0, best = 0, mi = 0, mj = 0;
+  if (bp.q_left > bp.l_edge) { delta_start = bp.q_left - bp.l_edge; j_start = bp.q_left; }
+  else { delta_start = 0; j_start = bp.l_edge; }
+  j_len = bp.r_edge + 1;
+  uint8_t *dirp = dir + delta_start;
+  for (int j = j_start; j < bp.q_len; j++) Hp[j] = Ep[j] = 0;
+  for (int i = bp.s_left; i < bp.s_len; i++) {
+    const int8_t *w = M + 8 * (win[i] & 7);
+    int F = 0;
+    for (int j = j_start; j < j_len; j++, dirp++) {
+      int H = currH + w[q[j] & 7];
+      currH = Hp[j];
+      bool cand;
+      *dirp = (uint8_t)cell_update(Hp[j], Ep[j], F, H, gi, ge, cand);
+      if (cand && H > best) { mi = i; mj = j; best = H; }
+    }
+    if (delta_start > 0) { currH = 0; dirp += --delta_start; }
+    else { currH = Hp[j_start]; j_start++; }
+    if (j_len < bp.q_len) j_len++;
+    else dirp += delta_end++;
+  }
+  *max_i = mi; *max_j = mj;
+  return best;
+}
+
+// makeMetaFromTrack (alignment.c:628-781): traceback into a REVERSED DiffStr; returns its
+// length (with terminator) or < 0
+SMG_HD inline int traceback_scalar(uint8_t *ds, uint32_t dscap, int *qs, int *rs, const Band &bp, const uint8_t *dir,
+                                   int max_i, int max_j, int max_scor, const uint8_t *q, const uint8_t *win,
+                                   const int8_t *M, int gi, int ge) {
+  uint32_t n = 0;
+  int i, j, checksum = 0;
+  bool gap_open = false;
+  uint8_t nmatch = 0;
+  const uint8_t *dp = dir + (size_t)(max_i - bp.s_left) * (size_t)(bp.band_width - 1) + (size_t)(max_j - bp.l_edge);
+#define SMG_PUT(cnt, typ) { if (n + 2 >= dscap) return -2; ds[n++] = (uint8_t)((cnt) + ((typ) << DIFF_TYPSHIFT)); }
+  for (i = max_i, j = max_j; i >= bp.s_left && j >= bp.q_left && *dp;) {
+    if (*dp == DIR_DIA) {
+      int s = M[8 * (win[i] & 7) + (q[j] & 7)];
+      if (s > 0) {
+        if (nmatch > DIFF_MAXMISMATCH) { SMG_PUT(DIFF_MAXMISMATCH, DIFF_M) nmatch -= DIFF_MAXMISMATCH; }
+        else nmatch++;
+      } else { SMG_PUT(nmatch, DIFF_S) nmatch = 0; }
+      checksum += s;
+      gap_open = false;
+      dp -= bp.band_width; i--; j--;
+      continue;
+    }
+    if (gap_open) checksum -= ge; else { checksum -= gi; gap_open = true; }
+    if (*dp & DIR_COL) { SMG_PUT(nmatch, DIFF_D) nmatch = 0; dp -= bp.band_width - 1; i--; continue; }
+    if (!(*dp & DIR_ROW)) return -1;
+    SMG_PUT(nmatch, DIFF_I) nmatch = 0; dp--; j--;
+  }
+  SMG_PUT(nmatch, DIFF_S)
+  SMG_PUT(0, DIFF_M)
+#undef SMG_PUT
+  *rs = i + 1; *qs = j + 1;
+  return (checksum != max_scor) ? -1 : (int)n;
+}
+
+SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t r, AlignScratch &x) {
+  const uint32_t qlen = read_len(b, r);
+  const CandHdr ch = b.ch[r];
+  const ReadCtl ctl = b.ctl[r];
+  ReadStat &st = b.stat[r];
+  const RCand *rc = b.rcpool + ch.rc_off;
+  enum { S_MINSW = 0, S_SWMAX = 1, S_SW2ND = 2, S_NRES = 3, S_NDSTR = 4, S_ERR = 5 };
+  int8_t M[64];
+  score_matrix(M, p.match, p.mismatch);
+  const int gi = -p.gap_init, ge = -p.gap_ext;
+
+  SMG_LANE0 {
+    x.state[S_MINSW] = ctl.min_swatscor; x.state[S_SWMAX] = 0; x.state[S_SW2ND] = 0;
+    x.state[S_NRES] = 0; x.state[S_NDSTR] = 0; x.state[S_ERR] = ch.err;
+  }
+  SMG_SYNC();
+  const uint32_t ncand = (ctl.go && qlen >= (uint32_t)ix.k) ? (uint32_t)ctl.n_scored : 0u;
+  for (uint32_t ci = 0; ci < ncand; ci++) {
+    const RCand c = rc[ci];
+    if (x.state[S_ERR]) break;
+    if (c.swscor < x.state[S_MINSW]) continue;            // rmap.c:826-828 (all ranked candidates are scored)
+    const uint32_t wlen = (uint32_t)(c.re - c.rs + 1);
+    if (wlen > x.wincap || c.qs > c.qe || c.qe >= qlen || (c.flags & RCF_ERR)) { SMG_LANE0 { x.state[S_ERR] = (wlen > x.wincap) ? SMG_ERR_CAP : SMG_ERR_ASSERT; } SMG_SYNC(); break; }
+    const uint64_t gbase = (c.sqidx < 0 ? 0ull : ix.sop[c.sqidx]) + c.rs;
+    SMG_PAR_CHUNKS(base, wlen) {                           // fetch + decode the reference window (rmap.c:831-845)
+      uint32_t i = base + SMG_LANE;
+      if (i < wlen) x.win[i] = (uint8_t)ref_code(ix.packed, gbase + i);
+    }
+    SMG_SYNC();
+    SMG_LANE0 {
+      const uint8_t *q = ((c.flags & RCF_REVERSE) ? b.codes_rc : b.codes) + b.read_off[r];
+      int min_swatscor = x.state[S_MINSW];
+      if ((p.flags & FLG_BEST) && x.state[S_SW2ND] > min_swatscor) min_swatscor = x.state[S_SW2ND];   // rmap.c:881-885
+      x.state[S_MINSW] = min_swatscor;
+      int bw = c.band_r - c.band_l, band_l, band_r;
+      if (bw < ctl.bandwidth_min) { bw = (ctl.bandwidth_min - bw + 1) / 2; band_l = c.band_l - bw; band_r = c.band_r + bw; }
+      else { band_l = c.band_l; band_r = c.band_r; }
+      // aliSmiWatInBand (alignment.c:1548-1601)
+      int minscore = min_swatscor, minscorlen = ctl.scorlen_min, err = 0;
+      if (minscore < 1 || p.match <= 0) err = SMG_ERR_ASSERT;
+      if (minscorlen * p.match < minscore) minscorlen = minscore / p.match;
+      if (minscorlen < ALILEN_MIN) err = SMG_ERR_ASSERT;
+      // results of this candidate are collected first (AliRsltSet), then merged (resultSetAddFromAli)
+      const int res_first = x.state[S_NRES];
+      int nali = 0;                      // number of alignments of this candidate
+      // temporary alignment records are written behind the accepted results
+      int sp = 0;
+      if (!err) { x.ivstack[0] = 0; x.ivstack[1] = (int)wlen - 1; sp = 1; }
+      // accepted-so-far results occupy res[0 .. res_first); candidates' alignments go to res[res_first + nali]
+      while (sp > 0 && !err) {
+        sp--;
+        const int s_left = x.ivstack[2 * sp], s_right = x.ivstack[2 * sp + 1];
+        Band band;
+        if (minscorlen < 2) { err = SMG_ERR_ASSERT; break; }
+        if (band_init(band, band_l, band_r, (int)c.qs, (int)c.qe, (int)qlen, s_left, s_right, (int)wlen)) continue;
+        if (band.s_left >= band.s_len || band.band_width < 0) { err = SMG_ERR_ASSERT; break; }
+        if ((uint64_t)band.band_width * (uint64_t)(band.s_len - band.s_left) + (uint64_t)band.band_width + 8 > x.dircap) { err = SMG_ERR_CAP; break; }
+        int max_i, max_j;
+        const int max_scor = band_track_scalar(band, q, x.win, M, gi, ge, x.Hp, x.Ep, x.dir, &max_i, &max_j);
+        if (max_scor < minscore) continue;
+        int qs, rs;
+        const int dn = traceback_scalar(x.dtmp, x.dtmpcap, &qs, &rs, band, x.dir, max_i, max_j, max_scor, q, x.win, M, gi, ge);
+        if (dn < 0) { err = (dn == -2) ? SMG_ERR_CAP : SMG_ERR_ASSERT; break; }
+        const int qe = max_j, re = max_i;
+        if (qs + minscorlen > qe + 1) continue;
+        {
+          // addALIMETAtoRsltSet (alignment.c:1277): forward DiffStr appended to the scratch string pool
+          if ((uint32_t)(res_first + nali) >= x.rescap || (uint32_t)(x.state[S_NDSTR] + dn + 2) > x.dstrcap) { err = SMG_ERR_CAP; break; }
+          Result &a = x.res[res_first + nali];
+          a.swatscor = max_scor; a.q_start = (uint32_t)qs; a.q_end = (uint32_t)qe; a.s_start = (uint64_t)rs; a.s_end = (uint64_t)re;
+          a.stroffs = (uint32_t)x.state[S_NDSTR];
+          const int fl = diffstr_reverse(x.dstr + a.stroffs, x.dtmp, dn);
+          if (fl < 0) { err = SMG_ERR_ASSERT; break; }
+          a.strlen = (uint32_t)fl;
+          x.state[S_NDSTR] += fl;
+          nali++;
+        }
+        // right interval is pushed first so that the left one is aligned first (alignment.c:1389-1431)
+        if (s_right > re + minscorlen) { if (sp >= 62) { err = SMG_ERR_CAP; break; } x.ivstack[2 * sp] = re + 1; x.ivstack[2 * sp + 1] = s_right; sp++; }
+        if (s_left + minscorlen < rs) { if (sp >= 62) { err = SMG_ERR_CAP; break; } x.ivstack[2 * sp] = s_left; x.ivstack[2 * sp + 1] = rs - 1; sp++; }
+      }
+      if (!err && nali > 0) {
+        // resultSetAddFromAli (results.c:1852-1942) incl. its duplicate handling: a result equal to
+        // its predecessor is popped; what is written after a popped slot within one call is lost
+        // from the array but still raises the score maxima.
+        const bool is_rev = (c.flags & RCF_REVERSE) != 0;
+        uint32_t arrlen = (uint32_t)res_first;
+        uint32_t dkeep = (nali > 0) ? x.res[res_first].stroffs : 0;   // compacted string pool write position
+        Result *rp = &x.res[arrlen++];
+        bool is_new = false;
+        Result cur;
+        for (int i = 0; i < nali; i++) {
+          cur = x.res[res_first + i];                    // raw alignment i (slots are consumed in order, never ahead of i)
+          if (is_new) { rp = &x.res[arrlen++]; is_new = false; }
+          Result nr;
+          nr.swatscor = cur.swatscor;
+          if (is_rev) { nr.q_start = qlen - cur.q_end; nr.q_end = qlen - cur.q_start; }
+          else { nr.q_start = cur.q_start + 1; nr.q_end = cur.q_end + 1; }
+          nr.s_start = (uint64_t)((uint32_t)c.rs + (uint32_t)cur.s_start + 1u);   // soffs is passed as SEQLEN_t
+          nr.s_end = (uint64_t)((uint32_t)c.rs + (uint32_t)cur.s_end + 1u);
+          nr.sidx = c.sqidx; nr.reverse = is_rev ? 1u : 0u; nr.pad = 0;
+          nr.stroffs = cur.stroffs; nr.strlen = cur.strlen;
+          const Result *pp = rp - 1;
+          is_new = (arrlen < 2) || !(nr.s_start == pp->s_start && nr.s_end == pp->s_end && nr.q_start == pp->q_start &&
+                                     nr.q_end == pp->q_end && nr.swatscor == pp->swatscor && nr.sidx == pp->sidx);
+          if (is_new) {
+            // keep the string: move it down to the compacted position
+            for (uint32_t t = 0; t < nr.strlen; t++) x.dstr[dkeep + t] = x.dstr[nr.stroffs + t];
+            nr.stroffs = dkeep; dkeep += nr.strlen;
+            if (nr.swatscor > x.state[S_SW2ND]) {        // UPDATE_SWATSCORMAX (results.c:1013)
+              if (nr.swatscor > x.state[S_SWMAX]) { x.state[S_SW2ND] = x.state[S_SWMAX]; x.state[S_SWMAX] = nr.swatscor; }
+              else if (nr.swatscor < x.state[S_SWMAX]) x.state[S_SW2ND] = nr.swatscor;
+            }
+            *rp = nr;
+          } else {
+            *rp = nr;
+            arrlen--;
+          }
+        }
+        x.state[S_NRES] = (int32_t)arrlen;
+        x.state[S_NDSTR] = (int32_t)dkeep;
+      }
+      if (err) x.state[S_ERR] = err;
+    }
+    SMG_SYNC();
+  }
+  // ---- publish: exact-size slices of the result and string pools ----
+  SMG_LANE0 {
+    const uint32_t nres = (uint32_t)x.state[S_NRES], nd = (uint32_t)x.state[S_NDSTR];
+    st.swmax = x.state[S_SWMAX]; st.sw2nd = x.state[S_SW2ND];
+    st.nseg = (int32_t)ch.n_sort; st.nseg_tot = (int32_t)ch.n_mincover;
+    st.nhit = b.hi[2 * r].nhit_rank + b.hi[2 * r + 1].nhit_rank;
+    st.nhit_tot = b.hi[2 * r].nhit_tot + b.hi[2 * r + 1].nhit_tot;
+    st.err = x.state[S_ERR];
+    st.nres = st.err ? 0 : nres;
+    st.res_off = atomic_add_u64(b.res_count, st.nres);
+    st.dstr_off = atomic_add_u64(b.dstr_count, st.err ? 0 : nd);
+    if (st.res_off + st.nres > b.rescap || st.dstr_off + nd > b.dstrcap) { st.err = SMG_ERR_CAP; st.nres = 0; }
+    if (st.err) atomic_add_u32((uint32_t *)b.err_flag, 1u);
+    x.state[S_NRES] = (int32_t)st.nres; x.state[S_NDSTR] = st.err ? 0 : (int32_t)nd;
+  }
+  SMG_SYNC();
+  {
+    const uint32_t nres = (uint32_t)x.state[S_NRES], nd = (uint32_t)x.state[S_NDSTR];
+    const uint64_t ro = st.res_off, dof = st.dstr_off;
+    SMG_PAR_CHUNKS(base, nres) { uint32_t i = base + SMG_LANE; if (i < nres) b.respool[ro + i] = x.res[i]; }
+    SMG_PAR_CHUNKS(base, nd) { uint32_t i = base + SMG_LANE; if (i < nd) b.dstrpool[dof + i] = x.dstr[i]; }
+  }
+}
+
+}  // namespace smg
