@@ -1,0 +1,224 @@
+"""ctypes binding of libsmaltgpu.so (C ABI in include/smaltgpu.h) and the host-side mirror of the
+reference's per-read mapping interface (rmap.h:83-145): `Index` stands for the (HashTable,
+SeqSet) pair that `rmapCreate` receives, `Mapper` for the `RMap`, `Mapper.map_batch` for a
+block of `rmapSingle` calls followed by `rmapGetData`.
+
+There is no CPU fallback: if the HIP library is missing or no device is present every call
+raises `SmaltGpuError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(HERE, "libsmaltgpu.so")
+
+FLG_BEST, FLG_SEQBYSEQ, FLG_NOSHRTINFO, FLG_SENSITIVE = 0x02, 0x10, 0x20, 0x80
+
+
+class SmaltGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("smaltgpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+class IndexDesc(C.Structure):
+    _fields_ = [("k", C.c_int32), ("s", C.c_int32), ("typ", C.c_int32), ("nbits_key", C.c_int32), ("nbits_lo", C.c_int32),
+                ("npos", C.c_uint32), ("nwords", C.c_uint32), ("idx", C.c_void_p), ("pos", C.c_void_p),
+                ("wordidx", C.c_void_p), ("posidx", C.c_void_p), ("nseq", C.c_int64), ("sop", C.c_void_p),
+                ("packed", C.c_void_p), ("on_device", C.c_int32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("ktuple_maxhit", C.c_int32), ("min_cover", C.c_uint32), ("min_swatscor", C.c_int32),
+                ("min_swatscor_below_max", C.c_int32), ("min_basqval", C.c_int32), ("target_depth", C.c_int32),
+                ("max_depth", C.c_int32), ("rmapflg", C.c_uint32), ("match", C.c_int32), ("mismatch", C.c_int32),
+                ("gap_init", C.c_int32), ("gap_ext", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("swatscor", C.c_int32), ("q_start", C.c_uint32), ("q_end", C.c_uint32), ("s_start", C.c_uint64),
+                ("s_end", C.c_uint64), ("sidx", C.c_int32), ("reverse", C.c_uint32), ("stroffs", C.c_uint32),
+                ("strlen", C.c_uint32)]
+
+
+class ReadStat(C.Structure):
+    _fields_ = [("swatscor_max", C.c_int32), ("swatscor_2ndmax", C.c_int32), ("n_ali_done", C.c_int32),
+                ("n_ali_tot", C.c_int32), ("n_hits_used", C.c_uint32), ("n_hits_tot", C.c_uint32),
+                ("errcode", C.c_int32), ("nres", C.c_uint32)]
+
+
+class BatchOut(C.Structure):
+    _fields_ = [("nreads", C.c_uint32), ("res_off", C.POINTER(C.c_uint64)), ("res", C.POINTER(Result)),
+                ("diffstr", C.POINTER(C.c_uint8)), ("stat", C.POINTER(ReadStat))]
+
+
+_lib = None
+
+
+def lib():
+    """Load libsmaltgpu.so; fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBPATH):
+            raise SmaltGpuError(-1, "libsmaltgpu.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIBPATH)
+        L.smaltgpu_last_error.restype = C.c_char_p
+        L.smaltgpu_timer_name.restype = C.c_char_p
+        L.smaltgpu_index_load.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_int]
+        L.smaltgpu_index_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(IndexDesc), C.c_int]
+        L.smaltgpu_index_free.argtypes = [C.c_void_p]
+        L.smaltgpu_index_info.argtypes = [C.c_void_p, C.POINTER(IndexDesc)]
+        L.smaltgpu_params_default.argtypes = [C.POINTER(Params), C.c_void_p]
+        L.smaltgpu_mapper_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32, C.c_uint32]
+        L.smaltgpu_mapper_free.argtypes = [C.c_void_p]
+        L.smaltgpu_map_batch.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint32,
+                                         C.POINTER(Params), C.POINTER(BatchOut)]
+        L.smaltgpu_map_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
+                                                C.POINTER(Params)]
+        L.smaltgpu_fetch_results.argtypes = [C.c_void_p, C.POINTER(BatchOut)]
+        L.smaltgpu_synchronize.argtypes = [C.c_void_p]
+        L.smaltgpu_timers.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+        L.smaltgpu_set_debug.argtypes = [C.c_void_p, C.c_int]
+        L.smaltgpu_dump_read.restype = C.c_long
+        L.smaltgpu_dump_read.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_size_t]
+        L.smaltgpu_sw_full_batch.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32), C.c_char_p,
+                                             C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(Params), C.POINTER(C.c_int32)]
+        _lib = L
+    return _lib
+
+
+def _check(rv):
+    if rv != 0:
+        raise SmaltGpuError(rv, lib().smaltgpu_last_error().decode())
+
+
+def device_count() -> int:
+    return lib().smaltgpu_device_count()
+
+
+class Index:
+    """Index image resident in HBM (replaces hashTableRead + seqSetReadBinFil)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def load(cls, prefix: str, device: int = 0) -> "Index":
+        h = C.c_void_p()
+        _check(lib().smaltgpu_index_load(C.byref(h), prefix.encode(), device))
+        return cls(h)
+
+    @classmethod
+    def from_desc(cls, desc: IndexDesc, device: int = 0) -> "Index":
+        h = C.c_void_p()
+        _check(lib().smaltgpu_index_create(C.byref(h), C.byref(desc), device))
+        return cls(h)
+
+    def info(self) -> IndexDesc:
+        d = IndexDesc()
+        _check(lib().smaltgpu_index_info(self.h, C.byref(d)))
+        return d
+
+    def default_params(self) -> Params:
+        p = Params()
+        lib().smaltgpu_params_default(C.byref(p), self.h)
+        return p
+
+    def close(self):
+        if self.h:
+            lib().smaltgpu_index_free(self.h)
+            self.h = None
+
+
+class Mapper:
+    """Work buffers + stream for one host thread (the analogue of an RMap, rmap.h:83)."""
+
+    def __init__(self, index: Index, max_batch_reads: int, max_read_len: int):
+        self.index = index
+        self.h = C.c_void_p()
+        _check(lib().smaltgpu_mapper_create(C.byref(self.h), index.h, max_batch_reads, max_read_len))
+
+    def close(self):
+        if self.h:
+            lib().smaltgpu_mapper_free(self.h)
+            self.h = None
+
+    def set_debug(self, level: int):
+        _check(lib().smaltgpu_set_debug(self.h, level))
+
+    @staticmethod
+    def _pack(reads: Sequence[bytes], quals: Optional[Sequence[bytes]]):
+        n = len(reads)
+        off = (C.c_uint64 * (n + 1))()
+        t = 0
+        for i, r in enumerate(reads):
+            off[i] = t
+            t += len(r)
+        off[n] = t
+        return b"".join(reads), (b"".join(quals) if quals is not None else None), off
+
+    def map_batch(self, reads: Sequence[bytes], quals: Optional[Sequence[bytes]], params: Params):
+        """-> (list per read of result dicts in the reference's raw order, list of stat dicts)."""
+        bases, q, off = self._pack(reads, quals)
+        out = BatchOut()
+        _check(lib().smaltgpu_map_batch(self.h, bases, q, off, len(reads), C.byref(params), C.byref(out)))
+        return self._unpack(out)
+
+    @staticmethod
+    def _unpack(out: BatchOut):
+        res, stats = [], []
+        for i in range(out.nreads):
+            rr = []
+            for j in range(out.res_off[i], out.res_off[i + 1]):
+                r = out.res[j]
+                rr.append(dict(reverse=int(r.reverse), score=r.swatscor, q_start=r.q_start, q_end=r.q_end, s_start=r.s_start,
+                               s_end=r.s_end, sidx=r.sidx, diffstr=bytes(out.diffstr[r.stroffs:r.stroffs + r.strlen])))
+            res.append(rr)
+            s = out.stat[i]
+            stats.append(dict(swmax=s.swatscor_max, sw2nd=s.swatscor_2ndmax, nseg=s.n_ali_done, nseg_tot=s.n_ali_tot,
+                              nhit=s.n_hits_used, nhit_tot=s.n_hits_tot, err=s.errcode))
+        return res, stats
+
+    def map_batch_device(self, d_bases: int, d_quals: int, d_off: int, nreads: int, total_bases: int, params: Params):
+        _check(lib().smaltgpu_map_batch_device(self.h, d_bases, d_quals, d_off, nreads, total_bases, C.byref(params)))
+
+    def synchronize(self):
+        _check(lib().smaltgpu_synchronize(self.h))
+
+    def fetch_results(self):
+        out = BatchOut()
+        _check(lib().smaltgpu_fetch_results(self.h, C.byref(out)))
+        return out
+
+    def timers(self):
+        ms = (C.c_double * 8)()
+        wk = (C.c_uint64 * 8)()
+        n = lib().smaltgpu_timers(self.h, ms, wk, 8)
+        names = [lib().smaltgpu_timer_name(i).decode() for i in range(n)]
+        return dict(zip(names, list(ms)[:n])), list(wk)
+
+    def dump_read(self, i: int, name: str) -> str:
+        n = lib().smaltgpu_dump_read(self.h, i, name.encode(), None, 0)
+        if n < 0:
+            _check(int(n))
+        buf = C.create_string_buffer(n + 1)
+        lib().smaltgpu_dump_read(self.h, i, name.encode(), buf, n + 1)
+        return buf.value.decode()
+
+    def sw_full_batch(self, queries: Sequence[bytes], windows: Sequence[bytes], params: Params) -> List[int]:
+        """Stand-alone K2a over explicit 3-bit code arrays (bytes of codes 0..7)."""
+        n = len(queries)
+        qo = (C.c_uint32 * (n + 1))()
+        ro = (C.c_uint32 * (n + 1))()
+        a = b = 0
+        for i in range(n):
+            qo[i], ro[i] = a, b
+            a += len(queries[i])
+            b += len(windows[i])
+        qo[n], ro[n] = a, b
+        sc = (C.c_int32 * n)()
+        _check(lib().smaltgpu_sw_full_batch(self.h, b"".join(queries), qo, b"".join(windows), ro, n, C.byref(params), sc))
+        return list(sc)

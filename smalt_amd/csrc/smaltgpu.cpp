@@ -1,0 +1,503 @@
+// smaltgpu.cpp -- host side of libsmaltgpu.so: the C ABI of include/smaltgpu.h on top of the
+// gfx950 kernels.  Device memory, one HIP stream and all scratch are owned by the mapper (the
+// analogue of the reference's RMap, rmap.c:130-171, which owns every per-thread buffer).
+// There is no CPU code path: every entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/smaltgpu.h"
+#include "smg_dump.hpp"
+#include "smg_indexfile.hpp"
+#include "smg_kernels.h"
+
+using namespace smg;
+
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(SMALTGPU_ENODEV, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+
+extern "C" const char *smaltgpu_last_error(void) { return g_err.c_str(); }
+extern "C" int smaltgpu_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------
+struct smaltgpu_index {
+  DevIndex d;
+  int device = 0;
+  bool owns = true;
+  std::vector<uint64_t> sop;       // host copy
+  void *bufs[8] = {nullptr};
+  int nbufs = 0;
+};
+
+template <class T>
+static int upload(smaltgpu_index *ix, const T *host, size_t n, const T **dev) {
+  T *p = nullptr;
+  HIPCHK(hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)));
+  ix->bufs[ix->nbufs++] = p;
+  if (n) HIPCHK(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+  *dev = p;
+  return 0;
+}
+
+extern "C" int smaltgpu_index_create(smaltgpu_index **out, const smaltgpu_index_desc *ds, int device) {
+  if (!out || !ds || !ds->idx || !ds->pos || !ds->sop || !ds->packed) return fail(SMALTGPU_EARG, "null argument");
+  if (ds->k < 1 || ds->k > 21 || ds->s < 1 || ds->nseq < 1 || ds->nseq >= (1 << KEY_SEQBITS))
+    return fail(SMALTGPU_EARG, "unsupported index geometry (k=%d s=%d nseq=%lld)", ds->k, ds->s, (long long)ds->nseq);
+  HIPCHK(hipSetDevice(device));
+  smaltgpu_index *ix = new smaltgpu_index();
+  ix->device = device;
+  DevIndex &d = ix->d;
+  d.k = ds->k; d.s = ds->s; d.typ = ds->typ;
+  d.nbits_key = ds->typ == IDX_PERFECT ? 2 * ds->k : ds->nbits_key;
+  d.nbits_lo = ds->typ == IDX_PERFECT ? 0 : ds->nbits_lo;
+  d.nkeys = 1u << d.nbits_key; d.npos = ds->npos; d.nwords = ds->nwords; d.nseq = (int32_t)ds->nseq;
+  ix->sop.assign(ds->sop, ds->sop + ds->nseq + 1);
+  d.totlen = ix->sop.back();
+  int rv = 0;
+  if (ds->on_device) {
+    ix->owns = false;
+    d.idx = ds->idx; d.pos = ds->pos; d.wordidx = ds->wordidx; d.posidx = ds->posidx; d.packed = ds->packed;
+  } else {
+    rv = upload(ix, ds->idx, (size_t)d.nkeys + 1, &d.idx);
+    if (!rv) rv = upload(ix, ds->pos, (size_t)d.npos, &d.pos);
+    if (!rv && d.typ != IDX_PERFECT) { rv = upload(ix, ds->wordidx, (size_t)d.nwords + 1, &d.wordidx); if (!rv) rv = upload(ix, ds->posidx, (size_t)d.nwords + 1, &d.posidx); }
+    if (!rv) rv = upload(ix, ds->packed, (size_t)(d.totlen / 10 + 1), &d.packed);
+  }
+  std::vector<uint32_t> seqlo((size_t)d.nseq + 1);
+  for (int i = 0; i <= d.nseq; i++) seqlo[(size_t)i] = (uint32_t)(ix->sop[(size_t)i] / (uint64_t)d.s);
+  if (!rv) rv = upload(ix, ix->sop.data(), ix->sop.size(), &d.sop);
+  if (!rv) rv = upload(ix, seqlo.data(), seqlo.size(), &d.seqlo);
+  if (rv) { smaltgpu_index_free(ix); return rv; }
+  *out = ix;
+  return SMALTGPU_OK;
+}
+
+extern "C" int smaltgpu_index_load(smaltgpu_index **out, const char *prefix, int device) {
+  if (!out || !prefix) return fail(SMALTGPU_EARG, "null argument");
+  HostIndex h;
+  std::string err;
+  if (!read_index_files(prefix, h, err)) return fail(SMALTGPU_EFILE, "%s", err.c_str());
+  smaltgpu_index_desc ds;
+  memset(&ds, 0, sizeof(ds));
+  ds.k = h.k; ds.s = h.s; ds.typ = h.typ; ds.nbits_key = h.nbits_key; ds.nbits_lo = h.nbits_lo; ds.npos = h.npos; ds.nwords = h.nwords;
+  ds.idx = h.idx.data(); ds.pos = h.pos.data(); ds.wordidx = h.wordidx.data(); ds.posidx = h.posidx.data();
+  ds.nseq = h.nseq; ds.sop = h.sop.data(); ds.packed = h.packed.data(); ds.on_device = 0;
+  return smaltgpu_index_create(out, &ds, device);
+}
+
+extern "C" void smaltgpu_index_free(smaltgpu_index *ix) {
+  if (!ix) return;
+  (void)hipSetDevice(ix->device);
+  for (int i = 0; i < ix->nbufs; i++) (void)hipFree(ix->bufs[i]);
+  delete ix;
+}
+
+extern "C" int smaltgpu_index_info(const smaltgpu_index *ix, smaltgpu_index_desc *o) {
+  if (!ix || !o) return fail(SMALTGPU_EARG, "null argument");
+  memset(o, 0, sizeof(*o));
+  o->k = ix->d.k; o->s = ix->d.s; o->typ = ix->d.typ; o->nbits_key = ix->d.nbits_key; o->nbits_lo = ix->d.nbits_lo;
+  o->npos = ix->d.npos; o->nwords = ix->d.nwords; o->idx = ix->d.idx; o->pos = ix->d.pos; o->wordidx = ix->d.wordidx;
+  o->posidx = ix->d.posidx; o->nseq = ix->d.nseq; o->sop = ix->sop.data(); o->packed = ix->d.packed; o->on_device = 1;
+  return SMALTGPU_OK;
+}
+
+extern "C" void smaltgpu_params_default(smaltgpu_params *p, const smaltgpu_index *ix) {
+  memset(p, 0, sizeof(*p));
+  p->ktuple_maxhit = 10000;                         // menu.c:603
+  p->min_cover = 0;
+  p->min_swatscor = ix->d.k + ix->d.s - 1;          // smalt.c:608-615
+  p->min_swatscor_below_max = 0;
+  p->min_basqval = 0;
+  p->target_depth = 512; p->max_depth = 2048;       // smalt.c:60-61
+  p->rmapflg = SMALTGPU_FLG_BEST | (ix->d.nseq < 512 ? SMALTGPU_FLG_SEQBYSEQ : 0);   // smalt.c:495-497, 599
+  p->match = 1; p->mismatch = -2; p->gap_init = -4; p->gap_ext = -3;                  // score.c:41-47
+}
+
+// ------------------------------------------------------------------------------------------
+enum { T_ENCODE = 0, T_SEED, T_CANDS, T_SW_FULL, T_SW_SCALAR, T_REPLAY, T_ALIGN, T_NUM };
+static const char *const kTimerNames[T_NUM] = {"encode", "seed", "cands", "sw_full", "sw_scalar", "replay", "align"};
+extern "C" const char *smaltgpu_timer_name(int i) { return (i >= 0 && i < T_NUM) ? kTimerNames[i] : nullptr; }
+
+struct smaltgpu_mapper {
+  const smaltgpu_index *ix = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  uint32_t max_reads = 0, max_len = 0, qmax = 0;
+  uint64_t max_bases = 0;
+  // device buffers
+  uint8_t *d_bases = nullptr, *d_quals = nullptr, *d_codes = nullptr, *d_codes_rc = nullptr;
+  uint64_t *d_off = nullptr;
+  Batch b;
+  uint8_t *d_counters = nullptr;            // rc_count | res_count | dstr_count | err_flag | work[8]
+  uint8_t *seed_scr = nullptr; size_t seed_bytes = 0; uint32_t seed_slots = 0;
+  uint8_t *cand_scr = nullptr; size_t cand_bytes = 0; uint32_t cand_slots = 0;
+  uint32_t hcap = 0, ngrp = 0, segcap = 0, candcap = 0;
+  uint8_t *cand_scr_dbg = nullptr; uint32_t cand_dbg_reads = 0;
+  int *sw_rows = nullptr; uint32_t sw_rowlen = 0, sw_threads = 0;
+  uint8_t *align_scr = nullptr; size_t align_bytes = 0; uint32_t align_slots = 0;
+  uint32_t wincap = 0, rescap_slot = 0, dstrcap_slot = 0; uint64_t dircap = 0;
+  // host mirrors
+  std::vector<ReadStat> h_stat;
+  std::vector<Result> h_res;
+  std::vector<uint8_t> h_dstr;
+  std::vector<uint64_t> h_res_off;
+  std::vector<smaltgpu_result> o_res;
+  std::vector<smaltgpu_readstat> o_stat;
+  std::vector<uint64_t> h_off;              // read offsets of the last batch (host copy)
+  uint32_t last_n = 0;
+  MapPar last_par;
+  bool have_host_off = false;
+  int debug = 0;
+  hipEvent_t ev[T_NUM + 1] = {nullptr};
+  double ms[T_NUM] = {0};
+  unsigned long long work[WK_NWORK] = {0};
+};
+
+template <class T>
+static int dalloc(T **p, size_t n) {
+  HIPCHK(hipMalloc((void **)p, (n ? n : 1) * sizeof(T)));
+  return 0;
+}
+
+static uint32_t next_pow2(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+
+extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_index *ix, uint32_t max_batch_reads, uint32_t max_read_len) {
+  if (!out || !ix || !max_batch_reads || !max_read_len) return fail(SMALTGPU_EARG, "bad argument");
+  if (max_read_len >= (1u << KEY_QBITS)) return fail(SMALTGPU_EARG, "reads longer than %u bases are not supported", (1u << KEY_QBITS) - 1);
+  HIPCHK(hipSetDevice(ix->device));
+  smaltgpu_mapper *m = new smaltgpu_mapper();
+  m->ix = ix; m->device = ix->device; m->max_reads = max_batch_reads; m->max_len = max_read_len;
+  m->qmax = (max_read_len + 8 + 7) & ~7u;
+  m->max_bases = (uint64_t)max_batch_reads * max_read_len;
+  HIPCHK(hipStreamCreate(&m->stream));
+  for (int i = 0; i <= T_NUM; i++) HIPCHK(hipEventCreate(&m->ev[i]));
+  const DevIndex &d = ix->d;
+  Batch &b = m->b;
+  memset(&b, 0, sizeof(b));
+  b.qmax = m->qmax;
+  int rv = 0;
+#define DA(ptr, n) if (!rv) rv = dalloc(&(ptr), (size_t)(n))
+  DA(m->d_bases, m->max_bases + 16); DA(m->d_quals, m->max_bases + 16); DA(m->d_codes, m->max_bases + 16); DA(m->d_codes_rc, m->max_bases + 16);
+  DA(m->d_off, (size_t)max_batch_reads + 1);
+  DA(b.hi, 2 * (size_t)max_batch_reads);
+  DA(b.seeds, 2 * (size_t)max_batch_reads * m->qmax);
+  DA(b.qmask, 2 * (size_t)max_batch_reads * m->qmax);
+  DA(b.ch, max_batch_reads); DA(b.ctl, max_batch_reads); DA(b.stat, max_batch_reads);
+  {
+    const char *e = getenv("SMALTGPU_CANDS_PER_READ");
+    uint64_t per = e ? strtoull(e, nullptr, 10) : 256;
+    if (per < 8) per = 8;
+    if (per > 2048) per = 2048;
+    uint64_t cap = (uint64_t)max_batch_reads * per;
+    if (max_batch_reads <= 4096) cap = (uint64_t)max_batch_reads * 2048;
+    if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
+    b.rccap = (uint32_t)cap;
+  }
+  DA(b.rcpool, b.rccap);
+  b.rescap = (uint64_t)max_batch_reads * 8 + 4096;
+  DA(b.respool, b.rescap);
+  b.dstrcap = b.rescap * (uint64_t)(m->qmax / 4 + 48);
+  DA(b.dstrpool, b.dstrcap);
+  DA(m->d_counters, 256);
+  if (!rv) {
+    b.rc_count = (uint32_t *)(m->d_counters + 0);
+    b.res_count = (unsigned long long *)(m->d_counters + 8);
+    b.dstr_count = (unsigned long long *)(m->d_counters + 16);
+    b.err_flag = (int32_t *)(m->d_counters + 24);
+    b.work = (unsigned long long *)(m->d_counters + 64);
+  }
+  // scratch geometry -------------------------------------------------------------------
+  m->seed_bytes = (seed_scratch_bytes(m->qmax, d.s) + 255) & ~(size_t)255;
+  m->seed_slots = 8192;
+  if (m->seed_bytes > 48 * 1024) DA(m->seed_scr, m->seed_bytes * m->seed_slots);
+  {
+    // hit list capacity per strand (hashhit.c:1262-1288) for the longest read
+    double t = (double)max_read_len * log((double)(max_read_len > 1 ? max_read_len : 2)) * HITLST_LOGQLEN_FACT;
+    uint64_t alloc = HITLST_BLKSZ;
+    if (t > (double)alloc) alloc = (((uint64_t)t + HITLST_BLKSZ - 1) / HITLST_BLKSZ) * HITLST_BLKSZ;
+    m->hcap = next_pow2(2 * alloc);
+    m->ngrp = d.nseq < 512 ? (uint32_t)d.nseq : 1u;     // both modes fit: concatenated mode uses group 0
+    m->segcap = m->hcap / 2;
+    m->candcap = m->hcap / 4 < 4096 ? 4096 : m->hcap / 4;
+    m->cand_bytes = cand_scratch_bytes(m->qmax, d.s, m->hcap, m->ngrp, m->segcap, m->candcap);
+    uint64_t budget = 6ull << 30;
+    uint64_t slots = budget / m->cand_bytes;
+    if (slots > 4096) slots = 4096;
+    if (slots < 64) slots = 64;
+    if (slots > max_batch_reads) slots = max_batch_reads;
+    m->cand_slots = (uint32_t)slots;
+    DA(m->cand_scr, m->cand_bytes * m->cand_slots);
+  }
+  m->sw_rowlen = m->qmax + 8; m->sw_threads = 16384;
+  DA(m->sw_rows, (size_t)m->sw_threads * 2 * m->sw_rowlen);
+  {
+    m->wincap = 4 * m->qmax + 1024;
+    m->dircap = (uint64_t)(m->qmax + 64) * (m->wincap + 8);
+    m->rescap_slot = 512; m->dstrcap_slot = 512 * (m->qmax / 4 + 48);
+    m->align_bytes = align_scratch_bytes(m->qmax, m->wincap, m->dircap, m->rescap_slot, m->dstrcap_slot);
+    uint64_t budget = 4ull << 30;
+    uint64_t slots = budget / m->align_bytes;
+    if (slots > 4096) slots = 4096;
+    if (slots < 16) slots = 16;
+    if (slots > max_batch_reads) slots = max_batch_reads;
+    m->align_slots = (uint32_t)slots;
+    DA(m->align_scr, m->align_bytes * m->align_slots);
+  }
+#undef DA
+  if (rv) { smaltgpu_mapper_free(m); return rv; }
+  *out = m;
+  return SMALTGPU_OK;
+}
+
+extern "C" void smaltgpu_mapper_free(smaltgpu_mapper *m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  void *ps[] = {m->d_bases, m->d_quals, m->d_codes, m->d_codes_rc, m->d_off, m->b.hi, m->b.seeds, m->b.qmask, m->b.ch, m->b.ctl,
+                m->b.stat, m->b.rcpool, m->b.respool, m->b.dstrpool, m->d_counters, m->seed_scr, m->cand_scr, m->cand_scr_dbg,
+                m->sw_rows, m->align_scr};
+  for (void *p : ps) if (p) (void)hipFree(p);
+  for (int i = 0; i <= T_NUM; i++) if (m->ev[i]) (void)hipEventDestroy(m->ev[i]);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+}
+
+extern "C" int smaltgpu_set_debug(smaltgpu_mapper *m, int level) {
+  if (!m) return fail(SMALTGPU_EARG, "null mapper");
+  m->debug = level;
+  return SMALTGPU_OK;
+}
+
+static MapPar to_par(const smaltgpu_params *p) {
+  MapPar q;
+  q.ncut = p->ktuple_maxhit; q.min_cover = p->min_cover; q.min_swatscor = p->min_swatscor; q.below_max = p->min_swatscor_below_max;
+  q.min_basq = p->min_basqval; q.target_depth = p->target_depth; q.max_depth = p->max_depth; q.flags = p->rmapflg;
+  q.match = p->match; q.mismatch = p->mismatch; q.gap_init = p->gap_init; q.gap_ext = p->gap_ext;
+  return q;
+}
+
+static int check_par(const smaltgpu_mapper *m, const smaltgpu_params *p) {
+  if (p->match < 1 || p->mismatch >= 0 || p->gap_init >= 0 || p->gap_ext >= 0 || p->match > 15 || p->mismatch < -100)
+    return fail(SMALTGPU_EARG, "unsupported penalties");
+  if (p->min_swatscor < 1) return fail(SMALTGPU_EARG, "min_swatscor must be >= 1 (alignment.c:1569)");
+  if ((p->rmapflg & SMALTGPU_FLG_SEQBYSEQ) && m->ix->d.nseq >= 512) return fail(SMALTGPU_EARG, "sequence-by-sequence mode needs < 512 sequences (smalt.c:599)");
+  if (p->ktuple_maxhit < 1) return fail(SMALTGPU_EARG, "ktuple_maxhit < 1 is not supported");
+  return 0;
+}
+
+// the device pipeline over reads already in HBM
+static int run_pipeline(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_off, uint32_t n,
+                        const smaltgpu_params *par) {
+  Batch &b = m->b;
+  const DevIndex &d = m->ix->d;
+  const MapPar p = to_par(par);
+  m->last_par = p; m->last_n = n;
+  b.nreads = n; b.codes = m->d_codes; b.codes_rc = m->d_codes_rc; b.qual = d_quals; b.read_off = d_off;
+  hipStream_t s = m->stream;
+  HIPCHK(hipMemsetAsync(m->d_counters, 0, 256, s));
+  int rv = 0;
+  const bool seqbyseq = (p.flags & FLG_SEQBYSEQ) != 0;
+  const uint32_t ngrp = seqbyseq ? (uint32_t)d.nseq : 1u;
+  uint8_t *cscr = m->cand_scr;
+  uint32_t cslots = m->cand_slots;
+  int slot_per_read = 0;
+  if (m->debug) {
+    if (n > 2048) return fail(SMALTGPU_EARG, "debug batches are limited to 2048 reads");
+    if (m->cand_dbg_reads < n) {
+      if (m->cand_scr_dbg) (void)hipFree(m->cand_scr_dbg);
+      m->cand_scr_dbg = nullptr;
+      HIPCHK(hipMalloc((void **)&m->cand_scr_dbg, m->cand_bytes * n));
+      m->cand_dbg_reads = n;
+    }
+    cscr = m->cand_scr_dbg; cslots = n; slot_per_read = 1;
+  }
+  HIPCHK(hipEventRecord(m->ev[T_ENCODE], s));
+  rv = launch_encode(s, d_bases, d_off, n, m->d_codes, m->d_codes_rc);
+  HIPCHK(hipEventRecord(m->ev[T_SEED], s));
+  if (!rv) rv = launch_seed(s, b, d, p, m->seed_scr, m->seed_bytes, m->seed_slots);
+  HIPCHK(hipEventRecord(m->ev[T_CANDS], s));
+  if (!rv) rv = launch_cands(s, b, d, p, cscr, m->cand_bytes, cslots, m->hcap, ngrp, m->segcap, m->candcap, slot_per_read);
+  HIPCHK(hipEventRecord(m->ev[T_SW_FULL], s));
+  if (!rv) rv = launch_sw_full(s, b, d, p, m->max_len, b.rccap, 8192);
+  HIPCHK(hipEventRecord(m->ev[T_SW_SCALAR], s));
+  if (!rv) rv = launch_sw_scalar(s, b, d, p, m->sw_rows, m->sw_rowlen, m->sw_threads, m->max_len);
+  HIPCHK(hipEventRecord(m->ev[T_REPLAY], s));
+  if (!rv) rv = launch_replay(s, b, d, p);
+  HIPCHK(hipEventRecord(m->ev[T_ALIGN], s));
+  if (!rv) rv = launch_align(s, b, d, p, m->align_scr, m->align_bytes, m->align_slots, m->wincap, m->dircap, m->rescap_slot, m->dstrcap_slot);
+  HIPCHK(hipEventRecord(m->ev[T_NUM], s));
+  if (rv) return fail(SMALTGPU_ENODEV, "kernel launch failed: %s", hipGetErrorString((hipError_t)rv));
+  return SMALTGPU_OK;
+}
+
+extern "C" int smaltgpu_synchronize(smaltgpu_mapper *m) {
+  if (!m) return fail(SMALTGPU_EARG, "null mapper");
+  HIPCHK(hipStreamSynchronize(m->stream));
+  return SMALTGPU_OK;
+}
+
+extern "C" int smaltgpu_map_batch_device(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_read_off,
+                                          uint32_t nreads, uint64_t total_bases, const smaltgpu_params *par) {
+  if (!m || !d_bases || !d_read_off || !par) return fail(SMALTGPU_EARG, "null argument");
+  if (nreads > m->max_reads || total_bases > m->max_bases) return fail(SMALTGPU_EARG, "batch exceeds the mapper's capacity");
+  int rv = check_par(m, par);
+  if (rv) return rv;
+  HIPCHK(hipSetDevice(m->device));
+  m->have_host_off = false;
+  return run_pipeline(m, d_bases, d_quals, d_read_off, nreads, par);
+}
+
+extern "C" int smaltgpu_fetch_results(smaltgpu_mapper *m, smaltgpu_batch_out *out) {
+  if (!m || !out) return fail(SMALTGPU_EARG, "null argument");
+  HIPCHK(hipSetDevice(m->device));
+  const uint32_t n = m->last_n;
+  uint8_t ctr[256];
+  HIPCHK(hipMemcpyAsync(ctr, m->d_counters, 256, hipMemcpyDeviceToHost, m->stream));
+  m->h_stat.resize(n ? n : 1);
+  if (n) HIPCHK(hipMemcpyAsync(m->h_stat.data(), m->b.stat, (size_t)n * sizeof(ReadStat), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  const uint32_t rc_count = *(uint32_t *)(ctr + 0);
+  const uint64_t nres = *(unsigned long long *)(ctr + 8), ndstr = *(unsigned long long *)(ctr + 16);
+  memcpy(m->work, ctr + 64, sizeof(m->work));
+  for (int i = 0; i < T_NUM; i++) { float f = 0; (void)hipEventElapsedTime(&f, m->ev[i], m->ev[i + 1]); m->ms[i] = f; }
+  if (rc_count > m->b.rccap) return fail(SMALTGPU_ECAP, "candidate pool overflow (%u > %u): use a smaller batch or SMALTGPU_CANDS_PER_READ", rc_count, m->b.rccap);
+  if (nres > m->b.rescap || ndstr > m->b.dstrcap) return fail(SMALTGPU_ECAP, "result pool overflow");
+  m->h_res.resize(nres ? nres : 1);
+  m->h_dstr.resize(ndstr ? ndstr : 1);
+  if (nres) HIPCHK(hipMemcpy(m->h_res.data(), m->b.respool, nres * sizeof(Result), hipMemcpyDeviceToHost));
+  if (ndstr) HIPCHK(hipMemcpy(m->h_dstr.data(), m->b.dstrpool, ndstr, hipMemcpyDeviceToHost));
+  // per-read order: results of read i are contiguous in the pool but reads finish in any order;
+  // re-pack in read order so that res_off is monotone
+  m->h_res_off.assign((size_t)n + 1, 0);
+  m->o_res.resize(nres ? nres : 1);
+  m->o_stat.resize(n ? n : 1);
+  uint64_t w = 0;
+  int first_err = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    const ReadStat &st = m->h_stat[i];
+    m->h_res_off[i] = w;
+    smaltgpu_readstat &os = m->o_stat[i];
+    os.swatscor_max = st.swmax; os.swatscor_2ndmax = st.sw2nd; os.n_ali_done = st.nseg; os.n_ali_tot = st.nseg_tot;
+    os.n_hits_used = st.nhit; os.n_hits_tot = st.nhit_tot; os.errcode = st.err; os.nres = st.nres;
+    if (st.err && !first_err) first_err = st.err;
+    for (uint32_t j = 0; j < st.nres; j++) {
+      const Result &r = m->h_res[st.res_off + j];
+      smaltgpu_result &o = m->o_res[w++];
+      o.swatscor = r.swatscor; o.q_start = r.q_start; o.q_end = r.q_end; o.s_start = r.s_start; o.s_end = r.s_end;
+      o.sidx = r.sidx; o.reverse = r.reverse; o.stroffs = (uint32_t)(st.dstr_off + r.stroffs); o.strlen = r.strlen;
+    }
+  }
+  m->h_res_off[n] = w;
+  out->nreads = n; out->res_off = m->h_res_off.data(); out->res = m->o_res.data(); out->diffstr = m->h_dstr.data(); out->stat = m->o_stat.data();
+  if (first_err) return fail(first_err, "%d: at least one read hit a device-side limit or assertion (see stat[].errcode)", first_err);
+  return SMALTGPU_OK;
+}
+
+extern "C" int smaltgpu_map_batch(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
+                                   const smaltgpu_params *par, smaltgpu_batch_out *out) {
+  if (!m || !bases || !read_off || !par || !out) return fail(SMALTGPU_EARG, "null argument");
+  if (nreads > m->max_reads) return fail(SMALTGPU_EARG, "batch of %u reads exceeds the mapper's capacity %u", nreads, m->max_reads);
+  const uint64_t total = read_off[nreads] - read_off[0];
+  if (total > m->max_bases) return fail(SMALTGPU_EARG, "batch exceeds the mapper's base capacity");
+  int rv = check_par(m, par);
+  if (rv) return rv;
+  m->h_off.resize((size_t)nreads + 1);
+  for (uint32_t i = 0; i <= nreads; i++) {
+    m->h_off[i] = read_off[i] - read_off[0];
+    if (i && m->h_off[i] - m->h_off[i - 1] > m->max_len) return fail(SMALTGPU_EARG, "read %u is longer than the mapper's max_read_len", i - 1);
+  }
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipMemcpyAsync(m->d_bases, bases + read_off[0], total, hipMemcpyHostToDevice, m->stream));
+  if (quals) HIPCHK(hipMemcpyAsync(m->d_quals, quals + read_off[0], total, hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(m->d_off, m->h_off.data(), ((size_t)nreads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
+  rv = run_pipeline(m, m->d_bases, quals ? m->d_quals : nullptr, m->d_off, nreads, par);
+  m->have_host_off = true;
+  if (rv) return rv;
+  return smaltgpu_fetch_results(m, out);
+}
+
+extern "C" int smaltgpu_timers(const smaltgpu_mapper *m, double *ms, uint64_t *work, int n) {
+  if (!m) return fail(SMALTGPU_EARG, "null mapper");
+  for (int i = 0; i < n && i < T_NUM; i++) if (ms) ms[i] = m->ms[i];
+  for (int i = 0; i < n && i < WK_NWORK; i++) if (work) work[i] = m->work[i];
+  return T_NUM;
+}
+
+// ------------------------------------------------------------------------------------------
+template <class T>
+static int fetch(std::vector<T> &v, const T *dev, size_t n) {
+  v.resize(n ? n : 1);
+  if (n) HIPCHK(hipMemcpy(v.data(), dev, n * sizeof(T), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" long smaltgpu_dump_read(smaltgpu_mapper *m, uint32_t i, const char *name, char *buf, size_t bufsiz) {
+  if (!m) return fail(SMALTGPU_EARG, "null mapper");
+  if (!m->debug || !m->cand_scr_dbg) return fail(SMALTGPU_EARG, "smaltgpu_set_debug(m, 1) must precede the batch");
+  if (i >= m->last_n || !m->have_host_off) return fail(SMALTGPU_EARG, "read index out of range");
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  const Batch &b = m->b;
+  const DevIndex &d = m->ix->d;
+  DumpView v;
+  std::vector<HitInfoHdr> hi; std::vector<SeedRec> seeds; std::vector<uint8_t> qmask;
+  std::vector<CandHdr> ch; std::vector<ReadCtl> ctl; std::vector<ReadStat> st;
+  std::vector<uint8_t> slot;
+  if (fetch(hi, b.hi + 2 * (size_t)i, 2) || fetch(seeds, b.seeds + 2 * (size_t)i * m->qmax, 2 * (size_t)m->qmax) ||
+      fetch(qmask, b.qmask + 2 * (size_t)i * m->qmax, 2 * (size_t)m->qmax) || fetch(ch, b.ch + i, 1) || fetch(ctl, b.ctl + i, 1) ||
+      fetch(st, b.stat + i, 1) || fetch(slot, m->cand_scr_dbg + m->cand_bytes * i, m->cand_bytes)) return SMALTGPU_ENODEV;
+  const uint32_t ngrp = (m->last_par.flags & FLG_SEQBYSEQ) ? (uint32_t)d.nseq : 1u;
+  CandScratch cx = cand_scratch_carve(slot.data(), m->qmax, d.s, m->hcap, ngrp, m->segcap, m->candcap);
+  std::vector<RCand> rc; std::vector<Result> res; std::vector<uint8_t> dstr;
+  if (fetch(rc, b.rcpool + ch[0].rc_off, ch[0].n_sort) || fetch(res, b.respool + st[0].res_off, st[0].nres)) return SMALTGPU_ENODEV;
+  size_t nd = 0;
+  for (uint32_t j = 0; j < st[0].nres; j++) { size_t e = (size_t)res[j].stroffs + res[j].strlen; if (e > nd) nd = e; }
+  if (fetch(dstr, b.dstrpool + st[0].dstr_off, nd)) return SMALTGPU_ENODEV;
+  v.qlen = (uint32_t)(m->h_off[i + 1] - m->h_off[i]); v.qmax = m->qmax; v.k = d.k;
+  for (int s2 = 0; s2 < 2; s2++) { v.hi[s2] = hi[s2]; v.seeds[s2] = seeds.data() + (size_t)s2 * m->qmax; v.qmask[s2] = qmask.data() + (size_t)s2 * m->qmax; }
+  v.ch = ch[0]; v.cand = cx.cand; v.sort_idx = cx.sort_idx; v.sort_keys = cx.sort_keys; v.rc = rc.data(); v.ctl = ctl[0]; v.st = st[0];
+  v.res = res.data(); v.dstr = dstr.data(); v.hitwords = cx.keys; v.grp_first = cx.grp_first; v.grp_cnt = cx.grp_cnt; v.ngrp = ngrp;
+  std::string o;
+  dump_read(o, v, i, name, m->debug >= 2);
+  if (buf && bufsiz) { size_t c = o.size() < bufsiz - 1 ? o.size() : bufsiz - 1; memcpy(buf, o.data(), c); buf[c] = 0; }
+  return (long)o.size();
+}
+
+extern "C" int smaltgpu_sw_full_batch(smaltgpu_mapper *m, const uint8_t *qcodes, const uint32_t *q_off, const uint8_t *rcodes,
+                                       const uint32_t *r_off, uint32_t ntask, const smaltgpu_params *par, int32_t *scores) {
+  if (!m || !qcodes || !q_off || !rcodes || !r_off || !par || !scores) return fail(SMALTGPU_EARG, "null argument");
+  HIPCHK(hipSetDevice(m->device));
+  uint8_t *dq = nullptr, *dr = nullptr; uint32_t *dqo = nullptr, *dro = nullptr; int32_t *dsc = nullptr;
+  uint32_t qmaxlen = 0;
+  for (uint32_t t = 0; t < ntask; t++) { uint32_t l = q_off[t + 1] - q_off[t]; if (l > qmaxlen) qmaxlen = l; }
+  int rv = 0;
+  if (dalloc(&dq, q_off[ntask] + 16) || dalloc(&dr, r_off[ntask] + 16) || dalloc(&dqo, (size_t)ntask + 1) || dalloc(&dro, (size_t)ntask + 1) || dalloc(&dsc, ntask)) rv = SMALTGPU_ENOMEM;
+  if (!rv) {
+    (void)hipMemcpy(dq, qcodes, q_off[ntask], hipMemcpyHostToDevice);
+    (void)hipMemcpy(dr, rcodes, r_off[ntask], hipMemcpyHostToDevice);
+    (void)hipMemcpy(dqo, q_off, ((size_t)ntask + 1) * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dro, r_off, ((size_t)ntask + 1) * 4, hipMemcpyHostToDevice);
+    int lr = launch_sw_full_raw(m->stream, dq, dqo, dr, dro, ntask, to_par(par), dsc, qmaxlen);
+    if (lr) rv = fail(SMALTGPU_EARG, "query longer than the register-tiled kernel supports");
+    else if (hipStreamSynchronize(m->stream) != hipSuccess) rv = fail(SMALTGPU_ENODEV, "kernel failed");
+    else (void)hipMemcpy(scores, dsc, (size_t)ntask * 4, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(dq); (void)hipFree(dr); (void)hipFree(dqo); (void)hipFree(dro); (void)hipFree(dsc);
+  return rv;
+}

@@ -91,6 +91,8 @@ struct RCand {                                                      // rmap.c:11
   uint32_t flags;           // RCF_*
   uint32_t cover;
   int32_t swscor;
+  uint32_t rid;             // read index in the batch
+  uint32_t pad;
 };
 
 struct CandHdr {                                                    // segment.c:267-284 + rmap.c:1333-1338

@@ -1,0 +1,400 @@
+// smg_kernels.hip -- gfx950 kernels of libsmaltgpu: thin wave-per-read wrappers around the
+// stage functions of smg_stages.hpp, and the wide Smith-Waterman score pass (K2a).
+#include <hip/hip_runtime.h>
+#include "smg_kernels.h"
+#include "smg_stages.hpp"
+
+namespace smg {
+
+// ---------------------------------------------------------------------------------------
+// read encoding: ASCII -> 3-bit codes (sequence.c:287-322) + reverse complement
+// (sequence.c:884-896: non-standard codes are kept).  One wave per read.
+// ---------------------------------------------------------------------------------------
+__device__ inline uint8_t code_of(uint8_t c) {
+  c &= 0xDF;   // upper case for letters
+  return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : (c == 'T' || c == 'U') ? 3 : 5;
+}
+
+__global__ void __launch_bounds__(64) k_encode(const uint8_t *bases, const uint64_t *off, uint32_t n, uint8_t *codes, uint8_t *codes_rc) {
+  for (uint32_t r = blockIdx.x; r < n; r += gridDim.x) {
+    const uint64_t o = off[r];
+    const uint32_t len = (uint32_t)(off[r + 1] - o);
+    for (uint32_t i = threadIdx.x; i < len; i += 64) {
+      uint8_t c = code_of(bases[o + i]);
+      codes[o + i] = c;
+      codes_rc[o + len - 1 - i] = (c & 4) ? c : (uint8_t)(3 - c);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// S1 + S2: one wave per (read, strand); scratch in LDS when it fits, else in HBM slots
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_seed(Batch b, DevIndex ix, MapPar p, uint8_t *gscratch, size_t gbytes, int use_lds) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  uint8_t *base = use_lds ? lds : gscratch + gbytes * blockIdx.x;
+  SeedScratch x = seed_scratch_carve(base, b.qmax, ix.s);
+  unsigned long long nlook = 0;
+  for (uint32_t rs = blockIdx.x; rs < 2 * b.nreads; rs += gridDim.x) {
+    nlook += stage_seed(b, ix, p, rs >> 1, rs & 1, x);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && nlook) atomicAdd(b.work + WK_LOOKUPS, nlook);
+}
+
+// S3 - S7: one wave per read, scratch slot in HBM
+__global__ void __launch_bounds__(64) k_cands(Batch b, DevIndex ix, MapPar p, uint8_t *gscratch, size_t gbytes, uint32_t hcap,
+                                              uint32_t ngrp, uint32_t segcap, uint32_t candcap, int slot_per_read) {
+  unsigned long long nhit = 0;
+  for (uint32_t r = blockIdx.x; r < b.nreads; r += gridDim.x) {
+    uint8_t *base = gscratch + gbytes * (slot_per_read ? r : blockIdx.x);
+    CandScratch x = cand_scratch_carve(base, b.qmax, ix.s, hcap, ngrp, segcap, candcap);
+    nhit += stage_cands(b, ix, p, r, x);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && nhit) atomicAdd(b.work + WK_HITS, nhit);
+}
+
+// O1: one thread per read
+__global__ void __launch_bounds__(256) k_replay(Batch b, DevIndex ix, MapPar p) {
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < b.nreads) stage_replay(b, ix, p, r);
+}
+
+// K3: one wave per read, scratch slot in HBM
+__global__ void __launch_bounds__(64) k_align(Batch b, DevIndex ix, MapPar p, uint8_t *gscratch, size_t gbytes, uint32_t wincap,
+                                              uint64_t dircap, uint32_t rescap, uint32_t dstrcap) {
+  uint8_t *base = gscratch + gbytes * blockIdx.x;
+  AlignScratch x = align_scratch_carve(base, b.qmax, wincap, dircap, rescap, dstrcap);
+  for (uint32_t r = blockIdx.x; r < b.nreads; r += gridDim.x) {
+    stage_align(b, ix, p, r, x);
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// K2a: un-banded Smith-Waterman score pass (swsimd.c:868 -- textbook Gotoh maximum).
+//
+// A task = one ranked candidate (read x reference window).  G adjacent lanes own one task;
+// lane g keeps C consecutive query columns (H, E and a byte selector per column) in
+// registers and sweeps the window row by row, one row behind lane g-1 (anti-diagonal skew
+// ACROSS lanes only).  Per row a lane receives H[row][first-1] and the running F from its
+// left neighbour with DPP row_shr:1 -- no LDS traffic in the recurrence.  Substitution
+// scores come from one v_perm_b32 per cell on an 8-byte row of the biased score matrix.
+// Window bases are decoded once per task into LDS.  Rows beyond a task's window and columns
+// beyond the read are fed 'N' (score 0), which can never raise the maximum, so lanes need no
+// predication.  int32 arithmetic equals the reference's 8-bit pass, and its 16-bit re-run on
+// saturation, for any score < 65535.
+// ---------------------------------------------------------------------------------------
+template <int G>
+__device__ inline int shr1(int v) {          // value of the lane to the left inside a 16-lane row
+  return __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+}
+
+template <int G, int C>
+__global__ void __launch_bounds__(64) k_sw_full(Batch b, DevIndex ix, MapPar p, uint32_t ntask_cap) {
+  constexpr int NG = 64 / G;                 // tasks in flight per wave
+  constexpr int WMAX = SW_FULL_WMAX;         // longest window handled here
+  __shared__ uint8_t win[NG][WMAX + 8];
+  __shared__ uint2 tab[8];
+  const int lane = threadIdx.x, g = lane % G, grp = lane / G;
+  const uint32_t ntask = min(*b.rc_count, ntask_cap);
+  const int bias = (p.mismatch < p.mismatch - p.match ? -p.mismatch : -(p.mismatch - p.match));   // >= -min(M)
+  const int gi = -p.gap_init, ge = -p.gap_ext;
+  if (lane < 8) {                            // biased score matrix rows (score.c:138-173; rows 4,6 = N, 7 = A)
+    int rb = lane == 7 ? 0 : ((lane == 6 || lane == 4) ? 5 : lane);
+    uint32_t w[2] = {0, 0};
+    for (int qc = 0; qc < 8; qc++) {
+      int v = (rb == 5 || qc >= 4) ? 0 : ((rb == qc) ? p.match : p.mismatch);
+      w[qc >> 2] |= (uint32_t)((v + bias) & 0xff) << (8 * (qc & 3));
+    }
+    tab[lane] = make_uint2(w[0], w[1]);
+  }
+  __syncthreads();
+  const uint32_t ngroups = gridDim.x * NG;
+  unsigned long long cells = 0, ntasks_done = 0;
+  for (uint32_t t0 = blockIdx.x * NG; t0 < ntask; t0 += ngroups) {
+    const uint32_t t = t0 + grp;
+    RCand c;
+    bool live = false;
+    uint32_t qlen = 0, wlen = 0;
+    uint64_t gbase = 0;
+    if (t < ntask) {
+      c = b.rcpool[t];
+      qlen = read_len(b, c.rid);
+      wlen = (uint32_t)(c.re - c.rs + 1);
+      live = !(c.flags & (RCF_BANDED | RCF_ERR)) && wlen <= (uint32_t)WMAX && qlen <= (uint32_t)(G * C);
+      gbase = (c.sqidx < 0 ? 0ull : ix.sop[c.sqidx]) + c.rs;
+    }
+    if (!live) { qlen = 0; wlen = 0; }
+    // window -> LDS (sequence.c:1499 decode folded into the fetch)
+    for (uint32_t i = g; i < wlen; i += G) win[grp][i] = (uint8_t)ref_code(ix.packed, gbase + i);
+    // query columns of this lane: selector byte = code (0..3 standard, 5 = N -> score 0 column)
+    uint32_t sel[C];
+    {
+      const uint8_t *q = ((c.flags & RCF_REVERSE) ? b.codes_rc : b.codes) + (live ? b.read_off[c.rid] : 0);
+#pragma unroll
+      for (int cc = 0; cc < C; cc++) {
+        uint32_t j = (uint32_t)(g * C + cc);
+        uint32_t qc = (live && j < qlen) ? q[j] : 5u;
+        sel[cc] = 0x0c0c0c00u | qc;
+      }
+    }
+    int H[C], E[C];
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) { H[cc] = 0; E[cc] = 0; }
+    int best = 0, F = 0, prev_hl = 0;
+    // wave-uniform number of steps
+    int nstep = (int)wlen + G - 1;
+    for (int o = 32; o > 0; o >>= 1) nstep = max(nstep, __shfl_xor(nstep, o));
+    __syncthreads();
+    for (int step = 0; step < nstep; step++) {
+      const int row = step - g;
+      const uint32_t rb = (row >= 0 && row < (int)wlen) ? win[grp][row] : 5u;
+      const uint2 tr = tab[rb];
+      int hl = shr1<G>(H[C - 1]);
+      int fin = shr1<G>(F);
+      if (g == 0) { hl = 0; fin = 0; }
+      int diag = prev_hl;
+      prev_hl = hl;
+      F = fin;
+#pragma unroll
+      for (int cc = 0; cc < C; cc++) {
+        const int w = (int)__builtin_amdgcn_perm(tr.y, tr.x, sel[cc]);
+        const int h = diag + w - bias;
+        const int hh = max(max(h, E[cc]), F);       // v_max3_i32; E, F >= 0 keep H >= 0
+        best = max(best, hh);
+        diag = H[cc];
+        H[cc] = hh;
+        const int tt = hh - gi;
+        E[cc] = max(max(E[cc] - ge, tt), 0);
+        F = max(max(F - ge, tt), 0);
+      }
+    }
+    for (int o = G / 2; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
+    if (live && g == 0) {
+      b.rcpool[t].swscor = best;
+      b.rcpool[t].flags = c.flags | RCF_SCORED | (best >= 65535 ? RCF_BANDED : 0u);   // ERRCODE_SWATEXCEED -> K2b
+      cells += (unsigned long long)qlen * wlen;
+      ntasks_done++;
+    }
+    __syncthreads();
+  }
+  for (int o = 32; o > 0; o >>= 1) { cells += __shfl_xor(cells, o); ntasks_done += __shfl_xor(ntasks_done, o); }
+  if (lane == 0 && cells) { atomicAdd(b.work + WK_CELLS_FULL, cells); atomicAdd(b.work + WK_TASKS_FULL, ntasks_done); }
+}
+
+// K2a for tasks the register-tiled kernel does not cover (long reads / long windows) and
+// K2b (banded score-only pass, alignment.c:1029) -- one lane per task, rows in HBM scratch.
+__global__ void __launch_bounds__(64) k_sw_scalar(Batch b, DevIndex ix, MapPar p, int *rows, uint32_t rowlen, int full_gc) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
+  const uint32_t ntask = *b.rc_count;
+  int *Hp = rows + (size_t)tid * 2 * rowlen, *Ep = Hp + rowlen;
+  int8_t M[64];
+  score_matrix(M, p.match, p.mismatch);
+  for (uint32_t t = tid; t < ntask; t += nthr) {
+    RCand c = b.rcpool[t];
+    if (c.flags & (RCF_ERR | RCF_SCORED)) { if (!(c.flags & RCF_BANDED) || (c.flags & RCF_ERR)) continue; }
+    const uint32_t qlen = read_len(b, c.rid), wlen = (uint32_t)(c.re - c.rs + 1);
+    const uint8_t *q = ((c.flags & RCF_REVERSE) ? b.codes_rc : b.codes) + b.read_off[c.rid];
+    const uint64_t gbase = (c.sqidx < 0 ? 0ull : ix.sop[c.sqidx]) + c.rs;
+    bool banded = (c.flags & RCF_BANDED) != 0;
+    if (!banded) {
+      if (wlen <= (uint32_t)SW_FULL_WMAX && qlen <= (uint32_t)full_gc) continue;   // k_sw_full did / will do it
+      c.swscor = sw_full_scalar(q, qlen, ix.packed, gbase, wlen, M, -p.gap_init, -p.gap_ext, Hp, Ep);
+      if (c.swscor >= 65535) banded = true;
+    }
+    if (banded) {
+      Band bd;
+      if (band_init(bd, c.band_l, c.band_r, (int)c.qs, (int)c.qe, (int)qlen, 0, (int)wlen - 1, (int)wlen)) { b.rcpool[t].flags = c.flags | RCF_ERR; continue; }
+      c.swscor = band_fast_scalar(bd, q, ix.packed, gbase, M, -p.gap_init, -p.gap_ext, Hp, Ep);
+    }
+    b.rcpool[t].swscor = c.swscor;
+    b.rcpool[t].flags = c.flags | RCF_SCORED;
+  }
+}
+
+// stand-alone K2a over explicit (query, window) code arrays -- parity tests of the kernel
+template <int G, int C>
+__global__ void __launch_bounds__(64) k_sw_full_raw(const uint8_t *qcodes, const uint32_t *q_off, const uint8_t *rcodes,
+                                                     const uint32_t *r_off, uint32_t ntask, MapPar p, int32_t *scores) {
+  constexpr int NG = 64 / G;
+  constexpr int WMAX = SW_FULL_WMAX;
+  __shared__ uint8_t win[NG][WMAX + 8];
+  __shared__ uint2 tab[8];
+  const int lane = threadIdx.x, g = lane % G, grp = lane / G;
+  const int bias = (p.mismatch < p.mismatch - p.match ? -p.mismatch : -(p.mismatch - p.match));
+  const int gi = -p.gap_init, ge = -p.gap_ext;
+  if (lane < 8) {
+    int rb = lane == 7 ? 0 : ((lane == 6 || lane == 4) ? 5 : lane);
+    uint32_t w[2] = {0, 0};
+    for (int qc = 0; qc < 8; qc++) {
+      int v = (rb == 5 || qc >= 4) ? 0 : ((rb == qc) ? p.match : p.mismatch);
+      w[qc >> 2] |= (uint32_t)((v + bias) & 0xff) << (8 * (qc & 3));
+    }
+    tab[lane] = make_uint2(w[0], w[1]);
+  }
+  __syncthreads();
+  const uint32_t ngroups = gridDim.x * NG;
+  for (uint32_t t0 = blockIdx.x * NG; t0 < ntask; t0 += ngroups) {
+    const uint32_t t = t0 + grp;
+    uint32_t qlen = 0, wlen = 0;
+    const uint8_t *q = qcodes, *r = rcodes;
+    bool live = false;
+    if (t < ntask) {
+      qlen = q_off[t + 1] - q_off[t]; wlen = r_off[t + 1] - r_off[t];
+      q += q_off[t]; r += r_off[t];
+      live = wlen <= (uint32_t)WMAX && qlen <= (uint32_t)(G * C);
+    }
+    if (!live) { qlen = 0; wlen = 0; }
+    for (uint32_t i = g; i < wlen; i += G) { uint32_t cd = r[i] & 7; win[grp][i] = (uint8_t)(cd == 7 ? 0 : (cd == 6 || cd == 4) ? 5 : cd); }
+    uint32_t sel[C];
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) {
+      uint32_t j = (uint32_t)(g * C + cc);
+      uint32_t qc = (j < qlen) ? (q[j] & 7u) : 5u;
+      sel[cc] = 0x0c0c0c00u | qc;
+    }
+    int H[C], E[C];
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) { H[cc] = 0; E[cc] = 0; }
+    int best = 0, F = 0, prev_hl = 0;
+    int nstep = (int)wlen + G - 1;
+    for (int o = 32; o > 0; o >>= 1) nstep = max(nstep, __shfl_xor(nstep, o));
+    __syncthreads();
+    for (int step = 0; step < nstep; step++) {
+      const int row = step - g;
+      const uint32_t rb = (row >= 0 && row < (int)wlen) ? win[grp][row] : 5u;
+      const uint2 tr = tab[rb];
+      int hl = shr1<G>(H[C - 1]);
+      int fin = shr1<G>(F);
+      if (g == 0) { hl = 0; fin = 0; }
+      int diag = prev_hl;
+      prev_hl = hl;
+      F = fin;
+#pragma unroll
+      for (int cc = 0; cc < C; cc++) {
+        const int w = (int)__builtin_amdgcn_perm(tr.y, tr.x, sel[cc]);
+        const int h = diag + w - bias;
+        const int hh = max(max(h, E[cc]), F);
+        best = max(best, hh);
+        diag = H[cc];
+        H[cc] = hh;
+        const int tt = hh - gi;
+        E[cc] = max(max(E[cc] - ge, tt), 0);
+        F = max(max(F - ge, tt), 0);
+      }
+    }
+    for (int o = G / 2; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
+    if (t < ntask && g == 0) scores[t] = live ? best : -1;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host-side launchers (declared in smg_kernels.h)
+// ---------------------------------------------------------------------------------------
+#define SMG_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+int launch_encode(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint32_t n, uint8_t *codes, uint8_t *codes_rc) {
+  if (!n) return 0;
+  uint32_t grid = n < 16384u ? n : 16384u;
+  hipLaunchKernelGGL(k_encode, dim3(grid), dim3(64), 0, s, bases, off, n, codes, codes_rc);
+  SMG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_seed(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint8_t *scratch, size_t sbytes, uint32_t nslots) {
+  if (!b.nreads) return 0;
+  const int use_lds = sbytes <= 48 * 1024;
+  uint32_t items = 2 * b.nreads;
+  uint32_t grid = use_lds ? (items < 32768u ? items : 32768u) : (items < nslots ? items : nslots);
+  hipLaunchKernelGGL(k_seed, dim3(grid), dim3(64), use_lds ? sbytes : 0, s, b, ix, p, scratch, sbytes, use_lds);
+  SMG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_cands(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint8_t *scratch, size_t sbytes, uint32_t nslots,
+                 uint32_t hcap, uint32_t ngrp, uint32_t segcap, uint32_t candcap, int slot_per_read) {
+  if (!b.nreads) return 0;
+  uint32_t grid = b.nreads < nslots ? b.nreads : nslots;
+  hipLaunchKernelGGL(k_cands, dim3(grid), dim3(64), 0, s, b, ix, p, scratch, sbytes, hcap, ngrp, segcap, candcap, slot_per_read);
+  SMG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_replay(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p) {
+  if (!b.nreads) return 0;
+  hipLaunchKernelGGL(k_replay, dim3((b.nreads + 255) / 256), dim3(256), 0, s, b, ix, p);
+  SMG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_align(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint8_t *scratch, size_t sbytes, uint32_t nslots,
+                 uint32_t wincap, uint64_t dircap, uint32_t rescap, uint32_t dstrcap) {
+  if (!b.nreads) return 0;
+  uint32_t grid = b.nreads < nslots ? b.nreads : nslots;
+  hipLaunchKernelGGL(k_align, dim3(grid), dim3(64), 0, s, b, ix, p, scratch, sbytes, wincap, dircap, rescap, dstrcap);
+  SMG_LAUNCH_CHECK();
+  return 0;
+}
+
+int sw_full_geometry(uint32_t qmax_len, int *G, int *C) {
+  if (qmax_len <= 64) { *G = 4; *C = 16; }
+  else if (qmax_len <= 104) { *G = 8; *C = 13; }
+  else if (qmax_len <= 160) { *G = 8; *C = 20; }
+  else if (qmax_len <= 256) { *G = 16; *C = 16; }
+  else if (qmax_len <= 512) { *G = 16; *C = 32; }
+  else { *G = 0; *C = 0; return -1; }
+  return 0;
+}
+
+template <int G, int C>
+static void launch_sw_full_t(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t ntask_cap, uint32_t grid) {
+  hipLaunchKernelGGL((k_sw_full<G, C>), dim3(grid), dim3(64), 0, s, b, ix, p, ntask_cap);
+}
+
+int launch_sw_full(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t qmax_len, uint32_t ntask_cap, uint32_t grid) {
+  int G, C;
+  if (sw_full_geometry(qmax_len, &G, &C)) return 0;    // nothing for the register-tiled kernel: k_sw_scalar takes all
+  if (G == 4) launch_sw_full_t<4, 16>(s, b, ix, p, ntask_cap, grid);
+  else if (G == 8 && C == 13) launch_sw_full_t<8, 13>(s, b, ix, p, ntask_cap, grid);
+  else if (G == 8) launch_sw_full_t<8, 20>(s, b, ix, p, ntask_cap, grid);
+  else if (C == 16) launch_sw_full_t<16, 16>(s, b, ix, p, ntask_cap, grid);
+  else launch_sw_full_t<16, 32>(s, b, ix, p, ntask_cap, grid);
+  SMG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_sw_scalar(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, int *rows, uint32_t rowlen, uint32_t nthreads,
+                     uint32_t qmax_len) {
+  int G, C;
+  int full_gc = sw_full_geometry(qmax_len, &G, &C) ? 0 : G * C;
+  hipLaunchKernelGGL(k_sw_scalar, dim3(nthreads / 64), dim3(64), 0, s, b, ix, p, rows, rowlen, full_gc);
+  SMG_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int G, int C>
+static void launch_sw_raw_t(hipStream_t s, const uint8_t *q, const uint32_t *qo, const uint8_t *r, const uint32_t *ro, uint32_t n,
+                            const MapPar &p, int32_t *sc, uint32_t grid) {
+  hipLaunchKernelGGL((k_sw_full_raw<G, C>), dim3(grid), dim3(64), 0, s, q, qo, r, ro, n, p, sc);
+}
+
+int launch_sw_full_raw(hipStream_t s, const uint8_t *q, const uint32_t *qo, const uint8_t *r, const uint32_t *ro, uint32_t n,
+                       const MapPar &p, int32_t *sc, uint32_t qmax_len) {
+  int G, C;
+  if (!n) return 0;
+  if (sw_full_geometry(qmax_len, &G, &C)) return -1;
+  uint32_t grid = (n + (64 / G) - 1) / (64 / G);
+  if (grid > 8192) grid = 8192;
+  if (G == 4) launch_sw_raw_t<4, 16>(s, q, qo, r, ro, n, p, sc, grid);
+  else if (G == 8 && C == 13) launch_sw_raw_t<8, 13>(s, q, qo, r, ro, n, p, sc, grid);
+  else if (G == 8) launch_sw_raw_t<8, 20>(s, q, qo, r, ro, n, p, sc, grid);
+  else if (C == 16) launch_sw_raw_t<16, 16>(s, q, qo, r, ro, n, p, sc, grid);
+  else launch_sw_raw_t<16, 32>(s, q, qo, r, ro, n, p, sc, grid);
+  SMG_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace smg

@@ -34,7 +34,9 @@ struct Batch {                          // one block of reads resident in HBM
   Result *respool; uint64_t rescap; unsigned long long *res_count;
   uint8_t *dstrpool; uint64_t dstrcap; unsigned long long *dstr_count;
   int32_t *err_flag;                    // batch-wide first error
+  unsigned long long *work;             // [8] work counters (WK_*), one atomic per workgroup
 };
+enum : int { WK_LOOKUPS = 0, WK_HITS = 1, WK_CELLS_FULL = 2, WK_TASKS_FULL = 3, WK_CELLS_BAND = 4, WK_NWORK = 8 };
 
 SMG_HD inline uint32_t read_len(const Batch &b, uint32_t r) { return (uint32_t)(b.read_off[r + 1] - b.read_off[r]); }
 
@@ -89,7 +91,8 @@ SMG_HD inline SeedScratch seed_scratch_carve(uint8_t *base, uint32_t qmax, int s
   return x;
 }
 
-SMG_HD inline void stage_seed(const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t r, uint32_t st, SeedScratch &x) {
+// returns the number of index lookups made (wave-uniform)
+SMG_HD inline uint32_t stage_seed(const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t r, uint32_t st, SeedScratch &x) {
   const uint32_t rs = 2 * r + st;
   const uint32_t qlen = read_len(b, r);
   const uint8_t *codes = b.codes + b.read_off[r];
@@ -104,7 +107,7 @@ SMG_HD inline void stage_seed(const Batch &b, const DevIndex &ix, const MapPar &
 
   if (qlen < (uint32_t)k) {          // ERRCODE_SHORTSEQ, swallowed by rmapSingle (rmap.c:1736)
     SMG_LANE0 { hdr.n_seeds = 0; hdr.seed_rank = 0; hdr.status = st ? HI_REVERSE : 0; hdr.qlen = qlen; hdr.nhit_rank = hdr.nhit_tot = 0; }
-    return;
+    return 0;
   }
   const uint32_t nk = qlen - (uint32_t)k + 1;
   const uint64_t wordmask = (1ull << (2 * k)) - 1;
@@ -137,10 +140,10 @@ SMG_HD inline void stage_seed(const Batch &b, const DevIndex &ix, const MapPar &
   SMG_SYNC();
 
   // (2) repeat filter over the previous NREPEATS looked-at words (hashhit.c:325-340), then lookup
-  uint32_t nseeds = 0;
+  uint32_t nseeds = 0, nlook = 0;
   SMG_PAR_CHUNKS(base, nvalid) {
     uint32_t j = base + SMG_LANE;
-    bool hit = false;
+    bool hit = false, looked = false;
     uint32_t t = 0, nh = 0, posidx = 0;
     if (j < nvalid) {
       t = x.vt[j];
@@ -150,11 +153,13 @@ SMG_HD inline void stage_seed(const Batch &b, const DevIndex &ix, const MapPar &
       if (rep) qmask[t] = HQ_REPEAT;
       else {
         nh = index_lookup(ix, w, &posidx);
+        looked = true;
         if (nh < 1) qmask[t] = HQ_NOHIT;
         else if (ncut > 0 && nh > ncut) qmask[t] = HQ_MULTIHIT;
         else { qmask[t] = HQ_NORMHIT; hit = true; }
       }
     }
+    (void)compact_slot(looked, nlook);
     uint32_t slot = compact_slot(hit, nseeds);
     if (hit) { x.key[slot] = nh; x.sidx[slot] = slot; x.sposidx[slot] = posidx; x.sqoffs[slot] = t; }
   }
@@ -196,6 +201,7 @@ SMG_HD inline void stage_seed(const Batch &b, const DevIndex &ix, const MapPar &
       out[i] = sr;
     }
   }
+  return nlook;
 }
 
 // =======================================================================================
@@ -254,7 +260,8 @@ SMG_HD inline uint32_t seq_of_pos(const uint32_t *seqlo, int nseq, uint32_t pos)
   return lo;
 }
 
-SMG_HD inline void stage_cands(const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t r, CandScratch &x) {
+// returns the number of hits gathered (wave-uniform)
+SMG_HD inline uint32_t stage_cands(const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t r, CandScratch &x) {
   const uint32_t qlen = read_len(b, r);
   CandHdr &ch = b.ch[r];
   const int k = ix.k, s = ix.s;
@@ -263,7 +270,7 @@ SMG_HD inline void stage_cands(const Batch &b, const DevIndex &ix, const MapPar 
 
   if (qlen < (uint32_t)k) {
     SMG_LANE0 { ch.ncand = ch.n_sort = ch.n_mincover = ch.max_cover = ch.max2nd_cover = 0; ch.cover_deficit[0] = ch.cover_deficit[1] = 0; ch.rc_off = 0; ch.err = 0; ch.nhits[0] = ch.nhits[1] = 0; }
-    return;
+    return 0;
   }
   // calcMinKtup (rmap.c:240-247) and the coverage threshold of mapSingleRead (:1283-1289)
   uint32_t min_cover = p.min_cover;
@@ -465,9 +472,11 @@ SMG_HD inline void stage_cands(const Batch &b, const DevIndex &ix, const MapPar 
     if (i < n_sort) {
       RCand c;
       if (cand_offsets(c, x.cand[x.sort_idx[i]], ix, qlen)) { c.flags |= RCF_ERR; c.rs = c.re = 0; c.qs = c.qe = 0; c.band_l = c.band_r = 0; }
+      c.rid = r; c.pad = 0;
       b.rcpool[rc_off + i] = c;
     }
   }
+  return nkeys;
 }
 
 // =======================================================================================

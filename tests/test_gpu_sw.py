@@ -1,0 +1,66 @@
+"""K2a kernel (register-tiled, DPP) against the oracle's textbook Gotoh maximum on random
+(query, window) pairs in every tile geometry, with indels, Ns, and scores past 8-bit range."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def _pairs(rng, n, qlen_lo, qlen_hi, with_n):
+    qs, ws = [], []
+    for _ in range(n):
+        ql = int(rng.integers(qlen_lo, qlen_hi + 1))
+        q = rng.integers(0, 4, size=ql, dtype=np.uint8)
+        # window: mutated copy of the query embedded in random flanks, or unrelated
+        if rng.random() < 0.8:
+            core = q.copy()
+            m = rng.random(ql) < rng.choice([0.0, 0.02, 0.1, 0.3])
+            core = np.where(m, (core + rng.integers(1, 4, size=ql)) & 3, core).astype(np.uint8)
+            if rng.random() < 0.5 and ql > 20:
+                p = int(rng.integers(5, ql - 5))
+                core = np.concatenate([core[:p], core[p + int(rng.integers(1, 4)):]]) if rng.random() < 0.5 else \
+                    np.concatenate([core[:p], rng.integers(0, 4, size=int(rng.integers(1, 4)), dtype=np.uint8), core[p:]])
+            w = np.concatenate([rng.integers(0, 4, size=int(rng.integers(0, 40)), dtype=np.uint8), core,
+                                rng.integers(0, 4, size=int(rng.integers(0, 40)), dtype=np.uint8)])
+        else:
+            w = rng.integers(0, 4, size=int(rng.integers(1, ql + 80)), dtype=np.uint8)
+        if with_n:
+            if rng.random() < 0.3:
+                q[int(rng.integers(0, ql))] = 5
+            if rng.random() < 0.3:
+                w[int(rng.integers(0, len(w)))] = 5
+        qs.append(q.tobytes())
+        ws.append(w.tobytes())
+    return qs, ws
+
+
+@pytest.mark.parametrize("qlo,qhi", [(32, 64), (65, 104), (105, 160), (161, 256), (257, 512)])
+def test_sw_full_kernel_matches_oracle(qlo, qhi, oracle_built):
+    from smalt_amd import api
+    rng = np.random.default_rng(qlo * 7919 + qhi)
+    seqs = [bytes(rng.choice(list(b"ACGT"), size=4000).astype(np.uint8))]
+    oix = ol.build_index(seqs, ["s"], 11, 3)
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        pre = os.path.join(tmp, "x")
+        ol.lib().or_index_write(oix, pre.encode())
+        gix = api.Index.load(pre, 0)
+    mp = api.Mapper(gix, 16, 512)
+    par = gix.default_params()
+    M = (C.c_int8 * 64)()
+    ol.lib().or_score_matrix(M, 1, -2)
+    try:
+        for with_n in (False, True):
+            qs, ws = _pairs(rng, 700, qlo, qhi, with_n)
+            got = mp.sw_full_batch(qs, ws, par)
+            for i, (q, w) in enumerate(zip(qs, ws)):
+                exp = ol.lib().or_sw_full(q, len(q), w, len(w), M, -4, -3)
+                assert got[i] == exp, (i, len(q), len(w), got[i], exp)
+    finally:
+        mp.close()
+        gix.close()
+        ol.lib().or_index_free(oix)
