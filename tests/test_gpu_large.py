@@ -1,0 +1,91 @@
+"""Larger seeded workloads on the GPU against the CPU oracle (results + per-read scalars of every
+read), including repeat-rich reads that exercise the hit-list allocation-boundary protocol, and
+the torch-built index image against the oracle's builder."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_map_all(oix, reads, par):
+    m = ol.Mapper(oix)
+    out = []
+    for r in reads:
+        rv, res = m.map(r, b"I" * len(r), par)
+        assert rv == 0
+        st = m.stats()
+        out.append((res, dict(swmax=st[0], sw2nd=st[1], nseg=st[2], nseg_tot=st[3], nhit=st[4], nhit_tot=st[5])))
+    m.close()
+    return out
+
+
+def test_repeat_rich_genome_matches_oracle(oracle_built, tmp_path):
+    from smalt_amd import api, synth
+    ch = synth.make_reference(4, 2_500_000, seed=21, repeat_frac=0.15, n_fam=1, cons_len=300, divergence=0.05)
+    reads, _ = synth.make_reads(ch, 1200, 150, seed=22, sub_rate=0.01, indel_read_frac=0.05)
+    seqs = [synth.codes_to_ascii(c) for c in ch]
+    rb = [synth.codes_to_ascii(r) for r in reads]
+    oix0 = ol.build_index(seqs, ["c%d" % i for i in range(4)], 13, 6)
+    pre = str(tmp_path / "rep")
+    assert ol.lib().or_index_write(oix0, pre.encode()) == 0
+    oix = ol.lib().or_index_read(pre.encode())
+    exp = _oracle_map_all(oix, rb, ol.default_params(oix))
+    assert max(e[1]["nhit"] for e in exp) > 32768          # allocation-boundary path is exercised
+    gix = api.Index.load(pre, 0)
+    mp = api.Mapper(gix, len(rb), 150)
+    try:
+        res, stats = mp.map_batch(rb, [b"I" * len(r) for r in rb], gix.default_params())
+    finally:
+        mp.close()
+        gix.close()
+    for i in range(len(rb)):
+        assert stats[i]["err"] == 0
+        assert res[i] == exp[i][0], i
+        for kk, v in exp[i][1].items():
+            assert stats[i][kk] == v, (i, kk)
+
+
+def test_torch_index_equals_oracle_index(oracle_built, tmp_path):
+    import torch
+    from smalt_amd import api, gpuindex, synth
+    dev = torch.device("cuda", 0)
+    nchr, chrlen, k, s = 3, 300_001, 9, 6
+    ref = gpuindex.make_reference_gpu(nchr, chrlen, 5, dev, repeat_frac=0.1, n_fam=3)
+    sop = np.arange(nchr + 1, dtype=np.int64) * chrlen
+    packed = gpuindex.pack_reference(ref)
+    idx, pos = gpuindex.build_perfect_index(ref, sop, k, s)
+    codes = ref.cpu().numpy()
+    seqs = [synth.codes_to_ascii(codes[i * chrlen:(i + 1) * chrlen]) for i in range(nchr)]
+    oix = ol.build_index(seqs, ["c%d" % i for i in range(nchr)], k, s)
+    o = oix.contents
+    assert o.typ == 0
+    assert np.array_equal(np.ctypeslib.as_array(o.idx, shape=(o.nkeys + 1,)), idx.cpu().numpy().view(np.uint32))
+    assert np.array_equal(np.ctypeslib.as_array(o.pos, shape=(o.npos,)), pos.cpu().numpy().view(np.uint32))
+    assert np.array_equal(np.ctypeslib.as_array(o.packed, shape=(o.totlen // 10 + 1,)), packed.cpu().numpy().view(np.uint32))
+    # map through the adopted device image
+    reads_ascii, _ = gpuindex.make_reads_gpu(ref, sop, 400, 100, 9)
+    rb = [bytes(x) for x in reads_ascii.cpu().numpy().reshape(400, 100)]
+    desc = api.IndexDesc()
+    desc.k, desc.s, desc.typ, desc.nbits_key, desc.nbits_lo = k, s, 0, 2 * k, 0
+    desc.npos, desc.nwords = int(pos.numel()), 0
+    desc.idx, desc.pos, desc.packed = idx.data_ptr(), pos.data_ptr(), packed.data_ptr()
+    desc.nseq = nchr
+    sop_u64 = np.ascontiguousarray(sop.astype(np.uint64))
+    desc.sop = sop_u64.ctypes.data
+    desc.on_device = 1
+    torch.cuda.synchronize()
+    gix = api.Index.from_desc(desc, 0)
+    mp = api.Mapper(gix, 400, 100)
+    try:
+        res, stats = mp.map_batch(rb, None, gix.default_params())
+    finally:
+        mp.close()
+        gix.close()
+    exp = _oracle_map_all(oix, rb, ol.default_params(oix))
+    for i in range(len(rb)):
+        assert res[i] == exp[i][0], i
