@@ -49,7 +49,11 @@ def cpu_baseline(args, ref_pack, idx, pos, sop, names, k, s, reads_ascii, nreads
     """Time the UNMODIFIED reference (`oracle/_ref/smalt map -n T`) on a bounded sample of the same
     reads against the same index (kind "reference"); falls back to the oracle port."""
     smalt = os.path.join(ROOT, "oracle", "_ref", "smalt")
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get('SMALT_BENCH_CPU_THREADS', '16'))))   # the GPU box's CPU share per GPU
     from smalt_amd import indexfile
     n2 = min(args.cpu_sample, nreads)
     n1 = max(n2 // 10, 1000)
@@ -148,10 +152,14 @@ def main():
         torch.cuda.synchronize()
         bcast_ms = (time.time() - tb) * 1e3
     # reads of this rank (weak scaling: every rank maps args.reads reads of its own)
+    torch.cuda.synchronize()
+    t_idx = time.time() - t0
     reads_ascii, _ = gpuindex.make_reads_gpu(ref, sop, args.reads, args.read_len, 777 + rank)
     del ref
     torch.cuda.synchronize()
     setup_s = time.time() - t0
+    if rank == 0:
+        print("[bench] setup: reference+index %.1f s, reads %.1f s" % (t_idx, setup_s - t_idx), file=sys.stderr, flush=True)
 
     desc = api.IndexDesc()
     desc.k, desc.s, desc.typ, desc.nbits_key, desc.nbits_lo = k, s, 0, 2 * k, 0
@@ -197,7 +205,10 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
+        tw = time.time()
         one_step(False)
+        if rank == 0:
+            print("[bench] warmup step %.2f s" % (time.time() - tw), file=sys.stderr, flush=True)
     barrier()
     t1 = time.time()
     mapped = 0
