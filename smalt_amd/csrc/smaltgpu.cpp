@@ -148,7 +148,7 @@ struct smaltgpu_mapper {
   uint8_t *d_counters = nullptr;            // rc_count | res_count | dstr_count | err_flag | work[8]
   uint8_t *seed_scr = nullptr; size_t seed_bytes = 0; uint32_t seed_slots = 0;
   uint8_t *cand_scr = nullptr; size_t cand_bytes = 0; uint32_t cand_slots = 0;
-  uint32_t hcap = 0, ngrp = 0, segcap = 0, candcap = 0;
+  CandGeom cg;
   uint8_t *cand_scr_dbg = nullptr; uint32_t cand_dbg_reads = 0;
   int *sw_rows = nullptr; uint32_t sw_rowlen = 0, sw_threads = 0;
   uint8_t *align_scr = nullptr; size_t align_bytes = 0; uint32_t align_slots = 0;
@@ -232,12 +232,14 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
     double t = (double)max_read_len * log((double)(max_read_len > 1 ? max_read_len : 2)) * HITLST_LOGQLEN_FACT;
     uint64_t alloc = HITLST_BLKSZ;
     if (t > (double)alloc) alloc = (((uint64_t)t + HITLST_BLKSZ - 1) / HITLST_BLKSZ) * HITLST_BLKSZ;
-    m->hcap = next_pow2(2 * alloc);
-    m->ngrp = d.nseq < 512 ? (uint32_t)d.nseq : 1u;     // both modes fit: concatenated mode uses group 0
-    m->segcap = m->hcap / 2;
-    m->candcap = m->hcap / 4 < 4096 ? 4096 : m->hcap / 4;
-    m->cand_bytes = cand_scratch_bytes(m->qmax, d.s, m->hcap, m->ngrp, m->segcap, m->candcap);
-    uint64_t budget = 6ull << 30;
+    memset(&m->cg, 0, sizeof(m->cg));
+    m->cg.hcap = next_pow2(2 * alloc);
+    m->cg.hcap_strand = next_pow2(alloc);
+    m->cg.ngrp = d.nseq < 512 ? (uint32_t)d.nseq : 1u;  // both modes fit: concatenated mode uses group 0
+    m->cg.segcap = m->cg.hcap / 2;
+    m->cg.candcap = m->cg.hcap;                         // every hit can be a candidate of its own (mincover = k)
+    m->cg.slot_bytes = m->cand_bytes = cand_slot_bytes(m->cg, m->qmax, d.s);
+    uint64_t budget = 12ull << 30;
     uint64_t slots = budget / m->cand_bytes;
     if (slots > 4096) slots = 4096;
     if (slots < 64) slots = 64;
@@ -332,7 +334,7 @@ static int run_pipeline(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_
   HIPCHK(hipEventRecord(m->ev[T_SEED], s));
   if (!rv) rv = launch_seed(s, b, d, p, m->seed_scr, m->seed_bytes, m->seed_slots);
   HIPCHK(hipEventRecord(m->ev[T_CANDS], s));
-  if (!rv) rv = launch_cands(s, b, d, p, cscr, m->cand_bytes, cslots, m->hcap, ngrp, m->segcap, m->candcap, slot_per_read);
+  { CandGeom g = m->cg; g.ngrp = ngrp; g.debug = slot_per_read; if (!rv) rv = launch_cands(s, b, d, p, cscr, cslots, g); }
   HIPCHK(hipEventRecord(m->ev[T_SW_FULL], s));
   if (!rv) rv = launch_sw_full(s, b, d, p, m->max_len, b.rccap, 8192);
   HIPCHK(hipEventRecord(m->ev[T_SW_SCALAR], s));
@@ -389,13 +391,14 @@ extern "C" int smaltgpu_fetch_results(smaltgpu_mapper *m, smaltgpu_batch_out *ou
   m->o_stat.resize(n ? n : 1);
   uint64_t w = 0;
   int first_err = 0;
+  uint32_t first_err_read = 0, nerr = 0;
   for (uint32_t i = 0; i < n; i++) {
     const ReadStat &st = m->h_stat[i];
     m->h_res_off[i] = w;
     smaltgpu_readstat &os = m->o_stat[i];
     os.swatscor_max = st.swmax; os.swatscor_2ndmax = st.sw2nd; os.n_ali_done = st.nseg; os.n_ali_tot = st.nseg_tot;
     os.n_hits_used = st.nhit; os.n_hits_tot = st.nhit_tot; os.errcode = st.err; os.nres = st.nres;
-    if (st.err && !first_err) first_err = st.err;
+    if (st.err) { if (!first_err) { first_err = st.err; first_err_read = i; } nerr++; }
     for (uint32_t j = 0; j < st.nres; j++) {
       const Result &r = m->h_res[st.res_off + j];
       smaltgpu_result &o = m->o_res[w++];
@@ -405,7 +408,7 @@ extern "C" int smaltgpu_fetch_results(smaltgpu_mapper *m, smaltgpu_batch_out *ou
   }
   m->h_res_off[n] = w;
   out->nreads = n; out->res_off = m->h_res_off.data(); out->res = m->o_res.data(); out->diffstr = m->h_dstr.data(); out->stat = m->o_stat.data();
-  if (first_err) return fail(first_err, "%d: at least one read hit a device-side limit or assertion (see stat[].errcode)", first_err);
+  if (first_err) return fail(first_err, "%u of %u reads hit a device-side limit (-5) or assertion (-6); first: read %u code %d (see stat[].errcode)", nerr, n, first_err_read, first_err);
   return SMALTGPU_OK;
 }
 
@@ -463,7 +466,9 @@ extern "C" long smaltgpu_dump_read(smaltgpu_mapper *m, uint32_t i, const char *n
       fetch(qmask, b.qmask + 2 * (size_t)i * m->qmax, 2 * (size_t)m->qmax) || fetch(ch, b.ch + i, 1) || fetch(ctl, b.ctl + i, 1) ||
       fetch(st, b.stat + i, 1) || fetch(slot, m->cand_scr_dbg + m->cand_bytes * i, m->cand_bytes)) return SMALTGPU_ENODEV;
   const uint32_t ngrp = (m->last_par.flags & FLG_SEQBYSEQ) ? (uint32_t)d.nseq : 1u;
-  CandScratch cx = cand_scratch_carve(slot.data(), m->qmax, d.s, m->hcap, ngrp, m->segcap, m->candcap);
+  const bool v2 = cands_v2_applicable(m->last_par, d.k, d.s, (uint32_t)(m->h_off[i + 1] - m->h_off[i]));
+  CandScratch cx = cand_scratch_carve(slot.data(), m->qmax, d.s, m->cg.hcap, ngrp, m->cg.segcap, m->cg.candcap);
+  CandsV2Scratch c2 = cands_v2_carve(nullptr, 0, slot.data(), m->qmax, d.s, m->cg.hcap_strand, ngrp, m->cg.candcap, true);
   std::vector<RCand> rc; std::vector<Result> res; std::vector<uint8_t> dstr;
   if (fetch(rc, b.rcpool + ch[0].rc_off, ch[0].n_sort) || fetch(res, b.respool + st[0].res_off, st[0].nres)) return SMALTGPU_ENODEV;
   size_t nd = 0;
@@ -471,8 +476,9 @@ extern "C" long smaltgpu_dump_read(smaltgpu_mapper *m, uint32_t i, const char *n
   if (fetch(dstr, b.dstrpool + st[0].dstr_off, nd)) return SMALTGPU_ENODEV;
   v.qlen = (uint32_t)(m->h_off[i + 1] - m->h_off[i]); v.qmax = m->qmax; v.k = d.k;
   for (int s2 = 0; s2 < 2; s2++) { v.hi[s2] = hi[s2]; v.seeds[s2] = seeds.data() + (size_t)s2 * m->qmax; v.qmask[s2] = qmask.data() + (size_t)s2 * m->qmax; }
-  v.ch = ch[0]; v.cand = cx.cand; v.sort_idx = cx.sort_idx; v.sort_keys = cx.sort_keys; v.rc = rc.data(); v.ctl = ctl[0]; v.st = st[0];
-  v.res = res.data(); v.dstr = dstr.data(); v.hitwords = cx.keys; v.grp_first = cx.grp_first; v.grp_cnt = cx.grp_cnt; v.ngrp = ngrp;
+  v.ch = ch[0]; v.rc = rc.data(); v.ctl = ctl[0]; v.st = st[0]; v.res = res.data(); v.dstr = dstr.data(); v.ngrp = ngrp;
+  if (v2) { v.cand = c2.cand; v.sort_idx = c2.sort_idx; v.sort_keys = c2.sort_keys; v.hitwords = c2.dbg_words; v.grp_first = c2.dbg_first; v.grp_cnt = c2.dbg_cnt; }
+  else { v.cand = cx.cand; v.sort_idx = cx.sort_idx; v.sort_keys = cx.sort_keys; v.hitwords = cx.keys; v.grp_first = cx.grp_first; v.grp_cnt = cx.grp_cnt; }
   std::string o;
   dump_read(o, v, i, name, m->debug >= 2);
   if (buf && bufsiz) { size_t c = o.size() < bufsiz - 1 ? o.size() : bufsiz - 1; memcpy(buf, o.data(), c); buf[c] = 0; }

@@ -1,0 +1,557 @@
+// smg_cands.hpp -- wave-parallel form of the candidate stage (S3-S7) for the common case
+// (min_ktup == 1, reads up to 256 bases): the same results as the sequential restatement in
+// smg_stages.hpp (stage_cands), which stays as the path for everything else.
+//
+// What makes the parallel form possible (all derived from the reference's loops, see comments):
+//   * every boundary in segment.c's three scans (hit region / seed / constant-shift segment) is
+//     a LOCAL predicate on two neighbouring sorted hits, so each scan is a flag + ordered
+//     stream compaction;
+//   * addCandsFast's greedy absorption runs independently inside each hit region, so regions
+//     go to different lanes; the read-coverage mask of a region fits in 8 registers (256 bits);
+//   * candidates are emitted in (strand, sequence, region, segment) order, which an ordered
+//     compaction over "first segment of a candidate" flags reproduces exactly;
+//   * max_cover / max2nd_cover are order-free (largest and second largest DISTINCT cover).
+// The per-strand working set (hit words, seeds, segments, regions) lives in LDS when the strand
+// has at most CANDS_LDS_HITS hits, else in the HBM slot.
+// `file:line` citations refer to the reference tree (SMALT 0.7.6, src/).
+#pragma once
+#include "smg_stages.hpp"
+
+namespace smg {
+
+enum : uint32_t { CANDS_LDS_HITS = 2048 };
+
+template <class IT>
+struct StrandWork {           // one strand's working set; IT = uint16_t (LDS) or uint32_t (HBM)
+  uint64_t *dat;              // [cap]  sorted keys: seq(10) | diagonal(33) | q(20)  (strand bit cleared)
+  IT *seed_first, *seed_len;  // [cap]
+  IT *segm_first, *segm_nseed, *segm_cover;   // [cap]
+  IT *reg_first, *reg_num;    // [cap]
+  uint8_t *cflag;             // [cap]  1: a candidate starts at this segment
+  uint32_t cap;
+};
+
+template <class IT>
+SMG_HD inline size_t strand_work_bytes(uint32_t cap) { return (size_t)cap * (8 + 7 * sizeof(IT) + 1) + 64; }
+
+template <class IT>
+SMG_HD inline StrandWork<IT> strand_work_carve(uint8_t *base, uint32_t cap) {
+  StrandWork<IT> w;
+  w.cap = cap;
+  w.dat = (uint64_t *)base; base += (size_t)cap * 8;
+  w.seed_first = (IT *)base; base += (size_t)cap * sizeof(IT);
+  w.seed_len = (IT *)base; base += (size_t)cap * sizeof(IT);
+  w.segm_first = (IT *)base; base += (size_t)cap * sizeof(IT);
+  w.segm_nseed = (IT *)base; base += (size_t)cap * sizeof(IT);
+  w.segm_cover = (IT *)base; base += (size_t)cap * sizeof(IT);
+  w.reg_first = (IT *)base; base += (size_t)cap * sizeof(IT);
+  w.reg_num = (IT *)base; base += (size_t)cap * sizeof(IT);
+  w.cflag = base;
+  return w;
+}
+
+SMG_HD inline uint32_t key_q(uint64_t key) { return (uint32_t)(key & KEY_QMASK); }
+SMG_HD inline uint64_t key_diag(uint64_t key) { return (key >> KEY_QBITS) & KEY_DIAGMASK; }
+SMG_HD inline uint32_t key_grp(uint64_t key) { return (uint32_t)(key >> (KEY_QBITS + KEY_DIAGBITS)); }
+SMG_HD inline uint64_t key_packed(uint64_t key) { return (key_diag(key) << HALFBIT) | key_q(key); }   // hashhit.h:67-72
+
+// defineHitRegions (segment.c:431-444): region boundary between sorted hits a (previous) and b
+SMG_HD inline bool region_break(uint64_t a, uint64_t b, uint64_t dsthresh) {
+  return key_grp(a) != key_grp(b) || (key_packed(b) - key_packed(a)) >= dsthresh;
+}
+// makeSeedsFromHits (segment.c:493-510): hit b starts a new seed after hit a.  Inside a seed all
+// offsets are congruent to the first one modulo s, so "(qo - qoffs) % s" is local.
+SMG_HD inline bool seed_break(uint64_t a, uint64_t b, int k, int s) {
+  const uint32_t qa = key_q(a), qb = key_q(b);
+  return key_diag(a) != key_diag(b) || qb > qa + (uint32_t)k || ((qb - qa) % (uint32_t)s) != 0;
+}
+
+// 256-bit read-coverage mask in registers
+struct QMask256 { uint32_t w[8]; };
+SMG_HD inline void qm_clear(QMask256 &m) { for (int i = 0; i < 8; i++) m.w[i] = 0; }
+// add [q, q+len) ; returns the number of newly covered bases
+SMG_HD inline uint32_t qm_add(QMask256 &m, uint32_t q, uint32_t len) {
+  uint32_t added = 0;
+  const uint32_t e = q + len;
+  for (int i = 0; i < 8; i++) {
+    const uint32_t lo = (uint32_t)i * 32, hi = lo + 32;
+    if (e <= lo || q >= hi) continue;
+    const uint32_t a = q > lo ? q - lo : 0, b = e < hi ? e - lo : 32;
+    const uint32_t bits = (b >= 32 ? 0xFFFFFFFFu : ((1u << b) - 1)) & ~((1u << a) - 1);
+    added += (uint32_t)__builtin_popcount(bits & ~m.w[i]);
+    m.w[i] |= bits;
+  }
+  return added;
+}
+
+// calcSegmentBoundaries (segment.c:635-668) from the compact arrays
+template <class IT>
+SMG_HD inline void segm_bounds(const StrandWork<IT> &w, uint32_t m, int k, int s, bool is_reverse, uint32_t *qs, uint32_t *qe,
+                               uint32_t *rs, uint32_t *re) {
+  const uint32_t sa = w.segm_first[m], sb = sa + w.segm_nseed[m] - 1;
+  const uint64_t ka = w.dat[w.seed_first[sa]], kb = w.dat[w.seed_first[sb]];
+  const uint32_t qa = key_q(ka), qb = key_q(kb), lb = w.seed_len[sb];
+  *qs = qa;
+  *qe = qb + lb - 1;
+  if (is_reverse) {
+    *rs = (uint32_t)((key_diag(kb) - qb / (uint32_t)s) & SOFFSMASK);
+    *rs -= (lb - (uint32_t)k) / (uint32_t)s;
+    *re = (uint32_t)((key_diag(ka) - qa / (uint32_t)s) & SOFFSMASK);
+  } else {
+    *rs = (uint32_t)((key_diag(ka) + qa / (uint32_t)s) & SOFFSMASK);
+    *re = (uint32_t)((key_diag(kb) + qb / (uint32_t)s) & SOFFSMASK);
+    *re += (lb - (uint32_t)k) / (uint32_t)s;
+  }
+}
+
+// derriveSEGCAND (segment.c:929-1059) over segments [m0, m0 + nseg)
+template <class IT>
+SMG_HD inline int derive_cand_c(SegCand &c, const StrandWork<IT> &w, uint32_t m0, int nseg, int k, int s, uint32_t cover,
+                                uint32_t mincover_noindel, uint32_t hregix, bool is_reverse, int32_t seqidx) {
+  const uint64_t offbit = 1ull << (HALFBIT + 1);
+  segm_bounds(w, m0, k, s, is_reverse, &c.qs, &c.qe, &c.rs, &c.re);
+  int64_t shift_min = (int64_t)key_diag(w.dat[w.seed_first[w.segm_first[m0]]]), shift_2mm = shift_min, shift_start, shift_last = shift_min;
+  uint32_t maxcover = w.segm_cover[m0], qs, qe, rs, re;
+  for (int n = 1; n < nseg; n++) {
+    const uint32_t m = m0 + (uint32_t)n;
+    segm_bounds(w, m, k, s, is_reverse, &qs, &qe, &rs, &re);
+    shift_last = (int64_t)key_diag(w.dat[w.seed_first[w.segm_first[m]]]);
+    if (w.segm_cover[m] > maxcover) { shift_2mm = shift_last; maxcover = w.segm_cover[m]; }
+    if (qs < c.qs) c.qs = qs;
+    if (qe > c.qe) c.qe = qe;
+    if (rs < c.rs) c.rs = rs;
+    if (re > c.re) c.re = re;
+  }
+  uint8_t flag = 0;
+  if (is_reverse) { flag |= CANDFLG_REVERSE; shift_start = ((int64_t)c.rs) + (int64_t)((c.qe - (uint32_t)k + 1) / (uint32_t)s); }
+  else shift_start = (int64_t)((((uint64_t)c.rs) | offbit) - (uint64_t)(c.qs / (uint32_t)s));
+  const uint64_t shift_range = (uint64_t)(shift_last - shift_min);
+  const int64_t diff_shift = shift_min - shift_start;
+  if (shift_range > 32767 || diff_shift < -32768 || diff_shift > 32767) return -1;
+  c.shiftoffs = (int16_t)diff_shift;
+  if (maxcover >= mincover_noindel) {
+    const int64_t ds = shift_2mm - shift_start;
+    flag |= CANDFLG_MMALI;
+    if (ds < -32768 || ds > 32767) return -1;
+    c.shift2mm = (int16_t)ds;
+  } else c.shift2mm = 0;
+  c.flag = flag; c.pad = 0;
+  c.srange = (int16_t)shift_range;
+  c.cover = cover; c.nseg = nseg; c.hregix = hregix; c.seqidx = seqidx;
+  return 0;
+}
+
+// One strand: hits in w.dat[0..n) (unsorted keys on entry) -> candidates appended to cand[*ncand..].
+// cand_tmp: HBM array of capacity >= n used for the sparse (per first-segment) candidates.
+// Returns 0 or an SMG_ERR_* code (wave-uniform).
+template <class IT>
+SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, bool seqbyseq, uint32_t qlen, int k, int s,
+                               uint32_t mincover, SegCand *cand_tmp, SegCand *cand, uint32_t candcap, uint32_t *ncand_io,
+                               uint32_t *max_cover_io, uint32_t *max2nd_io) {
+  if (!n) return 0;
+  wave_sort_u64(w.dat, n);
+  SMG_SYNC();
+  uint32_t max_dshift = (uint32_t)(k * SEGMENTING_DIFFSHIFT / s) & 0xffffu;     // segment.c:426-429
+  { uint32_t ds = (qlen - (uint32_t)k) / (uint32_t)s + 1; if (ds < max_dshift) max_dshift = ds & 0xffffu; }
+  const uint64_t dsthresh = ((uint64_t)max_dshift) << HALFBIT;
+
+  // hits -> seeds
+  uint32_t nseed = 0;
+  SMG_PAR_CHUNKS(base, n) {
+    const uint32_t i = base + SMG_LANE;
+    bool sb = false;
+    if (i < n) sb = (i == 0) || region_break(w.dat[i - 1], w.dat[i], dsthresh) || seed_break(w.dat[i - 1], w.dat[i], k, s);
+    const uint32_t slot = compact_slot(sb, nseed);
+    if (sb) w.seed_first[slot] = (IT)i;
+  }
+  SMG_SYNC();
+  SMG_PAR_CHUNKS(base, nseed) {
+    const uint32_t j = base + SMG_LANE;
+    if (j < nseed) {
+      const uint32_t last = (j + 1 < nseed ? (uint32_t)w.seed_first[j + 1] : n) - 1;
+      w.seed_len[j] = (IT)(key_q(w.dat[last]) + (uint32_t)k - key_q(w.dat[w.seed_first[j]]));
+    }
+  }
+  // seeds -> constant-shift segments (makeSegmentsFromSeeds, segment.c:558-580)
+  uint32_t nsegm = 0;
+  SMG_PAR_CHUNKS(base, nseed) {
+    const uint32_t j = base + SMG_LANE;
+    bool gb = false;
+    if (j < nseed) {
+      if (j == 0) gb = true;
+      else {
+        const uint32_t a = w.seed_first[j], ap = w.seed_first[j - 1];
+        const uint64_t ka = w.dat[a], kp = w.dat[ap];
+        gb = region_break(w.dat[a - 1], ka, dsthresh) || key_diag(ka) != key_diag(kp) || ((key_q(ka) - key_q(kp)) % (uint32_t)s) != 0;
+      }
+    }
+    const uint32_t slot = compact_slot(gb, nsegm);
+    if (gb) w.segm_first[slot] = (IT)j;
+  }
+  SMG_SYNC();
+  SMG_PAR_CHUNKS(base, nsegm) {
+    const uint32_t m = base + SMG_LANE;
+    if (m < nsegm) {
+      const uint32_t a = w.segm_first[m], e = (m + 1 < nsegm ? (uint32_t)w.segm_first[m + 1] : nseed);
+      uint32_t cov = 0;
+      for (uint32_t j = a; j < e; j++) cov += w.seed_len[j];
+      w.segm_nseed[m] = (IT)(e - a);
+      w.segm_cover[m] = (IT)cov;
+      w.cflag[m] = 0;
+    }
+  }
+  // segments -> hit regions
+  uint32_t nreg = 0;
+  SMG_PAR_CHUNKS(base, nsegm) {
+    const uint32_t m = base + SMG_LANE;
+    bool rb = false;
+    if (m < nsegm) {
+      const uint32_t a = w.seed_first[w.segm_first[m]];
+      rb = (a == 0) || region_break(w.dat[a - 1], w.dat[a], dsthresh);
+    }
+    const uint32_t slot = compact_slot(rb, nreg);
+    if (rb) w.reg_first[slot] = (IT)m;
+  }
+  SMG_SYNC();
+  // S5: one lane per hit region (addCandsFast, segment.c:1169-1217)
+  uint32_t mx = *max_cover_io, mx2 = *max2nd_io;
+  int err = 0;
+  SMG_PAR_CHUNKS(base, nreg) {
+    const uint32_t r = base + SMG_LANE;
+    if (r < nreg) {
+      const uint32_t first = w.reg_first[r], num = (r + 1 < nreg ? (uint32_t)w.reg_first[r + 1] : nsegm) - first;
+      const int32_t seqidx = seqbyseq ? (int32_t)(key_grp(w.dat[w.seed_first[w.segm_first[first]]]) & ((1u << KEY_SEQBITS) - 1)) : -1;
+      for (uint32_t i = 0; i < num;) {
+        const uint32_t m0 = first + i;
+        uint32_t cover = w.segm_cover[m0], j = i + 1;
+        if (j < num) {
+          QMask256 mk;
+          qm_clear(mk);
+          for (uint32_t t = 0; t < (uint32_t)w.segm_nseed[m0]; t++) { const uint32_t sd = (uint32_t)w.segm_first[m0] + t; (void)qm_add(mk, key_q(w.dat[w.seed_first[sd]]), w.seed_len[sd]); }
+          for (; j < num; j++) {
+            const uint32_t m = first + j;
+            uint32_t cover_new = 0;
+            for (uint32_t t = 0; t < (uint32_t)w.segm_nseed[m]; t++) { const uint32_t sd = (uint32_t)w.segm_first[m] + t; cover_new += qm_add(mk, key_q(w.dat[w.seed_first[sd]]), w.seed_len[sd]); }
+            if ((cover_new << 1) < (uint32_t)w.segm_cover[m] && cover >= mincover) break;
+            cover += cover_new;
+          }
+        }
+        if (cover >= mincover) {
+          SegCand c;
+          if (derive_cand_c(c, w, m0, (int)(j - i), k, s, cover, mincover, r, is_reverse, seqidx)) err = SMG_ERR_ASSERT;
+          cand_tmp[m0] = c;
+          w.cflag[m0] = 1;
+          if (cover > mx2) { if (cover > mx) { mx2 = mx; mx = cover; } else if (cover != mx) mx2 = cover; }
+        }
+        i = j;
+      }
+    }
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (largest, second largest distinct) over the lanes
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t omx = (uint32_t)__shfl_xor((int)mx, o), omx2 = (uint32_t)__shfl_xor((int)mx2, o);
+    const uint32_t hi = mx > omx ? mx : omx;
+    uint32_t lo = mx2 > omx2 ? mx2 : omx2;
+    const uint32_t mn = mx < omx ? mx : omx;
+    if (mn != hi && mn > lo) lo = mn;
+    mx = hi; mx2 = lo;
+  }
+#endif
+  *max_cover_io = mx; *max2nd_io = mx2;
+  if (wave_any(err != 0)) return SMG_ERR_ASSERT;
+  SMG_SYNC();
+  // ordered compaction of the sparse candidates
+  uint32_t nc = *ncand_io;
+  bool ovf = false;
+  SMG_PAR_CHUNKS(base, nsegm) {
+    const uint32_t m = base + SMG_LANE;
+    const bool f = m < nsegm && w.cflag[m];
+    const uint32_t slot = compact_slot(f, nc);
+    if (f) { if (slot < candcap) cand[slot] = cand_tmp[m]; else ovf = true; }
+  }
+  *ncand_io = nc;
+  if (wave_any(ovf)) return SMG_ERR_CAP;
+  return 0;
+}
+
+struct CandsV2Scratch {
+  uint8_t *lds; size_t lds_bytes;        // per-workgroup LDS block (null on the host build -> HBM is used)
+  uint8_t *hbm;                          // HBM slot: strand work for large strands + cand_tmp + candidates
+  uint32_t hcap_strand;                  // capacity of the HBM strand work (hits per strand)
+  SegCand *cand_tmp; SegCand *cand; uint32_t candcap;
+  uint32_t *sort_keys, *sort_idx;
+  FillDecision *dec; uint32_t ngrp;
+  uint32_t *qbr, *frame_cnt, *frame_rank; uint32_t stride; uint8_t *qbuf;
+  uint64_t *dbg_words; uint32_t *dbg_first, *dbg_cnt;   // debug: packed hit words grouped as the dump expects (or null)
+};
+
+SMG_HD inline size_t cands_v2_hbm_bytes(uint32_t qmax, int s, uint32_t hcap_strand, uint32_t ngrp, uint32_t candcap, bool debug) {
+  const uint32_t stride = qmax / (uint32_t)s + 2;
+  size_t n = strand_work_bytes<uint32_t>(hcap_strand) + (size_t)hcap_strand * sizeof(SegCand) + (size_t)candcap * (sizeof(SegCand) + 8) +
+             (size_t)ngrp * 2 * sizeof(FillDecision) + (size_t)qmax * 5 + (size_t)s * 4 + (size_t)s * stride * 4 + 256;
+  if (debug) n += (size_t)hcap_strand * 2 * 8 + (size_t)ngrp * 2 * 8;
+  return (n + 255) & ~(size_t)255;
+}
+
+SMG_HD inline CandsV2Scratch cands_v2_carve(uint8_t *lds, size_t lds_bytes, uint8_t *hbm, uint32_t qmax, int s, uint32_t hcap_strand,
+                                            uint32_t ngrp, uint32_t candcap, bool debug) {
+  CandsV2Scratch x;
+  x.lds = lds; x.lds_bytes = lds_bytes; x.hcap_strand = hcap_strand; x.candcap = candcap; x.ngrp = ngrp;
+  uint8_t *b = hbm;
+  x.hbm = b; b += (strand_work_bytes<uint32_t>(hcap_strand) + 63) & ~(size_t)63;
+  x.cand_tmp = (SegCand *)b; b += (size_t)hcap_strand * sizeof(SegCand);
+  x.cand = (SegCand *)b; b += (size_t)candcap * sizeof(SegCand);
+  x.sort_keys = (uint32_t *)b; b += (size_t)candcap * 4;
+  x.sort_idx = (uint32_t *)b; b += (size_t)candcap * 4;
+  x.dec = (FillDecision *)b; b += (size_t)ngrp * 2 * sizeof(FillDecision);
+  x.qbr = (uint32_t *)b; b += (size_t)qmax * 4;
+  x.stride = qmax / (uint32_t)s + 2;
+  x.frame_cnt = (uint32_t *)b; b += (size_t)s * 4;
+  x.frame_rank = (uint32_t *)b; b += (size_t)s * x.stride * 4;
+  x.qbuf = b; b += qmax;
+  b = (uint8_t *)(((uintptr_t)b + 15) & ~(uintptr_t)15);
+  if (debug) {
+    x.dbg_words = (uint64_t *)b; b += (size_t)hcap_strand * 2 * 8;
+    x.dbg_first = (uint32_t *)b; b += (size_t)ngrp * 2 * 4;
+    x.dbg_cnt = (uint32_t *)b;
+  } else { x.dbg_words = nullptr; x.dbg_first = x.dbg_cnt = nullptr; }
+  return x;
+}
+
+// true when the parallel form applies to this read
+SMG_HD inline bool cands_v2_applicable(const MapPar &p, int k, int s, uint32_t qlen) {
+  return qlen <= 256 && p.min_cover < (uint32_t)(k + s);     // calcMinKtup (rmap.c:240-247) gives min_ktup == 1
+}
+
+SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t r, CandsV2Scratch &x) {
+  const uint32_t qlen = read_len(b, r);
+  CandHdr &ch = b.ch[r];
+  const int k = ix.k, s = ix.s;
+  const bool seqbyseq = (p.flags & FLG_SEQBYSEQ) != 0;
+  const uint32_t ngrp = x.ngrp;
+  if (qlen < (uint32_t)k) {
+    SMG_LANE0 { ch.ncand = ch.n_sort = ch.n_mincover = ch.max_cover = ch.max2nd_cover = 0; ch.cover_deficit[0] = ch.cover_deficit[1] = 0; ch.rc_off = 0; ch.err = 0; ch.nhits[0] = ch.nhits[1] = 0; }
+    return 0;
+  }
+  const uint32_t min_cover = (uint32_t)k;                         // (min_ktup - 1) * s + k with min_ktup == 1
+  const int mismatchdiff = p.match - p.mismatch;
+  uint32_t mincov_below_max;
+  if (p.below_max < 0) mincov_below_max = qlen - 1;
+  else {
+    mincov_below_max = ((uint32_t)(p.below_max / mismatchdiff)) * (uint32_t)s;
+    if (mincov_below_max < (uint32_t)k || (p.flags & FLG_BEST)) mincov_below_max = (uint32_t)(k + 2 * (s - 1));
+  }
+  int nhits_alloc, nhits_max;
+  {
+    double t = (double)qlen * log((double)qlen) * HITLST_LOGQLEN_FACT;   // hashhit.c:1266
+    long long target = (long long)t;
+    if (target > 0x7fffffffLL) target = 0x7fffffffLL; else if (target < HITLST_MINSIZ) target = HITLST_MINSIZ;
+    long long alloc = HITLST_BLKSZ;
+    if (target > alloc) alloc = ((target + HITLST_BLKSZ - 1) / HITLST_BLKSZ) * HITLST_BLKSZ;
+    nhits_alloc = (int)alloc; nhits_max = (int)target;
+  }
+  const uint32_t ncut = (uint32_t)(p.ncut > 0 ? p.ncut : 0);
+  int err = 0;
+  uint32_t ncand = 0, max_cover = 0, max2nd = 0, nhits_total = 0;
+  if (x.dbg_first) { SMG_PAR_CHUNKS(base, 2 * ngrp) { uint32_t g = base + SMG_LANE; if (g < 2 * ngrp) { x.dbg_first[g] = 0; x.dbg_cnt[g] = 0; } } }
+
+  for (uint32_t st = 0; st < 2 && !err; st++) {
+    const uint32_t rs = 2 * r + st;
+    const HitInfoHdr hdr = b.hi[rs];
+    const SeedRec *seeds = b.seeds + (size_t)rs * b.qmax;
+    uint8_t *qmask = b.qmask + (size_t)rs * b.qmax;
+    const uint32_t n_use = hdr.seed_rank > 0 ? hdr.seed_rank : hdr.n_seeds;
+    uint32_t tot = 0;
+    SMG_PAR_CHUNKS(base, n_use) {
+      uint32_t n = base + SMG_LANE;
+      if (n < n_use && !(ncut > 0 && seeds[n].nhits > ncut)) tot += seeds[n].nhits;
+    }
+    tot = wave_sum_u32(tot);
+    FillDecision *dec = x.dec + st * ngrp;
+    bool all_in = false;                     // every usable seed contributes everywhere (the common case)
+    if (seqbyseq) {
+      if (tot <= (uint32_t)nhits_alloc) {
+        all_in = true;
+        SMG_PAR_CHUNKS(base, n_use) {        // hashhit.c:1472-1481: over-cut seeds are flagged (-x mode only)
+          uint32_t n = base + SMG_LANE;
+          if (n < n_use && ncut > 0 && seeds[n].nhits > ncut) qmask[seeds[n].qoffs] = HQ_MULTIHIT;
+        }
+      } else {
+        SMG_PAR_CHUNKS(base, ngrp) {         // rare: allocation-boundary retry protocol per sequence
+          uint32_t g = base + SMG_LANE;
+          if (g < ngrp) {
+            uint64_t lo = ix.sop[g] / (uint64_t)s, hi = ix.sop[g + 1] / (uint64_t)s;
+            if (hi > 0xFFFFFFFFull) hi = 0xFFFFFFFFull;
+            dec[g] = fill_decide(ix, seeds, n_use, (uint32_t)lo, (uint32_t)hi, ncut, nhits_alloc, qmask);
+          }
+        }
+      }
+    } else {
+      SMG_LANE0 {                            // hashCollectHitsUsingCutoff (hashhit.c:1593-1689)
+        uint32_t m = ncut;
+        for (;;) {
+          uint32_t total = 0, i;
+          bool ceiling = false;
+          for (i = 0; i < n_use; i++) {
+            uint32_t nh = seeds[i].nhits;
+            if (nh < 1) continue;
+            if (m > 0 && nh > m) continue;
+            if ((int)(total + nh) > nhits_max) { ceiling = true; break; }
+            total += nh;
+          }
+          uint32_t mf = m;
+          m /= 2;
+          if (!(ceiling && m > (uint32_t)MINHIT_PER_TUPLE)) { dec[0].n_used = i; dec[0].m_final = mf; break; }
+        }
+      }
+    }
+    SMG_SYNC();
+    // choose the working set: LDS for small strands
+    const uint32_t bound = (seqbyseq && !all_in) || !seqbyseq ? tot : tot;     // upper bound of gathered hits
+    const bool in_lds = x.lds && bound <= CANDS_LDS_HITS && strand_work_bytes<uint16_t>(CANDS_LDS_HITS) <= x.lds_bytes;
+    if (!in_lds && bound > x.hcap_strand) { err = SMG_ERR_CAP; break; }
+    StrandWork<uint16_t> wl = strand_work_carve<uint16_t>(x.lds, CANDS_LDS_HITS);
+    StrandWork<uint32_t> wg = strand_work_carve<uint32_t>(x.hbm, x.hcap_strand);
+    uint64_t *dat = in_lds ? wl.dat : wg.dat;
+    // gather (hashhit.c:1416-1546): lanes stride over the position list of one seed at a time
+    uint32_t nkeys = 0;
+    for (uint32_t n = 0; n < n_use; n++) {
+      const SeedRec sd = seeds[n];
+      if (ncut > 0 && sd.nhits > ncut && seqbyseq) continue;
+      const uint32_t *posp;
+      const uint32_t nh = index_positions(ix, sd.posidx, &posp);
+      if (!seqbyseq) {
+        if (n >= dec[0].n_used || (dec[0].m_final > 0 && sd.nhits > dec[0].m_final) || sd.nhits < 1) continue;
+        SMG_PAR_CHUNKS(base, nh) {
+          uint32_t i = base + SMG_LANE;
+          if (i < nh) dat[nkeys + i] = (hit_diag(st != 0, posp[i], sd.qoffs, s) << KEY_QBITS) | sd.qoffs;
+        }
+        nkeys += nh;
+      } else if (all_in) {
+        SMG_PAR_CHUNKS(base, nh) {
+          uint32_t i = base + SMG_LANE;
+          if (i < nh) {
+            const uint32_t pos = posp[i];
+            const uint32_t g = seq_of_pos(ix.seqlo, ix.nseq, pos);
+            dat[nkeys + i] = ((uint64_t)g << (KEY_DIAGBITS + KEY_QBITS)) | (hit_diag(st != 0, pos, sd.qoffs, s) << KEY_QBITS) | sd.qoffs;
+          }
+        }
+        nkeys += nh;
+      } else {
+        uint32_t cnt = 0;
+        SMG_PAR_CHUNKS(base, nh) {
+          uint32_t i = base + SMG_LANE;
+          bool take = false;
+          uint64_t key = 0;
+          if (i < nh) {
+            const uint32_t pos = posp[i];
+            const uint32_t g = seq_of_pos(ix.seqlo, ix.nseq, pos);
+            const FillDecision d = dec[g];
+            take = n < d.n_used && !(d.m_final > 0 && sd.nhits > d.m_final);
+            key = ((uint64_t)g << (KEY_DIAGBITS + KEY_QBITS)) | (hit_diag(st != 0, pos, sd.qoffs, s) << KEY_QBITS) | sd.qoffs;
+          }
+          const uint32_t slot = compact_slot(take, cnt);
+          if (take) dat[nkeys + slot] = key;
+        }
+        nkeys += cnt;
+      }
+    }
+    SMG_SYNC();
+    SMG_LANE0 { ch.nhits[st] = nkeys; }
+    nhits_total += nkeys;
+    int rv;
+    if (in_lds) rv = strand_cands(wl, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd);
+    else rv = strand_cands(wg, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd);
+    if (rv) { err = rv; break; }
+    if (x.dbg_words) {       // debug: the hit lists in the layout of the reference's per-sequence hit lists
+      uint64_t *dw = x.dbg_words + (size_t)st * x.hcap_strand;
+      SMG_PAR_CHUNKS(base, nkeys) {
+        uint32_t i = base + SMG_LANE;
+        if (i < nkeys) {
+          const uint64_t key = dat[i];
+          const uint32_t gi = st * ngrp + (seqbyseq ? (key_grp(key) & ((1u << KEY_SEQBITS) - 1)) : 0u);
+          if (i == 0 || key_grp(dat[i - 1]) != key_grp(key)) x.dbg_first[gi] = i + st * x.hcap_strand;
+          if (i + 1 == nkeys || key_grp(dat[i + 1]) != key_grp(key)) x.dbg_cnt[gi] = i + 1;
+          dw[i] = key_packed(key);
+        }
+      }
+      SMG_SYNC();
+      SMG_PAR_CHUNKS(base, ngrp) { uint32_t g = base + SMG_LANE; if (g < ngrp && x.dbg_cnt[st * ngrp + g]) x.dbg_cnt[st * ngrp + g] -= x.dbg_first[st * ngrp + g] - st * x.hcap_strand; }
+    }
+    SMG_SYNC();
+  }
+
+  // ---- S6: cover deficits (hashhit.c:1096), threshold, ranking (segment.c:1616-1785) ----
+  uint32_t cdf[2] = {0, 0};
+  SMG_LANE0 {
+    for (uint32_t st = 0; st < 2; st++) {
+      const uint32_t rs = 2 * r + st;
+      const HitInfoHdr hdr = b.hi[rs];
+      const SeedRec *seeds = b.seeds + (size_t)rs * b.qmax;
+      if (hdr.status & HI_RANK) {
+        for (uint32_t i = 0; i < hdr.n_seeds; i++) x.qbr[i] = seeds[i].qoffs;
+        build_frames(hdr.n_seeds, x.qbr, s, x.frame_cnt, x.frame_rank, x.stride);
+      }
+      cdf[st] = cover_deficit(hdr.status, hdr.seed_rank, qlen, b.qmask + (size_t)rs * b.qmax, x.qbr, k, s, x.frame_cnt, x.frame_rank, x.stride, x.qbuf);
+    }
+    ch.cover_deficit[0] = cdf[0]; ch.cover_deficit[1] = cdf[1];
+  }
+  SMG_SYNC();
+  cdf[0] = ch.cover_deficit[0];
+  uint32_t target_depth = (uint32_t)p.target_depth, max_depth = (uint32_t)p.max_depth;
+  if (max_depth < 1 || max_depth > (uint32_t)MAXIMUM_DEPTH) max_depth = MAXIMUM_DEPTH;
+  if (target_depth < 1) target_depth = DEFAULT_TARGET_DEPTH;
+  if (target_depth > max_depth) target_depth = max_depth;
+  uint32_t min_cov_thr = (mincov_below_max > max_cover) ? 0 : max_cover - mincov_below_max, cdfx = 0;
+  if (min_cov_thr > max2nd) { cdfx = min_cov_thr - max2nd; min_cov_thr = max2nd; }
+  const uint32_t adj = (cdf[0] > cdfx) ? cdf[0] - cdfx : 0;       // deficit of strand [0] for both strands (:1676)
+  uint32_t nmin = 0;
+  if (!err) {
+    SMG_PAR_CHUNKS(base, ncand) {           // filter (:1700-1730) keeps candidate order
+      const uint32_t i = base + SMG_LANE;
+      bool keep = false;
+      uint32_t cov = 0;
+      if (i < ncand) { cov = x.cand[i].cover; keep = !(cov + adj < min_cov_thr); }
+      const uint32_t slot = compact_slot(keep, nmin);
+      if (keep) { x.sort_keys[slot] = max_cover - cov; x.sort_idx[slot] = i; }
+    }
+  }
+  SMG_SYNC();
+  SMG_LANE0 {
+    uint32_t j = nmin;
+    if (!err) {
+      sort2_u32((int)j, x.sort_keys, x.sort_idx);      // sort.c:233 tie order
+      if (j > target_depth) {
+        const uint32_t maxj = (j < max_depth) ? j : max_depth;
+        if (p.flags & FLG_SENSITIVE) {
+          for (j = target_depth; j < maxj; j++) if (x.sort_keys[j] >= adj) break;     // :1760-1764
+          for (; j < nmin && x.sort_keys[j] < (uint32_t)s; j++) {}
+        } else {
+          uint32_t cov = x.sort_keys[j / 2];
+          if (cov < (uint32_t)s) cov = (uint32_t)s;
+          for (j = target_depth; j < maxj && x.sort_keys[j] < cov; j++) {}
+        }
+      }
+    } else j = 0;
+    ch.ncand = ncand; ch.n_sort = j; ch.n_mincover = nmin; ch.max_cover = max_cover; ch.max2nd_cover = max2nd;
+    ch.err = err;
+    ch.rc_off = atomic_add_u32(b.rc_count, ch.n_sort);
+    if (ch.rc_off + ch.n_sort > b.rccap) { ch.err = SMG_ERR_CAP; ch.n_sort = 0; }
+  }
+  SMG_SYNC();
+  // ---- S7 ----
+  const uint32_t n_sort = ch.n_sort, rc_off = ch.rc_off;
+  SMG_PAR_CHUNKS(base, n_sort) {
+    uint32_t i = base + SMG_LANE;
+    if (i < n_sort) {
+      RCand c;
+      if (cand_offsets(c, x.cand[x.sort_idx[i]], ix, qlen)) { c.flags |= RCF_ERR; c.rs = c.re = 0; c.qs = c.qe = 0; c.band_l = c.band_r = 0; }
+      c.rid = r; c.pad = 0;
+      b.rcpool[rc_off + i] = c;
+    }
+  }
+  return nhits_total;
+}
+
+}  // namespace smg

@@ -1,7 +1,7 @@
 // smg_kernels.h -- host-callable launchers of the gfx950 kernels (smg_kernels.hip).
 #pragma once
 #include <hip/hip_runtime_api.h>
-#include "smg_stages.hpp"
+#include "smg_cands.hpp"
 
 namespace smg {
 
@@ -9,8 +9,19 @@ enum : int { SW_FULL_WMAX = 1016 };   // longest reference window of the registe
 
 int launch_encode(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint32_t n, uint8_t *codes, uint8_t *codes_rc);
 int launch_seed(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint8_t *scratch, size_t sbytes, uint32_t nslots);
-int launch_cands(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint8_t *scratch, size_t sbytes, uint32_t nslots,
-                 uint32_t hcap, uint32_t ngrp, uint32_t segcap, uint32_t candcap, int slot_per_read);
+struct CandGeom {              // scratch geometry of the candidate stage (both code paths share one HBM slot)
+  uint32_t hcap;               // hits of both strands, power of two (sequential path)
+  uint32_t hcap_strand;        // hits of one strand (wave-parallel path)
+  uint32_t ngrp, segcap, candcap;
+  size_t slot_bytes;
+  int debug;                   // keep per-read slots + the grouped hit words for smaltgpu_dump_read
+};
+inline size_t cand_slot_bytes(const CandGeom &g, uint32_t qmax, int s) {
+  size_t a = cand_scratch_bytes(qmax, s, g.hcap, g.ngrp, g.segcap, g.candcap);
+  size_t b = cands_v2_hbm_bytes(qmax, s, g.hcap_strand, g.ngrp, g.candcap, true);
+  return a > b ? a : b;
+}
+int launch_cands(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint8_t *scratch, uint32_t nslots, const CandGeom &g);
 int launch_replay(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p);
 int launch_align(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint8_t *scratch, size_t sbytes, uint32_t nslots,
                  uint32_t wincap, uint64_t dircap, uint32_t rescap, uint32_t dstrcap);

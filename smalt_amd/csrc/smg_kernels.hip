@@ -42,14 +42,20 @@ __global__ void __launch_bounds__(64) k_seed(Batch b, DevIndex ix, MapPar p, uin
   if (threadIdx.x == 0 && nlook) atomicAdd(b.work + WK_LOOKUPS, nlook);
 }
 
-// S3 - S7: one wave per read, scratch slot in HBM
-__global__ void __launch_bounds__(64) k_cands(Batch b, DevIndex ix, MapPar p, uint8_t *gscratch, size_t gbytes, uint32_t hcap,
-                                              uint32_t ngrp, uint32_t segcap, uint32_t candcap, int slot_per_read) {
+// S3 - S7: one wave per read.  Reads the wave-parallel form covers (smg_cands.hpp) keep their
+// per-strand working set in LDS; everything else takes the sequential restatement on the HBM slot.
+__global__ void __launch_bounds__(64) k_cands(Batch b, DevIndex ix, MapPar p, uint8_t *gscratch, CandGeom g, uint32_t lds_bytes) {
+  extern __shared__ __align__(16) uint8_t lds[];
   unsigned long long nhit = 0;
   for (uint32_t r = blockIdx.x; r < b.nreads; r += gridDim.x) {
-    uint8_t *base = gscratch + gbytes * (slot_per_read ? r : blockIdx.x);
-    CandScratch x = cand_scratch_carve(base, b.qmax, ix.s, hcap, ngrp, segcap, candcap);
-    nhit += stage_cands(b, ix, p, r, x);
+    uint8_t *base = gscratch + g.slot_bytes * (g.debug ? r : blockIdx.x);
+    if (cands_v2_applicable(p, ix.k, ix.s, read_len(b, r))) {
+      CandsV2Scratch x = cands_v2_carve(lds, lds_bytes, base, b.qmax, ix.s, g.hcap_strand, g.ngrp, g.candcap, g.debug != 0);
+      nhit += stage_cands_v2(b, ix, p, r, x);
+    } else {
+      CandScratch x = cand_scratch_carve(base, b.qmax, ix.s, g.hcap, g.ngrp, g.segcap, g.candcap);
+      nhit += stage_cands(b, ix, p, r, x);
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0 && nhit) atomicAdd(b.work + WK_HITS, nhit);
@@ -61,11 +67,12 @@ __global__ void __launch_bounds__(256) k_replay(Batch b, DevIndex ix, MapPar p) 
   if (r < b.nreads) stage_replay(b, ix, p, r);
 }
 
-// K3: one wave per read, scratch slot in HBM
+// K3: one wave per read; hot arrays in LDS, results and oversized direction matrices in the HBM slot
 __global__ void __launch_bounds__(64) k_align(Batch b, DevIndex ix, MapPar p, uint8_t *gscratch, size_t gbytes, uint32_t wincap,
-                                              uint64_t dircap, uint32_t rescap, uint32_t dstrcap) {
+                                              uint64_t dircap, uint32_t rescap, uint32_t dstrcap, uint32_t lds_bytes) {
+  extern __shared__ __align__(16) uint8_t lds[];
   uint8_t *base = gscratch + gbytes * blockIdx.x;
-  AlignScratch x = align_scratch_carve(base, b.qmax, wincap, dircap, rescap, dstrcap);
+  AlignScratch x = align_scratch_carve_lds(lds_bytes ? lds : nullptr, lds_bytes, base, b.qmax, wincap, dircap, rescap, dstrcap);
   for (uint32_t r = blockIdx.x; r < b.nreads; r += gridDim.x) {
     stage_align(b, ix, p, r, x);
     __syncthreads();
@@ -314,11 +321,11 @@ int launch_seed(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar 
   return 0;
 }
 
-int launch_cands(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint8_t *scratch, size_t sbytes, uint32_t nslots,
-                 uint32_t hcap, uint32_t ngrp, uint32_t segcap, uint32_t candcap, int slot_per_read) {
+int launch_cands(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint8_t *scratch, uint32_t nslots, const CandGeom &g) {
   if (!b.nreads) return 0;
   uint32_t grid = b.nreads < nslots ? b.nreads : nslots;
-  hipLaunchKernelGGL(k_cands, dim3(grid), dim3(64), 0, s, b, ix, p, scratch, sbytes, hcap, ngrp, segcap, candcap, slot_per_read);
+  const uint32_t lds_bytes = (uint32_t)strand_work_bytes<uint16_t>(CANDS_LDS_HITS);
+  hipLaunchKernelGGL(k_cands, dim3(grid), dim3(64), lds_bytes, s, b, ix, p, scratch, g, lds_bytes);
   SMG_LAUNCH_CHECK();
   return 0;
 }
@@ -334,7 +341,9 @@ int launch_align(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar
                  uint32_t wincap, uint64_t dircap, uint32_t rescap, uint32_t dstrcap) {
   if (!b.nreads) return 0;
   uint32_t grid = b.nreads < nslots ? b.nreads : nslots;
-  hipLaunchKernelGGL(k_align, dim3(grid), dim3(64), 0, s, b, ix, p, scratch, sbytes, wincap, dircap, rescap, dstrcap);
+  size_t small = align_lds_small_bytes(b.qmax, wincap);
+  uint32_t lds_bytes = small + 4096 <= 40 * 1024 ? 40 * 1024 : 0;      // rows + window + 30-odd KB of direction bytes
+  hipLaunchKernelGGL(k_align, dim3(grid), dim3(64), lds_bytes, s, b, ix, p, scratch, sbytes, wincap, dircap, rescap, dstrcap, lds_bytes);
   SMG_LAUNCH_CHECK();
   return 0;
 }

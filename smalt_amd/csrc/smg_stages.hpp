@@ -564,7 +564,8 @@ SMG_HD inline void stage_replay(const Batch &b, const DevIndex &ix, const MapPar
 struct AlignScratch {
   int *Hp, *Ep;               // [qmax + 2]
   uint8_t *win; uint32_t wincap;
-  uint8_t *dir; uint64_t dircap;
+  uint8_t *dir; uint64_t dircap;        // direction matrix in the HBM slot
+  uint8_t *dir_lds; uint32_t dir_lds_cap;   // ... and its LDS home for bands that fit (0 on the host build)
   uint8_t *dtmp; uint32_t dtmpcap;      // reversed DiffStr of the current traceback
   Result *res; uint32_t rescap;
   uint8_t *dstr; uint32_t dstrcap;
@@ -589,6 +590,30 @@ SMG_HD inline AlignScratch align_scratch_carve(uint8_t *base, uint32_t qmax, uin
   x.dtmp = base; base += x.dtmpcap;
   x.dstr = base; base += dstrcap; x.dstrcap = dstrcap;
   x.dir = base; x.dircap = dircap;
+  x.dir_lds = nullptr; x.dir_lds_cap = 0;
+  return x;
+}
+
+// Same, with the small hot arrays (DP rows, window, reversed DiffStr, interval stack, state) and the
+// direction matrix of ordinary-sized bands in the workgroup's LDS block.
+SMG_HD inline size_t align_lds_small_bytes(uint32_t qmax, uint32_t wincap) {
+  return (((size_t)qmax + 2) * 8 + 128 * 4 + 64 + wincap + ((size_t)qmax + wincap + 16) + 63) & ~(size_t)63;
+}
+SMG_HD inline AlignScratch align_scratch_carve_lds(uint8_t *lds, size_t lds_bytes, uint8_t *base, uint32_t qmax, uint32_t wincap,
+                                                   uint64_t dircap, uint32_t rescap, uint32_t dstrcap) {
+  AlignScratch x = align_scratch_carve(base, qmax, wincap, dircap, rescap, dstrcap);
+  const size_t small = align_lds_small_bytes(qmax, wincap);
+  if (lds && small + 1024 <= lds_bytes) {
+    uint8_t *l = lds;
+    x.Hp = (int *)l; l += ((size_t)qmax + 2) * 4;
+    x.Ep = (int *)l; l += ((size_t)qmax + 2) * 4;
+    x.ivstack = (int *)l; l += 128 * 4;
+    x.state = (int32_t *)l; l += 64;
+    x.win = l; l += wincap;
+    x.dtmp = l;
+    x.dir_lds = lds + small;
+    x.dir_lds_cap = (uint32_t)(lds_bytes - small);
+  }
   return x;
 }
 
@@ -711,12 +736,14 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
         if (minscorlen < 2) { err = SMG_ERR_ASSERT; break; }
         if (band_init(band, band_l, band_r, (int)c.qs, (int)c.qe, (int)qlen, s_left, s_right, (int)wlen)) continue;
         if (band.s_left >= band.s_len || band.band_width < 0) { err = SMG_ERR_ASSERT; break; }
-        if ((uint64_t)band.band_width * (uint64_t)(band.s_len - band.s_left) + (uint64_t)band.band_width + 8 > x.dircap) { err = SMG_ERR_CAP; break; }
+        const uint64_t dneed = (uint64_t)band.band_width * (uint64_t)(band.s_len - band.s_left) + (uint64_t)band.band_width + 8;
+        if (dneed > x.dircap) { err = SMG_ERR_CAP; break; }
+        uint8_t *dirm = (dneed <= x.dir_lds_cap) ? x.dir_lds : x.dir;
         int max_i, max_j;
-        const int max_scor = band_track_scalar(band, q, x.win, M, gi, ge, x.Hp, x.Ep, x.dir, &max_i, &max_j);
+        const int max_scor = band_track_scalar(band, q, x.win, M, gi, ge, x.Hp, x.Ep, dirm, &max_i, &max_j);
         if (max_scor < minscore) continue;
         int qs, rs;
-        const int dn = traceback_scalar(x.dtmp, x.dtmpcap, &qs, &rs, band, x.dir, max_i, max_j, max_scor, q, x.win, M, gi, ge);
+        const int dn = traceback_scalar(x.dtmp, x.dtmpcap, &qs, &rs, band, dirm, max_i, max_j, max_scor, q, x.win, M, gi, ge);
         if (dn < 0) { err = (dn == -2) ? SMG_ERR_CAP : SMG_ERR_ASSERT; break; }
         const int qe = max_j, re = max_i;
         if (qs + minscorlen > qe + 1) continue;

@@ -10,6 +10,7 @@
 #include <unistd.h>
 #include <string>
 #include <vector>
+#include "../../smalt_amd/csrc/smg_cands.hpp"
 #include "../../smalt_amd/csrc/smg_dump.hpp"
 #include "../../smalt_amd/csrc/smg_indexfile.hpp"
 
@@ -100,8 +101,11 @@ int main(int argc, char **argv) {
   b.res_count = &res_count; b.dstrpool = dstrpool.data(); b.dstrcap = dstrpool.size(); b.dstr_count = &dstr_count; b.err_flag = &err_flag;
 
   std::vector<uint8_t> sscr(seed_scratch_bytes(qmax, ix.s));
-  const uint32_t hcap = 1u << 16, segcap = 1u << 15, candcap = 1u << 14;
-  const size_t cbytes = cand_scratch_bytes(qmax, ix.s, hcap, ngrp, segcap, candcap);
+  const uint32_t hcap = 1u << 16, segcap = 1u << 15, candcap = 1u << 16;
+  const uint32_t hcap_strand = hcap / 2;
+  const char *force = getenv("EMU_CANDS");       // "v1": sequential restatement only; default: as the kernel chooses
+  size_t cbytes = cand_scratch_bytes(qmax, ix.s, hcap, ngrp, segcap, candcap);
+  { size_t b2 = cands_v2_hbm_bytes(qmax, ix.s, hcap_strand, ngrp, candcap, true); if (b2 > cbytes) cbytes = b2; }
   uint8_t *cscr_mem = (uint8_t *)malloc(cbytes * (size_t)n);      // one slot per read: state kept for the dump
   struct { uint8_t *p; uint8_t *data() { return p; } } cscr = {cscr_mem};
   const uint32_t wincap = 4 * qmax + 4096; const uint64_t dircap = (uint64_t)wincap * (qmax + 64);
@@ -117,8 +121,13 @@ int main(int argc, char **argv) {
     SeedScratch sx = seed_scratch_carve(sscr.data(), qmax, ix.s);
     stage_seed(b, ix, p, r, 0, sx);
     stage_seed(b, ix, p, r, 1, sx);
-    CandScratch cx = cand_scratch_carve(cscr.data() + cbytes * r, qmax, ix.s, hcap, ngrp, segcap, candcap);
-    stage_cands(b, ix, p, r, cx);
+    if (cands_v2_applicable(p, ix.k, ix.s, len) && !(force && !strcmp(force, "v1"))) {
+      CandsV2Scratch c2 = cands_v2_carve(nullptr, 0, cscr.data() + cbytes * r, qmax, ix.s, hcap_strand, ngrp, candcap, true);
+      stage_cands_v2(b, ix, p, r, c2);
+    } else {
+      CandScratch cx = cand_scratch_carve(cscr.data() + cbytes * r, qmax, ix.s, hcap, ngrp, segcap, candcap);
+      stage_cands(b, ix, p, r, cx);
+    }
     // score pass: K2a (un-banded) or K2b (banded) by the predicate set in cand_offsets
     for (uint32_t i = 0; i < ch[r].n_sort; i++) {
       RCand &rc = rcpool[ch[r].rc_off + i];
@@ -145,9 +154,12 @@ int main(int argc, char **argv) {
     DumpView v;
     v.qlen = (uint32_t)(off[r + 1] - off[r]); v.qmax = qmax; v.k = ix.k;
     for (int st = 0; st < 2; st++) { v.hi[st] = hi[2 * r + st]; v.seeds[st] = seeds.data() + (size_t)(2 * r + st) * qmax; v.qmask[st] = qmask.data() + (size_t)(2 * r + st) * qmax; }
-    v.ch = ch[r]; v.cand = cx.cand; v.sort_idx = cx.sort_idx; v.sort_keys = cx.sort_keys; v.rc = rcpool.data() + ch[r].rc_off;
-    v.ctl = ctl[r]; v.st = stat[r]; v.res = respool.data() + stat[r].res_off; v.dstr = dstrpool.data() + stat[r].dstr_off;
-    v.hitwords = cx.keys; v.grp_first = cx.grp_first; v.grp_cnt = cx.grp_cnt; v.ngrp = ngrp;
+    v.ch = ch[r]; v.rc = rcpool.data() + ch[r].rc_off;
+    v.ctl = ctl[r]; v.st = stat[r]; v.res = respool.data() + stat[r].res_off; v.dstr = dstrpool.data() + stat[r].dstr_off; v.ngrp = ngrp;
+    if (cands_v2_applicable(p, ix.k, ix.s, v.qlen) && !(force && !strcmp(force, "v1"))) {
+      CandsV2Scratch c2 = cands_v2_carve(nullptr, 0, cscr.data() + cbytes * r, qmax, ix.s, hcap_strand, ngrp, candcap, true);
+      v.cand = c2.cand; v.sort_idx = c2.sort_idx; v.sort_keys = c2.sort_keys; v.hitwords = c2.dbg_words; v.grp_first = c2.dbg_first; v.grp_cnt = c2.dbg_cnt;
+    } else { v.cand = cx.cand; v.sort_idx = cx.sort_idx; v.sort_keys = cx.sort_keys; v.hitwords = cx.keys; v.grp_first = cx.grp_first; v.grp_cnt = cx.grp_cnt; }
     out.clear();
     dump_read(out, v, r, names[r].c_str(), with_hl != 0);
     fwrite(out.data(), 1, out.size(), stdout);
