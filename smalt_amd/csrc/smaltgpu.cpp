@@ -233,15 +233,17 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
     uint64_t alloc = HITLST_BLKSZ;
     if (t > (double)alloc) alloc = (((uint64_t)t + HITLST_BLKSZ - 1) / HITLST_BLKSZ) * HITLST_BLKSZ;
     memset(&m->cg, 0, sizeof(m->cg));
-    m->cg.hcap = next_pow2(2 * alloc);
-    m->cg.hcap_strand = next_pow2(alloc);
+    // A strand gathers at most `alloc` hits per reference sequence (hashhit.c:1497); reads that take
+    // the allocation-boundary protocol can therefore exceed `alloc` over all sequences: 4x headroom.
+    m->cg.hcap_strand = next_pow2(4 * alloc);
+    m->cg.hcap = 2 * m->cg.hcap_strand;
     m->cg.ngrp = d.nseq < 512 ? (uint32_t)d.nseq : 1u;  // both modes fit: concatenated mode uses group 0
     m->cg.segcap = m->cg.hcap / 2;
     m->cg.candcap = m->cg.hcap;                         // every hit can be a candidate of its own (mincover = k)
     m->cg.slot_bytes = m->cand_bytes = cand_slot_bytes(m->cg, m->qmax, d.s);
-    uint64_t budget = 12ull << 30;
+    uint64_t budget = 24ull << 30;
     uint64_t slots = budget / m->cand_bytes;
-    if (slots > 4096) slots = 4096;
+    if (slots > 1024) slots = 1024;                     // LDS admits 3 workgroups per CU: 768 run at a time
     if (slots < 64) slots = 64;
     if (slots > max_batch_reads) slots = max_batch_reads;
     m->cand_slots = (uint32_t)slots;
@@ -256,7 +258,7 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
     m->align_bytes = align_scratch_bytes(m->qmax, m->wincap, m->dircap, m->rescap_slot, m->dstrcap_slot);
     uint64_t budget = 4ull << 30;
     uint64_t slots = budget / m->align_bytes;
-    if (slots > 4096) slots = 4096;
+    if (slots > 2048) slots = 2048;
     if (slots < 16) slots = 16;
     if (slots > max_batch_reads) slots = max_batch_reads;
     m->align_slots = (uint32_t)slots;

@@ -408,9 +408,11 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     }
     SMG_SYNC();
     // choose the working set: LDS for small strands
-    const uint32_t bound = (seqbyseq && !all_in) || !seqbyseq ? tot : tot;     // upper bound of gathered hits
-    const bool in_lds = x.lds && bound <= CANDS_LDS_HITS && strand_work_bytes<uint16_t>(CANDS_LDS_HITS) <= x.lds_bytes;
-    if (!in_lds && bound > x.hcap_strand) { err = SMG_ERR_CAP; break; }
+    // `tot` bounds the gathered hits unless the allocation-boundary protocol is active (then every
+    // sequence may contribute up to nhits_alloc): that case is range-checked while gathering
+    const bool in_lds = x.lds && (all_in || !seqbyseq) && tot <= CANDS_LDS_HITS && strand_work_bytes<uint16_t>(CANDS_LDS_HITS) <= x.lds_bytes;
+    const uint32_t gcap = in_lds ? CANDS_LDS_HITS : x.hcap_strand;
+    if ((all_in || !seqbyseq) && tot > gcap) { err = SMG_ERR_CAP; break; }
     StrandWork<uint16_t> wl = strand_work_carve<uint16_t>(x.lds, CANDS_LDS_HITS);
     StrandWork<uint32_t> wg = strand_work_carve<uint32_t>(x.hbm, x.hcap_strand);
     uint64_t *dat = in_lds ? wl.dat : wg.dat;
@@ -452,12 +454,14 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
             key = ((uint64_t)g << (KEY_DIAGBITS + KEY_QBITS)) | (hit_diag(st != 0, pos, sd.qoffs, s) << KEY_QBITS) | sd.qoffs;
           }
           const uint32_t slot = compact_slot(take, cnt);
-          if (take) dat[nkeys + slot] = key;
+          if (take && nkeys + slot < gcap) dat[nkeys + slot] = key;
         }
         nkeys += cnt;
+        if (nkeys > gcap) { err = SMG_ERR_CAP; break; }
       }
     }
     SMG_SYNC();
+    if (err) break;
     SMG_LANE0 { ch.nhits[st] = nkeys; }
     nhits_total += nkeys;
     int rv;
