@@ -178,7 +178,7 @@ def main():
     offs = torch.arange(sub + 1, dtype=torch.int64, device=dev) * args.read_len
     torch.cuda.synchronize()
 
-    ms_acc, work_acc = {}, [0] * 8
+    ms_acc, work_acc = {}, [0] * 24
 
     def one_step(collect):
         mapped = total_res = 0
@@ -193,7 +193,7 @@ def main():
                 ms, wk = mapper.timers()
                 for kk, v in ms.items():
                     ms_acc[kk] = ms_acc.get(kk, 0.0) + v
-                for i in range(8):
+                for i in range(24):
                     work_acc[i] += wk[i]
         return mapped, total_res
 
@@ -254,6 +254,9 @@ def main():
             "roofline_sw": roof_sw, "roofline_seed": roof_seed,
             "kernel_ms_per_step": {kk: v / args.steps for kk, v in ms_acc.items()},
             "dominant_kernel": dom,
+            "cands_phase_share": [round(x / max(1, sum(work_acc[8:24])), 4) for x in work_acc[8:24]],
+            "cands_per_read": work_acc[5] / max(1, world * args.steps * args.reads), "kept_per_read": work_acc[6] / max(1, world * args.steps * args.reads),
+            "hits_per_read": work_acc[1] / max(1, world * args.steps * args.reads),
         }
         if not args.no_cpu_baseline:
             try:

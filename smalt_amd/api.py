@@ -64,6 +64,10 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIBPATH):
             raise SmaltGpuError(-1, "libsmaltgpu.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        try:                       # torch bundles its own HIP runtime: load it first so that one runtime serves both
+            import torch  # noqa: F401
+        except Exception:          # torch is plumbing for bench/tests, not a dependency of the library
+            pass
         L = C.CDLL(LIBPATH)
         L.smaltgpu_last_error.restype = C.c_char_p
         L.smaltgpu_timer_name.restype = C.c_char_p
@@ -194,9 +198,9 @@ class Mapper:
         return out
 
     def timers(self):
-        ms = (C.c_double * 8)()
-        wk = (C.c_uint64 * 8)()
-        n = lib().smaltgpu_timers(self.h, ms, wk, 8)
+        ms = (C.c_double * 24)()
+        wk = (C.c_uint64 * 24)()
+        n = lib().smaltgpu_timers(self.h, ms, wk, 24)
         names = [lib().smaltgpu_timer_name(i).decode() for i in range(n)]
         return dict(zip(names, list(ms)[:n])), list(wk)
 

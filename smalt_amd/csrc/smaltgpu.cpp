@@ -215,7 +215,7 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
   DA(b.respool, b.rescap);
   b.dstrcap = b.rescap * (uint64_t)(m->qmax / 4 + 48);
   DA(b.dstrpool, b.dstrcap);
-  DA(m->d_counters, 256);
+  DA(m->d_counters, 512);
   if (!rv) {
     b.rc_count = (uint32_t *)(m->d_counters + 0);
     b.res_count = (unsigned long long *)(m->d_counters + 8);
@@ -314,7 +314,7 @@ static int run_pipeline(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_
   m->last_par = p; m->last_n = n;
   b.nreads = n; b.codes = m->d_codes; b.codes_rc = m->d_codes_rc; b.qual = d_quals; b.read_off = d_off;
   hipStream_t s = m->stream;
-  HIPCHK(hipMemsetAsync(m->d_counters, 0, 256, s));
+  HIPCHK(hipMemsetAsync(m->d_counters, 0, 512, s));
   int rv = 0;
   const bool seqbyseq = (p.flags & FLG_SEQBYSEQ) != 0;
   const uint32_t ngrp = seqbyseq ? (uint32_t)d.nseq : 1u;
@@ -371,8 +371,8 @@ extern "C" int smaltgpu_fetch_results(smaltgpu_mapper *m, smaltgpu_batch_out *ou
   if (!m || !out) return fail(SMALTGPU_EARG, "null argument");
   HIPCHK(hipSetDevice(m->device));
   const uint32_t n = m->last_n;
-  uint8_t ctr[256];
-  HIPCHK(hipMemcpyAsync(ctr, m->d_counters, 256, hipMemcpyDeviceToHost, m->stream));
+  uint8_t ctr[512];
+  HIPCHK(hipMemcpyAsync(ctr, m->d_counters, 512, hipMemcpyDeviceToHost, m->stream));
   m->h_stat.resize(n ? n : 1);
   if (n) HIPCHK(hipMemcpyAsync(m->h_stat.data(), m->b.stat, (size_t)n * sizeof(ReadStat), hipMemcpyDeviceToHost, m->stream));
   HIPCHK(hipStreamSynchronize(m->stream));

@@ -147,10 +147,13 @@ SMG_HD inline int derive_cand_c(SegCand &c, const StrandWork<IT> &w, uint32_t m0
 template <class IT>
 SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, bool seqbyseq, uint32_t qlen, int k, int s,
                                uint32_t mincover, SegCand *cand_tmp, SegCand *cand, uint32_t candcap, uint32_t *ncand_io,
-                               uint32_t *max_cover_io, uint32_t *max2nd_io) {
+                               uint32_t *max_cover_io, uint32_t *max2nd_io, unsigned long long *ph) {
   if (!n) return 0;
+  unsigned long long t0 = phase_clock(), t1;
+#define SMG_PH(i) { t1 = phase_clock(); ph[i] += t1 - t0; t0 = t1; }
   wave_sort_u64(w.dat, n);
   SMG_SYNC();
+  SMG_PH(2)
   uint32_t max_dshift = (uint32_t)(k * SEGMENTING_DIFFSHIFT / s) & 0xffffu;     // segment.c:426-429
   { uint32_t ds = (qlen - (uint32_t)k) / (uint32_t)s + 1; if (ds < max_dshift) max_dshift = ds & 0xffffu; }
   const uint64_t dsthresh = ((uint64_t)max_dshift) << HALFBIT;
@@ -213,6 +216,7 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
     if (rb) w.reg_first[slot] = (IT)m;
   }
   SMG_SYNC();
+  SMG_PH(3)
   // S5: one lane per hit region (addCandsFast, segment.c:1169-1217)
   uint32_t mx = *max_cover_io, mx2 = *max2nd_io;
   int err = 0;
@@ -261,6 +265,7 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
   *max_cover_io = mx; *max2nd_io = mx2;
   if (wave_any(err != 0)) return SMG_ERR_ASSERT;
   SMG_SYNC();
+  SMG_PH(4)
   // ordered compaction of the sparse candidates
   uint32_t nc = *ncand_io;
   bool ovf = false;
@@ -271,6 +276,8 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
     if (f) { if (slot < candcap) cand[slot] = cand_tmp[m]; else ovf = true; }
   }
   *ncand_io = nc;
+  SMG_PH(5)
+#undef SMG_PH
   if (wave_any(ovf)) return SMG_ERR_CAP;
   return 0;
 }
@@ -324,7 +331,9 @@ SMG_HD inline bool cands_v2_applicable(const MapPar &p, int k, int s, uint32_t q
   return qlen <= 256 && p.min_cover < (uint32_t)(k + s);     // calcMinKtup (rmap.c:240-247) gives min_ktup == 1
 }
 
-SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t r, CandsV2Scratch &x) {
+SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t r, CandsV2Scratch &x, unsigned long long *ph) {
+  unsigned long long t0 = phase_clock(), t1;
+#define SMG_PH(i) { t1 = phase_clock(); ph[i] += t1 - t0; t0 = t1; }
   const uint32_t qlen = read_len(b, r);
   CandHdr &ch = b.ch[r];
   const int k = ix.k, s = ix.s;
@@ -407,6 +416,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
       }
     }
     SMG_SYNC();
+    SMG_PH(0)
     // choose the working set: LDS for small strands
     // `tot` bounds the gathered hits unless the allocation-boundary protocol is active (then every
     // sequence may contribute up to nhits_alloc): that case is range-checked while gathering
@@ -461,12 +471,14 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
       }
     }
     SMG_SYNC();
+    SMG_PH(1)
     if (err) break;
     SMG_LANE0 { ch.nhits[st] = nkeys; }
     nhits_total += nkeys;
     int rv;
-    if (in_lds) rv = strand_cands(wl, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd);
-    else rv = strand_cands(wg, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd);
+    if (in_lds) rv = strand_cands(wl, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph);
+    else rv = strand_cands(wg, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph);
+    t0 = phase_clock();
     if (rv) { err = rv; break; }
     if (x.dbg_words) {       // debug: the hit lists in the layout of the reference's per-sequence hit lists
       uint64_t *dw = x.dbg_words + (size_t)st * x.hcap_strand;
@@ -522,6 +534,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     }
   }
   SMG_SYNC();
+  SMG_PH(6)
   SMG_LANE0 {
     uint32_t j = nmin;
     if (!err) {
@@ -544,6 +557,8 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     if (ch.rc_off + ch.n_sort > b.rccap) { ch.err = SMG_ERR_CAP; ch.n_sort = 0; }
   }
   SMG_SYNC();
+  SMG_PH(7)
+  ph[9] += ncand; ph[10] += nmin;
   // ---- S7 ----
   const uint32_t n_sort = ch.n_sort, rc_off = ch.rc_off;
   SMG_PAR_CHUNKS(base, n_sort) {
@@ -555,6 +570,8 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
       b.rcpool[rc_off + i] = c;
     }
   }
+  SMG_PH(8)
+#undef SMG_PH
   return nhits_total;
 }
 

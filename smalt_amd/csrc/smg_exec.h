@@ -30,6 +30,15 @@
 
 namespace smg {
 
+// phase clock for the diagnostic counters (shader clock on the device, nothing on the host)
+SMG_HD inline unsigned long long phase_clock() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (unsigned long long)__builtin_readcyclecounter();
+#else
+  return 0;
+#endif
+}
+
 // Ordered stream compaction: lanes with flag get consecutive slots in lane order.
 // `counter` is wave-uniform.
 SMG_HD inline uint32_t compact_slot(bool flag, uint32_t &counter) {

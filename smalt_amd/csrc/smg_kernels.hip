@@ -47,18 +47,23 @@ __global__ void __launch_bounds__(64) k_seed(Batch b, DevIndex ix, MapPar p, uin
 __global__ void __launch_bounds__(64) k_cands(Batch b, DevIndex ix, MapPar p, uint8_t *gscratch, CandGeom g, uint32_t lds_bytes) {
   extern __shared__ __align__(16) uint8_t lds[];
   unsigned long long nhit = 0;
+  unsigned long long ph[12] = {0};
   for (uint32_t r = blockIdx.x; r < b.nreads; r += gridDim.x) {
     uint8_t *base = gscratch + g.slot_bytes * (g.debug ? r : blockIdx.x);
     if (cands_v2_applicable(p, ix.k, ix.s, read_len(b, r))) {
       CandsV2Scratch x = cands_v2_carve(lds, lds_bytes, base, b.qmax, ix.s, g.hcap_strand, g.ngrp, g.candcap, g.debug != 0);
-      nhit += stage_cands_v2(b, ix, p, r, x);
+      nhit += stage_cands_v2(b, ix, p, r, x, ph);
     } else {
       CandScratch x = cand_scratch_carve(base, b.qmax, ix.s, g.hcap, g.ngrp, g.segcap, g.candcap);
       nhit += stage_cands(b, ix, p, r, x);
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0 && nhit) atomicAdd(b.work + WK_HITS, nhit);
+  if (threadIdx.x == 0) {
+    if (nhit) atomicAdd(b.work + WK_HITS, nhit);
+    for (int i = 0; i < 9; i++) if (ph[i]) atomicAdd(b.work + WK_PHASE0 + i, ph[i]);
+    if (ph[9]) { atomicAdd(b.work + WK_NCAND, ph[9]); atomicAdd(b.work + WK_NKEPT, ph[10]); }
+  }
 }
 
 // O1: one thread per read

@@ -34,9 +34,10 @@ struct Batch {                          // one block of reads resident in HBM
   Result *respool; uint64_t rescap; unsigned long long *res_count;
   uint8_t *dstrpool; uint64_t dstrcap; unsigned long long *dstr_count;
   int32_t *err_flag;                    // batch-wide first error
-  unsigned long long *work;             // [8] work counters (WK_*), one atomic per workgroup
+  unsigned long long *work;             // [WK_NWORK] work counters (WK_*), one atomic per workgroup
 };
-enum : int { WK_LOOKUPS = 0, WK_HITS = 1, WK_CELLS_FULL = 2, WK_TASKS_FULL = 3, WK_CELLS_BAND = 4, WK_NWORK = 8 };
+enum : int { WK_LOOKUPS = 0, WK_HITS = 1, WK_CELLS_FULL = 2, WK_TASKS_FULL = 3, WK_CELLS_BAND = 4, WK_NCAND = 5, WK_NKEPT = 6,
+              WK_PHASE0 = 8 /* .. 23: shader-clock ticks per phase of k_cands (diagnostic) */, WK_NWORK = 24 };
 
 SMG_HD inline uint32_t read_len(const Batch &b, uint32_t r) { return (uint32_t)(b.read_off[r + 1] - b.read_off[r]); }
 

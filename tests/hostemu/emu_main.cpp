@@ -123,7 +123,8 @@ int main(int argc, char **argv) {
     stage_seed(b, ix, p, r, 1, sx);
     if (cands_v2_applicable(p, ix.k, ix.s, len) && !(force && !strcmp(force, "v1"))) {
       CandsV2Scratch c2 = cands_v2_carve(nullptr, 0, cscr.data() + cbytes * r, qmax, ix.s, hcap_strand, ngrp, candcap, true);
-      stage_cands_v2(b, ix, p, r, c2);
+      unsigned long long ph[12] = {0};
+      stage_cands_v2(b, ix, p, r, c2, ph);
     } else {
       CandScratch cx = cand_scratch_carve(cscr.data() + cbytes * r, qmax, ix.s, hcap, ngrp, segcap, candcap);
       stage_cands(b, ix, p, r, cx);
