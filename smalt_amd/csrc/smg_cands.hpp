@@ -499,6 +499,26 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   }
 
   // ---- S6: cover deficits (hashhit.c:1096), threshold, ranking (segment.c:1616-1785) ----
+  // The strand working set is dead now: its LDS block hosts the small scratch arrays and, when the
+  // kept candidates fit, the two arrays of the sequential tie-order-preserving sort.
+  uint32_t *qbr = x.qbr, *frame_cnt = x.frame_cnt, *frame_rank = x.frame_rank;
+  uint8_t *qbuf = x.qbuf;
+  uint32_t *skeys = x.sort_keys, *sidx = x.sort_idx;
+  uint32_t lds_sort_cap = 0;
+  if (x.lds) {
+    const size_t small = ((size_t)b.qmax * 5 + (size_t)s * 4 + (size_t)s * x.stride * 4 + 63) & ~(size_t)63;
+    if (small + 4096 <= x.lds_bytes) {
+      uint8_t *l = x.lds;
+      qbr = (uint32_t *)l; l += (size_t)b.qmax * 4;
+      frame_cnt = (uint32_t *)l; l += (size_t)s * 4;
+      frame_rank = (uint32_t *)l; l += (size_t)s * x.stride * 4;
+      qbuf = l;
+      lds_sort_cap = (uint32_t)((x.lds_bytes - small) / 8);
+      skeys = (uint32_t *)(x.lds + small);
+      sidx = skeys + lds_sort_cap;
+    }
+  }
+  SMG_SYNC();
   uint32_t cdf[2] = {0, 0};
   SMG_LANE0 {
     for (uint32_t st = 0; st < 2; st++) {
@@ -506,10 +526,10 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
       const HitInfoHdr hdr = b.hi[rs];
       const SeedRec *seeds = b.seeds + (size_t)rs * b.qmax;
       if (hdr.status & HI_RANK) {
-        for (uint32_t i = 0; i < hdr.n_seeds; i++) x.qbr[i] = seeds[i].qoffs;
-        build_frames(hdr.n_seeds, x.qbr, s, x.frame_cnt, x.frame_rank, x.stride);
+        for (uint32_t i = 0; i < hdr.n_seeds; i++) qbr[i] = seeds[i].qoffs;
+        build_frames(hdr.n_seeds, qbr, s, frame_cnt, frame_rank, x.stride);
       }
-      cdf[st] = cover_deficit(hdr.status, hdr.seed_rank, qlen, b.qmask + (size_t)rs * b.qmax, x.qbr, k, s, x.frame_cnt, x.frame_rank, x.stride, x.qbuf);
+      cdf[st] = cover_deficit(hdr.status, hdr.seed_rank, qlen, b.qmask + (size_t)rs * b.qmax, qbr, k, s, frame_cnt, frame_rank, x.stride, qbuf);
     }
     ch.cover_deficit[0] = cdf[0]; ch.cover_deficit[1] = cdf[1];
   }
@@ -524,13 +544,20 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   const uint32_t adj = (cdf[0] > cdfx) ? cdf[0] - cdfx : 0;       // deficit of strand [0] for both strands (:1676)
   uint32_t nmin = 0;
   if (!err) {
-    SMG_PAR_CHUNKS(base, ncand) {           // filter (:1700-1730) keeps candidate order
+    SMG_PAR_CHUNKS(base, ncand) {           // count the candidates that pass (:1700-1730)
+      const uint32_t i = base + SMG_LANE;
+      const bool keep = i < ncand && !(x.cand[i].cover + adj < min_cov_thr);
+      (void)compact_slot(keep, nmin);
+    }
+    if (nmin > lds_sort_cap) { skeys = x.sort_keys; sidx = x.sort_idx; }
+    uint32_t w2 = 0;
+    SMG_PAR_CHUNKS(base, ncand) {           // ... and list them in candidate order
       const uint32_t i = base + SMG_LANE;
       bool keep = false;
       uint32_t cov = 0;
       if (i < ncand) { cov = x.cand[i].cover; keep = !(cov + adj < min_cov_thr); }
-      const uint32_t slot = compact_slot(keep, nmin);
-      if (keep) { x.sort_keys[slot] = max_cover - cov; x.sort_idx[slot] = i; }
+      const uint32_t slot = compact_slot(keep, w2);
+      if (keep) { skeys[slot] = max_cover - cov; sidx[slot] = i; }
     }
   }
   SMG_SYNC();
@@ -538,16 +565,16 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   SMG_LANE0 {
     uint32_t j = nmin;
     if (!err) {
-      sort2_u32((int)j, x.sort_keys, x.sort_idx);      // sort.c:233 tie order
+      sort2_u32((int)j, skeys, sidx);      // sort.c:233 tie order
       if (j > target_depth) {
         const uint32_t maxj = (j < max_depth) ? j : max_depth;
         if (p.flags & FLG_SENSITIVE) {
-          for (j = target_depth; j < maxj; j++) if (x.sort_keys[j] >= adj) break;     // :1760-1764
-          for (; j < nmin && x.sort_keys[j] < (uint32_t)s; j++) {}
+          for (j = target_depth; j < maxj; j++) if (skeys[j] >= adj) break;     // :1760-1764
+          for (; j < nmin && skeys[j] < (uint32_t)s; j++) {}
         } else {
-          uint32_t cov = x.sort_keys[j / 2];
+          uint32_t cov = skeys[j / 2];
           if (cov < (uint32_t)s) cov = (uint32_t)s;
-          for (j = target_depth; j < maxj && x.sort_keys[j] < cov; j++) {}
+          for (j = target_depth; j < maxj && skeys[j] < cov; j++) {}
         }
       }
     } else j = 0;
@@ -555,6 +582,11 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     ch.err = err;
     ch.rc_off = atomic_add_u32(b.rc_count, ch.n_sort);
     if (ch.rc_off + ch.n_sort > b.rccap) { ch.err = SMG_ERR_CAP; ch.n_sort = 0; }
+  }
+  SMG_SYNC();
+  if (skeys != x.sort_keys) {               // ranked part back to the slot (S7 below, diagnostics)
+    const uint32_t ns = ch.n_sort;
+    SMG_PAR_CHUNKS(base, ns) { const uint32_t i = base + SMG_LANE; if (i < ns) { x.sort_keys[i] = skeys[i]; x.sort_idx[i] = sidx[i]; } }
   }
   SMG_SYNC();
   SMG_PH(7)

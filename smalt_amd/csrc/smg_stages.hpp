@@ -571,11 +571,12 @@ struct AlignScratch {
   Result *res; uint32_t rescap;
   uint8_t *dstr; uint32_t dstrcap;
   int *ivstack;               // [2 * 64] pending reference intervals
-  int32_t *state;             // [8] lane-0 state visible to the wave
+  int32_t *state;             // [16] lane-0 state visible to the wave
+  uint8_t *qcodes; uint32_t qstride;   // [2][qstride] the read in both orientations
 };
 
 SMG_HD inline size_t align_scratch_bytes(uint32_t qmax, uint32_t wincap, uint64_t dircap, uint32_t rescap, uint32_t dstrcap) {
-  size_t n = ((size_t)qmax + 2) * 8 + wincap + dircap + ((size_t)qmax + wincap + 16) + (size_t)rescap * sizeof(Result) + dstrcap + 128 * 4 + 64 + 256;
+  size_t n = ((size_t)qmax + 2) * 8 + wincap + dircap + ((size_t)qmax + wincap + 16) + (size_t)rescap * sizeof(Result) + dstrcap + 128 * 4 + 64 + 256 + 2 * ((size_t)qmax + 8);
   return (n + 255) & ~(size_t)255;
 }
 
@@ -586,6 +587,8 @@ SMG_HD inline AlignScratch align_scratch_carve(uint8_t *base, uint32_t qmax, uin
   x.Ep = (int *)base; base += ((size_t)qmax + 2) * 4;
   x.ivstack = (int *)base; base += 128 * 4;
   x.state = (int32_t *)base; base += 64;
+  x.qstride = qmax + 8;
+  x.qcodes = base; base += 2 * (size_t)x.qstride;
   x.win = base; base += wincap; x.wincap = wincap;
   x.dtmpcap = qmax + wincap + 16;
   x.dtmp = base; base += x.dtmpcap;
@@ -598,7 +601,7 @@ SMG_HD inline AlignScratch align_scratch_carve(uint8_t *base, uint32_t qmax, uin
 // Same, with the small hot arrays (DP rows, window, reversed DiffStr, interval stack, state) and the
 // direction matrix of ordinary-sized bands in the workgroup's LDS block.
 SMG_HD inline size_t align_lds_small_bytes(uint32_t qmax, uint32_t wincap) {
-  return (((size_t)qmax + 2) * 8 + 128 * 4 + 64 + wincap + ((size_t)qmax + wincap + 16) + 63) & ~(size_t)63;
+  return (((size_t)qmax + 2) * 8 + 128 * 4 + 64 + 2 * ((size_t)qmax + 8) + wincap + ((size_t)qmax + wincap + 16) + 63) & ~(size_t)63;
 }
 SMG_HD inline AlignScratch align_scratch_carve_lds(uint8_t *lds, size_t lds_bytes, uint8_t *base, uint32_t qmax, uint32_t wincap,
                                                    uint64_t dircap, uint32_t rescap, uint32_t dstrcap) {
@@ -610,6 +613,7 @@ SMG_HD inline AlignScratch align_scratch_carve_lds(uint8_t *lds, size_t lds_byte
     x.Ep = (int *)l; l += ((size_t)qmax + 2) * 4;
     x.ivstack = (int *)l; l += 128 * 4;
     x.state = (int32_t *)l; l += 64;
+    x.qcodes = l; l += 2 * (size_t)x.qstride;
     x.win = l; l += wincap;
     x.dtmp = l;
     x.dir_lds = lds + small;
@@ -681,20 +685,82 @@ SMG_HD inline int traceback_scalar(uint8_t *ds, uint32_t dscap, int *qs, int *rs
   return (checksum != max_scor) ? -1 : (int)n;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline int wave_ror1(int v) {      // value of lane-1 (lane 0 takes lane 63)
+  return __builtin_amdgcn_update_dpp(v, v, 0x13C /* wave_ror:1 */, 0xf, 0xf, false);
+}
+
+// alignSmiWatBand (alignment.c:788-1027) by the whole wave for bands up to 64 columns wide.
+// Lane c owns the columns jmin + c + 64m; cell (i', j) is computed at step t = i' + (j - jmin), so
+// a column advances one row per step and its left neighbour column (lane c-1) is always one step
+// ahead on the same row: the diagonal H and the running F arrive by a wave rotate, the column's own
+// H/E stay in registers.  A column that enters the band starts from H = E = 0 (:871-872), exactly
+// as the reference's row buffers do.  Ties of the maximum resolve to the first cell in row-major
+// order (:826-830) by reducing (score, row, column).
+__device__ inline int band_track_wave(const Band &bp, const uint8_t *q, const uint8_t *win, int match, int mismatch, int gi, int ge,
+                                      uint8_t *dir, int *max_i, int *max_j) {
+  const int lane = (int)threadIdx.x;
+  const int nrows = bp.s_len - bp.s_left, l = bp.l_edge, r = bp.r_edge, bw = bp.band_width;
+  const int jmin = bp.q_left > l ? bp.q_left : l;
+  int jlast = r + nrows - 1; if (jlast > bp.q_len - 1) jlast = bp.q_len - 1;
+  const int tmax = (nrows - 1) + (jlast - jmin);
+  int Hcol = 0, Ecol = 0, Hprev = 0, Fout = 0, lastrow = -2, lastcol = -1, qc = 5;
+  int best = 0, bi = 0, bj = 0;
+  for (int t = 0; t <= tmax; t++) {
+    const int nH = wave_ror1(Hcol), nHp = wave_ror1(Hprev), nF = wave_ror1(Fout), nrow = wave_ror1(lastrow), ncol = wave_ror1(lastcol);
+    const int x0 = t + l - jmin - 2 * lane;
+    const int m = x0 <= 0 ? 0 : (x0 + 127) >> 7;
+    const int j = jmin + lane + 64 * m;
+    const int ip = t - (j - jmin);
+    const bool act = ip >= 0 && ip < nrows && j <= jlast && (j - ip) <= r && (j - ip) >= l;
+    if (act) {
+      if (j != lastcol) { Hcol = 0; Ecol = 0; Hprev = 0; qc = q[j] & 7; }
+      int diag = 0, F = 0;
+      if (ncol == j - 1) {
+        if (nrow == ip) { diag = nHp; F = nF; }
+        else if (nrow == ip - 1) diag = nH;
+      }
+      const int rb = win[bp.s_left + ip] & 7;
+      const int w = (rb >= 4 || qc >= 4) ? 0 : (rb == qc ? match : mismatch);      // score.c:138-173 (codes 0-3, 5 = N)
+      const int Hin = diag + w;
+      int Hnew;
+      bool cand;
+      const int hb = Hcol;
+      const int d = cell_update(Hnew, Ecol, F, Hin, gi, ge, cand);
+      Hprev = hb; Hcol = Hnew; Fout = F; lastrow = ip; lastcol = j;
+      dir[(size_t)ip * (size_t)(bw - 1) + (size_t)(j - l)] = (uint8_t)d;
+      if (cand && Hin > best) { best = Hin; bi = ip; bj = j; }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const int ob = __shfl_xor(best, o), oi = __shfl_xor(bi, o), oj = __shfl_xor(bj, o);
+    if (ob > best || (ob == best && (oi < bi || (oi == bi && oj < bj)))) { best = ob; bi = oi; bj = oj; }
+  }
+  *max_i = best > 0 ? bp.s_left + bi : 0;
+  *max_j = best > 0 ? bj : 0;
+  return best;
+}
+#endif
+
 SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t r, AlignScratch &x) {
   const uint32_t qlen = read_len(b, r);
   const CandHdr ch = b.ch[r];
   const ReadCtl ctl = b.ctl[r];
   ReadStat &st = b.stat[r];
   const RCand *rc = b.rcpool + ch.rc_off;
-  enum { S_MINSW = 0, S_SWMAX = 1, S_SW2ND = 2, S_NRES = 3, S_NDSTR = 4, S_ERR = 5 };
+  enum { S_MINSW = 0, S_SWMAX = 1, S_SW2ND = 2, S_NRES = 3, S_NDSTR = 4, S_ERR = 5, S_SP = 6, S_NALI = 7 };
   int8_t M[64];
   score_matrix(M, p.match, p.mismatch);
   const int gi = -p.gap_init, ge = -p.gap_ext;
 
   SMG_LANE0 {
     x.state[S_MINSW] = ctl.min_swatscor; x.state[S_SWMAX] = 0; x.state[S_SW2ND] = 0;
-    x.state[S_NRES] = 0; x.state[S_NDSTR] = 0; x.state[S_ERR] = ch.err;
+    x.state[S_NRES] = 0; x.state[S_NDSTR] = 0; x.state[S_ERR] = ch.err; x.state[S_SP] = 0; x.state[S_NALI] = 0;
+  }
+  // both orientations of the read next to the DP rows (codes are read once per column)
+  SMG_PAR_CHUNKS(base, qlen) {
+    uint32_t i = base + SMG_LANE;
+    if (i < qlen) { x.qcodes[i] = b.codes[b.read_off[r] + i]; x.qcodes[x.qstride + i] = b.codes_rc[b.read_off[r] + i]; }
   }
   SMG_SYNC();
   const uint32_t ncand = (ctl.go && qlen >= (uint32_t)ix.k) ? (uint32_t)ctl.n_scored : 0u;
@@ -703,74 +769,110 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
     if (x.state[S_ERR]) break;
     if (c.swscor < x.state[S_MINSW]) continue;            // rmap.c:826-828 (all ranked candidates are scored)
     const uint32_t wlen = (uint32_t)(c.re - c.rs + 1);
-    if (wlen > x.wincap || c.qs > c.qe || c.qe >= qlen || (c.flags & RCF_ERR)) { SMG_LANE0 { x.state[S_ERR] = (wlen > x.wincap) ? SMG_ERR_CAP : SMG_ERR_ASSERT; } SMG_SYNC(); break; }
+    if (wlen > x.wincap || c.qs > c.qe || c.qe >= qlen || (c.flags & RCF_ERR)) { SMG_SYNC(); SMG_LANE0 { x.state[S_ERR] = (wlen > x.wincap) ? SMG_ERR_CAP : SMG_ERR_ASSERT; } SMG_SYNC(); break; }
     const uint64_t gbase = (c.sqidx < 0 ? 0ull : ix.sop[c.sqidx]) + c.rs;
     SMG_PAR_CHUNKS(base, wlen) {                           // fetch + decode the reference window (rmap.c:831-845)
       uint32_t i = base + SMG_LANE;
       if (i < wlen) x.win[i] = (uint8_t)ref_code(ix.packed, gbase + i);
     }
+    // scalars of this candidate: every lane computes the same values from shared state
+    const uint8_t *q = x.qcodes + ((c.flags & RCF_REVERSE) ? x.qstride : 0);
+    int min_swatscor = x.state[S_MINSW];
+    if ((p.flags & FLG_BEST) && x.state[S_SW2ND] > min_swatscor) min_swatscor = x.state[S_SW2ND];   // rmap.c:881-885
+    int bwc = c.band_r - c.band_l, band_l, band_r;
+    if (bwc < ctl.bandwidth_min) { bwc = (ctl.bandwidth_min - bwc + 1) / 2; band_l = c.band_l - bwc; band_r = c.band_r + bwc; }
+    else { band_l = c.band_l; band_r = c.band_r; }
+    // aliSmiWatInBand (alignment.c:1548-1601)
+    const int minscore = min_swatscor;
+    int minscorlen = ctl.scorlen_min, err0 = 0;
+    if (minscore < 1 || p.match <= 0) err0 = SMG_ERR_ASSERT;
+    if (minscorlen * p.match < minscore) minscorlen = minscore / p.match;
+    if (minscorlen < ALILEN_MIN) err0 = SMG_ERR_ASSERT;
+    const int res_first = x.state[S_NRES];
     SMG_SYNC();
     SMG_LANE0 {
-      const uint8_t *q = ((c.flags & RCF_REVERSE) ? b.codes_rc : b.codes) + b.read_off[r];
-      int min_swatscor = x.state[S_MINSW];
-      if ((p.flags & FLG_BEST) && x.state[S_SW2ND] > min_swatscor) min_swatscor = x.state[S_SW2ND];   // rmap.c:881-885
       x.state[S_MINSW] = min_swatscor;
-      int bw = c.band_r - c.band_l, band_l, band_r;
-      if (bw < ctl.bandwidth_min) { bw = (ctl.bandwidth_min - bw + 1) / 2; band_l = c.band_l - bw; band_r = c.band_r + bw; }
-      else { band_l = c.band_l; band_r = c.band_r; }
-      // aliSmiWatInBand (alignment.c:1548-1601)
-      int minscore = min_swatscor, minscorlen = ctl.scorlen_min, err = 0;
-      if (minscore < 1 || p.match <= 0) err = SMG_ERR_ASSERT;
-      if (minscorlen * p.match < minscore) minscorlen = minscore / p.match;
-      if (minscorlen < ALILEN_MIN) err = SMG_ERR_ASSERT;
-      // results of this candidate are collected first (AliRsltSet), then merged (resultSetAddFromAli)
-      const int res_first = x.state[S_NRES];
-      int nali = 0;                      // number of alignments of this candidate
-      // temporary alignment records are written behind the accepted results
-      int sp = 0;
-      if (!err) { x.ivstack[0] = 0; x.ivstack[1] = (int)wlen - 1; sp = 1; }
-      // accepted-so-far results occupy res[0 .. res_first); candidates' alignments go to res[res_first + nali]
-      while (sp > 0 && !err) {
-        sp--;
-        const int s_left = x.ivstack[2 * sp], s_right = x.ivstack[2 * sp + 1];
-        Band band;
-        if (minscorlen < 2) { err = SMG_ERR_ASSERT; break; }
-        if (band_init(band, band_l, band_r, (int)c.qs, (int)c.qe, (int)qlen, s_left, s_right, (int)wlen)) continue;
-        if (band.s_left >= band.s_len || band.band_width < 0) { err = SMG_ERR_ASSERT; break; }
-        const uint64_t dneed = (uint64_t)band.band_width * (uint64_t)(band.s_len - band.s_left) + (uint64_t)band.band_width + 8;
-        if (dneed > x.dircap) { err = SMG_ERR_CAP; break; }
-        uint8_t *dirm = (dneed <= x.dir_lds_cap) ? x.dir_lds : x.dir;
-        int max_i, max_j;
-        const int max_scor = band_track_scalar(band, q, x.win, M, gi, ge, x.Hp, x.Ep, dirm, &max_i, &max_j);
-        if (max_scor < minscore) continue;
-        int qs, rs;
-        const int dn = traceback_scalar(x.dtmp, x.dtmpcap, &qs, &rs, band, dirm, max_i, max_j, max_scor, q, x.win, M, gi, ge);
-        if (dn < 0) { err = (dn == -2) ? SMG_ERR_CAP : SMG_ERR_ASSERT; break; }
-        const int qe = max_j, re = max_i;
-        if (qs + minscorlen > qe + 1) continue;
-        {
-          // addALIMETAtoRsltSet (alignment.c:1277): forward DiffStr appended to the scratch string pool
-          if ((uint32_t)(res_first + nali) >= x.rescap || (uint32_t)(x.state[S_NDSTR] + dn + 2) > x.dstrcap) { err = SMG_ERR_CAP; break; }
-          Result &a = x.res[res_first + nali];
-          a.swatscor = max_scor; a.q_start = (uint32_t)qs; a.q_end = (uint32_t)qe; a.s_start = (uint64_t)rs; a.s_end = (uint64_t)re;
-          a.stroffs = (uint32_t)x.state[S_NDSTR];
-          const int fl = diffstr_reverse(x.dstr + a.stroffs, x.dtmp, dn);
-          if (fl < 0) { err = SMG_ERR_ASSERT; break; }
-          a.strlen = (uint32_t)fl;
-          x.state[S_NDSTR] += fl;
-          nali++;
-        }
-        // right interval is pushed first so that the left one is aligned first (alignment.c:1389-1431)
-        if (s_right > re + minscorlen) { if (sp >= 62) { err = SMG_ERR_CAP; break; } x.ivstack[2 * sp] = re + 1; x.ivstack[2 * sp + 1] = s_right; sp++; }
-        if (s_left + minscorlen < rs) { if (sp >= 62) { err = SMG_ERR_CAP; break; } x.ivstack[2 * sp] = s_left; x.ivstack[2 * sp + 1] = rs - 1; sp++; }
+      x.state[S_NALI] = 0;
+      if (err0) { x.state[S_ERR] = err0; x.state[S_SP] = 0; }
+      else { x.ivstack[0] = 0; x.ivstack[1] = (int)wlen - 1; x.state[S_SP] = 1; }
+    }
+    SMG_SYNC();
+    // alignSmiWatBandRecursive (alignment.c:1300-1434) with an explicit interval stack: node, then the
+    // reference range left of its alignment, then the range to the right
+    for (;;) {
+      const int sp = x.state[S_SP];
+      if (sp <= 0 || x.state[S_ERR]) break;
+      const int s_left = x.ivstack[2 * (sp - 1)], s_right = x.ivstack[2 * (sp - 1) + 1];
+      Band band;
+      int nerr = 0;
+      bool skip = false;
+      if (minscorlen < 2) nerr = SMG_ERR_ASSERT;
+      else if (band_init(band, band_l, band_r, (int)c.qs, (int)c.qe, (int)qlen, s_left, s_right, (int)wlen)) skip = true;
+      else if (band.s_left >= band.s_len || band.band_width < 0) nerr = SMG_ERR_ASSERT;
+      uint64_t dneed = 0;
+      uint8_t *dirm = x.dir;
+      if (!nerr && !skip) {
+        dneed = (uint64_t)band.band_width * (uint64_t)(band.s_len - band.s_left) + (uint64_t)band.band_width + 8;
+        if (dneed > x.dircap) nerr = SMG_ERR_CAP;
+        else if (dneed <= x.dir_lds_cap) dirm = x.dir_lds;
       }
-      if (!err && nali > 0) {
+      int max_i = 0, max_j = 0, max_scor = 0;
+      if (!nerr && !skip) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (band.band_width >= 1 && band.band_width <= 64) {
+          max_scor = band_track_wave(band, q, x.win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j);
+        } else {
+          SMG_LANE0 { x.state[8] = band_track_scalar(band, q, x.win, M, gi, ge, x.Hp, x.Ep, dirm, &max_i, &max_j); x.state[9] = max_i; x.state[10] = max_j; }
+          SMG_SYNC();
+          max_scor = x.state[8]; max_i = x.state[9]; max_j = x.state[10];
+        }
+#else
+        max_scor = band_track_scalar(band, q, x.win, M, gi, ge, x.Hp, x.Ep, dirm, &max_i, &max_j);
+#endif
+      }
+      SMG_SYNC();
+      SMG_LANE0 {
+        int nsp = sp - 1, err = nerr;
+        if (!err && !skip && max_scor >= minscore) {
+          int qs, rs;
+          const int dn = traceback_scalar(x.dtmp, x.dtmpcap, &qs, &rs, band, dirm, max_i, max_j, max_scor, q, x.win, M, gi, ge);
+          if (dn < 0) err = (dn == -2) ? SMG_ERR_CAP : SMG_ERR_ASSERT;
+          const int qe = max_j, re = max_i;
+          if (!err && !(qs + minscorlen > qe + 1)) {
+            // addALIMETAtoRsltSet (alignment.c:1277): forward DiffStr appended to the scratch string pool
+            const int nali = x.state[S_NALI];
+            if ((uint32_t)(res_first + nali) >= x.rescap || (uint32_t)(x.state[S_NDSTR] + dn + 2) > x.dstrcap) err = SMG_ERR_CAP;
+            else {
+              Result &a = x.res[res_first + nali];
+              a.swatscor = max_scor; a.q_start = (uint32_t)qs; a.q_end = (uint32_t)qe; a.s_start = (uint64_t)rs; a.s_end = (uint64_t)re;
+              a.stroffs = (uint32_t)x.state[S_NDSTR];
+              const int fl = diffstr_reverse(x.dstr + a.stroffs, x.dtmp, dn);
+              if (fl < 0) err = SMG_ERR_ASSERT;
+              else {
+                a.strlen = (uint32_t)fl;
+                x.state[S_NDSTR] += fl;
+                x.state[S_NALI] = nali + 1;
+                // right interval is pushed first so that the left one is aligned first (alignment.c:1389-1431)
+                if (s_right > re + minscorlen) { if (nsp >= 62) err = SMG_ERR_CAP; else { x.ivstack[2 * nsp] = re + 1; x.ivstack[2 * nsp + 1] = s_right; nsp++; } }
+                if (!err && s_left + minscorlen < rs) { if (nsp >= 62) err = SMG_ERR_CAP; else { x.ivstack[2 * nsp] = s_left; x.ivstack[2 * nsp + 1] = rs - 1; nsp++; } }
+              }
+            }
+          }
+        }
+        if (err) x.state[S_ERR] = err;
+        x.state[S_SP] = nsp;
+      }
+      SMG_SYNC();
+    }
+    SMG_LANE0 {
+      const int nali = x.state[S_NALI];
+      if (!x.state[S_ERR] && nali > 0) {
         // resultSetAddFromAli (results.c:1852-1942) incl. its duplicate handling: a result equal to
         // its predecessor is popped; what is written after a popped slot within one call is lost
         // from the array but still raises the score maxima.
         const bool is_rev = (c.flags & RCF_REVERSE) != 0;
         uint32_t arrlen = (uint32_t)res_first;
-        uint32_t dkeep = (nali > 0) ? x.res[res_first].stroffs : 0;   // compacted string pool write position
+        uint32_t dkeep = x.res[res_first].stroffs;       // compacted string pool write position
         Result *rp = &x.res[arrlen++];
         bool is_new = false;
         Result cur;
@@ -789,7 +891,6 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
           is_new = (arrlen < 2) || !(nr.s_start == pp->s_start && nr.s_end == pp->s_end && nr.q_start == pp->q_start &&
                                      nr.q_end == pp->q_end && nr.swatscor == pp->swatscor && nr.sidx == pp->sidx);
           if (is_new) {
-            // keep the string: move it down to the compacted position
             for (uint32_t t = 0; t < nr.strlen; t++) x.dstr[dkeep + t] = x.dstr[nr.stroffs + t];
             nr.stroffs = dkeep; dkeep += nr.strlen;
             if (nr.swatscor > x.state[S_SW2ND]) {        // UPDATE_SWATSCORMAX (results.c:1013)
@@ -805,7 +906,6 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
         x.state[S_NRES] = (int32_t)arrlen;
         x.state[S_NDSTR] = (int32_t)dkeep;
       }
-      if (err) x.state[S_ERR] = err;
     }
     SMG_SYNC();
   }
