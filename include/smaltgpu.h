@@ -139,6 +139,12 @@ long smaltgpu_dump_read(smaltgpu_mapper *m, uint32_t i, const char *name, char *
 int smaltgpu_sw_full_batch(smaltgpu_mapper *m, const uint8_t *qcodes, const uint32_t *q_off, const uint8_t *rcodes,
                            const uint32_t *r_off, uint32_t ntask, const smaltgpu_params *par, int32_t *scores);
 
+/* The candidate ranking sort of segAliCandsStats (segment.c:1733 -> sort.c:233): `narr` arrays of keys (< 1024), array t
+ * in keys[off[t]..off[t+1]); returns the keys and the permutation (index into the array) in the reference's tie order
+ * for ranks < nneed (all ranks if nneed < 0; ranks at or beyond nneed may be left unsorted).  in_lds: sort in LDS. */
+int smaltgpu_rank_sort_batch(smaltgpu_mapper *m, const uint32_t *keys, const uint32_t *off, uint32_t narr, int nneed, int in_lds,
+                             uint32_t *out_keys, uint32_t *out_idx);
+
 const char *smaltgpu_last_error(void);
 int smaltgpu_device_count(void);
 

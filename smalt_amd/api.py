@@ -90,6 +90,7 @@ def lib():
         L.smaltgpu_dump_read.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_size_t]
         L.smaltgpu_sw_full_batch.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32), C.c_char_p,
                                              C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(Params), C.POINTER(C.c_int32)]
+        L.smaltgpu_rank_sort_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -226,3 +227,15 @@ class Mapper:
         sc = (C.c_int32 * n)()
         _check(lib().smaltgpu_sw_full_batch(self.h, b"".join(queries), qo, b"".join(windows), ro, n, C.byref(params), sc))
         return list(sc)
+
+    def rank_sort_batch(self, arrays, nneed: int = -1, in_lds: bool = True):
+        """Stand-alone candidate ranking sort: list of uint32 numpy arrays -> list of (keys, permutation)."""
+        import numpy as np
+        off = np.zeros(len(arrays) + 1, dtype=np.uint32)
+        off[1:] = np.cumsum([len(a) for a in arrays])
+        keys = np.ascontiguousarray(np.concatenate(arrays) if arrays else np.zeros(0), dtype=np.uint32)
+        ok = np.zeros(max(1, keys.size), dtype=np.uint32)
+        oi = np.zeros(max(1, keys.size), dtype=np.uint32)
+        _check(lib().smaltgpu_rank_sort_batch(self.h, keys.ctypes.data, off.ctypes.data, len(arrays), nneed, int(in_lds),
+                                              ok.ctypes.data, oi.ctypes.data))
+        return [(ok[off[t]:off[t + 1]], oi[off[t]:off[t + 1]]) for t in range(len(arrays))]

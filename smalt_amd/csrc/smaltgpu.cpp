@@ -509,3 +509,24 @@ extern "C" int smaltgpu_sw_full_batch(smaltgpu_mapper *m, const uint8_t *qcodes,
   (void)hipFree(dq); (void)hipFree(dr); (void)hipFree(dqo); (void)hipFree(dro); (void)hipFree(dsc);
   return rv;
 }
+
+extern "C" int smaltgpu_rank_sort_batch(smaltgpu_mapper *m, const uint32_t *keys, const uint32_t *off, uint32_t narr, int nneed, int in_lds,
+                                         uint32_t *out_keys, uint32_t *out_idx) {
+  if (!m || !keys || !off || !out_keys || !out_idx) return fail(SMALTGPU_EARG, "null argument");
+  HIPCHK(hipSetDevice(m->device));
+  const size_t tot = off[narr];
+  for (uint32_t t = 0; t < narr; t++) if (off[t + 1] < off[t] || off[t + 1] - off[t] > (1u << 22)) return fail(SMALTGPU_EARG, "bad array offsets");
+  for (size_t i = 0; i < tot; i++) if (keys[i] >= 1024u) return fail(SMALTGPU_EARG, "key out of range");
+  uint32_t *dk = nullptr, *doff = nullptr, *dkv = nullptr, *dok = nullptr, *doi = nullptr;
+  int rv = 0;
+  if (dalloc(&dk, tot + 1) || dalloc(&doff, (size_t)narr + 1) || dalloc(&dkv, tot + 1) || dalloc(&dok, tot + 1) || dalloc(&doi, tot + 1)) rv = SMALTGPU_ENOMEM;
+  if (!rv) {
+    (void)hipMemcpy(dk, keys, tot * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(doff, off, ((size_t)narr + 1) * 4, hipMemcpyHostToDevice);
+    launch_rank_sort_raw(m->stream, dk, doff, narr, nneed, in_lds, dkv, dok, doi);
+    if (hipStreamSynchronize(m->stream) != hipSuccess) rv = fail(SMALTGPU_ENODEV, "kernel failed");
+    else { (void)hipMemcpy(out_keys, dok, tot * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(out_idx, doi, tot * 4, hipMemcpyDeviceToHost); }
+  }
+  (void)hipFree(dk); (void)hipFree(doff); (void)hipFree(dkv); (void)hipFree(dok); (void)hipFree(doi);
+  return rv;
+}

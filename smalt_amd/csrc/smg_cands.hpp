@@ -16,6 +16,7 @@
 // `file:line` citations refer to the reference tree (SMALT 0.7.6, src/).
 #pragma once
 #include "smg_stages.hpp"
+#include "smg_wsort.hpp"
 
 namespace smg {
 
@@ -503,21 +504,24 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   // kept candidates fit, the two arrays of the sequential tie-order-preserving sort.
   uint32_t *qbr = x.qbr, *frame_cnt = x.frame_cnt, *frame_rank = x.frame_rank;
   uint8_t *qbuf = x.qbuf;
-  uint32_t *skeys = x.sort_keys, *sidx = x.sort_idx;
+  uint32_t *kv = x.sort_keys;             // packed (key << 22) | candidate index
+  uint32_t *wk = x.sort_idx;              // work words of the wave sort + key histogram
   uint32_t lds_sort_cap = 0;
   if (x.lds) {
     const size_t small = ((size_t)b.qmax * 5 + (size_t)s * 4 + (size_t)s * x.stride * 4 + 63) & ~(size_t)63;
-    if (small + 4096 <= x.lds_bytes) {
+    const size_t wkb = ((size_t)WSORT_WORDS + WSORT_NBINS) * 4;
+    if (small + wkb + 4096 <= x.lds_bytes) {
       uint8_t *l = x.lds;
       qbr = (uint32_t *)l; l += (size_t)b.qmax * 4;
       frame_cnt = (uint32_t *)l; l += (size_t)s * 4;
       frame_rank = (uint32_t *)l; l += (size_t)s * x.stride * 4;
       qbuf = l;
-      lds_sort_cap = (uint32_t)((x.lds_bytes - small) / 8);
-      skeys = (uint32_t *)(x.lds + small);
-      sidx = skeys + lds_sort_cap;
+      wk = (uint32_t *)(x.lds + small);
+      lds_sort_cap = (uint32_t)((x.lds_bytes - small - wkb) / 4);
+      kv = wk + WSORT_WORDS + WSORT_NBINS;
     }
   }
+  uint32_t *hist = wk + WSORT_WORDS;
   SMG_SYNC();
   uint32_t cdf[2] = {0, 0};
   SMG_LANE0 {
@@ -543,13 +547,16 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   if (min_cov_thr > max2nd) { cdfx = min_cov_thr - max2nd; min_cov_thr = max2nd; }
   const uint32_t adj = (cdf[0] > cdfx) ? cdf[0] - cdfx : 0;       // deficit of strand [0] for both strands (:1676)
   uint32_t nmin = 0;
+  if (!err && (ncand > (1u << WSORT_IDXBITS) || max_cover >= (uint32_t)WSORT_NBINS)) err = SMG_ERR_CAP;
   if (!err) {
     SMG_PAR_CHUNKS(base, ncand) {           // count the candidates that pass (:1700-1730)
       const uint32_t i = base + SMG_LANE;
       const bool keep = i < ncand && !(x.cand[i].cover + adj < min_cov_thr);
       (void)compact_slot(keep, nmin);
     }
-    if (nmin > lds_sort_cap) { skeys = x.sort_keys; sidx = x.sort_idx; }
+    if (nmin > lds_sort_cap) kv = x.sort_keys;
+    SMG_PAR_CHUNKS(base, (uint32_t)WSORT_NBINS) { const uint32_t i = base + SMG_LANE; if (i < (uint32_t)WSORT_NBINS) hist[i] = 0; }
+    SMG_SYNC();
     uint32_t w2 = 0;
     SMG_PAR_CHUNKS(base, ncand) {           // ... and list them in candidate order
       const uint32_t i = base + SMG_LANE;
@@ -557,36 +564,58 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
       uint32_t cov = 0;
       if (i < ncand) { cov = x.cand[i].cover; keep = !(cov + adj < min_cov_thr); }
       const uint32_t slot = compact_slot(keep, w2);
-      if (keep) { skeys[slot] = max_cover - cov; sidx[slot] = i; }
+      if (keep) {
+        const uint32_t key = max_cover - cov;
+        kv[slot] = (key << WSORT_IDXBITS) | i;
+        atomic_add_u32(&hist[key < (uint32_t)WSORT_NBINS ? key : (uint32_t)WSORT_NBINS - 1], 1u);
+      }
     }
   }
   SMG_SYNC();
   SMG_PH(6)
-  SMG_LANE0 {
+  // The sorted key sequence does not depend on the tie order: the depth cut (:1745-1775) follows from
+  // the key histogram, and only ranks below it have to be brought into the reference's order.
+  uint32_t nrank = 0;
+  if (!err) {
+    SMG_LANE0 { uint32_t c = 0; for (int v = 0; v < WSORT_NBINS; v++) { c += hist[v]; hist[v] = c; } }   // hist[v] = #keys <= v
+    SMG_SYNC();
+#define SMG_CLT(v) ((v) == 0 ? 0u : hist[((v) > (uint32_t)WSORT_NBINS ? (uint32_t)WSORT_NBINS : (v)) - 1])
     uint32_t j = nmin;
-    if (!err) {
-      sort2_u32((int)j, skeys, sidx);      // sort.c:233 tie order
-      if (j > target_depth) {
-        const uint32_t maxj = (j < max_depth) ? j : max_depth;
-        if (p.flags & FLG_SENSITIVE) {
-          for (j = target_depth; j < maxj; j++) if (skeys[j] >= adj) break;     // :1760-1764
-          for (; j < nmin && skeys[j] < (uint32_t)s; j++) {}
-        } else {
-          uint32_t cov = skeys[j / 2];
-          if (cov < (uint32_t)s) cov = (uint32_t)s;
-          for (j = target_depth; j < maxj && skeys[j] < cov; j++) {}
-        }
+    if (j > target_depth) {
+      const uint32_t maxj = (j < max_depth) ? j : max_depth;
+      if (p.flags & FLG_SENSITIVE) {
+        const uint32_t c1 = SMG_CLT(adj), c2 = SMG_CLT((uint32_t)s);
+        j = c1 > target_depth ? c1 : target_depth;                     // :1760-1764
+        if (j > maxj) j = maxj;
+        if (c2 > j) j = c2;
+      } else {
+        const uint32_t rank = j / 2;
+        uint32_t lo = 0, hi = WSORT_NBINS - 1;                         // key of rank j/2
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (hist[mid] > rank) hi = mid; else lo = mid + 1; }
+        uint32_t cov = lo;
+        if (cov < (uint32_t)s) cov = (uint32_t)s;
+        const uint32_t c1 = SMG_CLT(cov);
+        j = c1 > target_depth ? c1 : target_depth;
+        if (j > maxj) j = maxj;
       }
-    } else j = 0;
-    ch.ncand = ncand; ch.n_sort = j; ch.n_mincover = nmin; ch.max_cover = max_cover; ch.max2nd_cover = max2nd;
+    }
+#undef SMG_CLT
+    nrank = j;
+    SMG_SYNC();
+    wave_sort_kv(kv, (int)nmin, (int)nrank, wk);    // sort.c:233 tie order
+  }
+  SMG_LANE0 {
+    ch.ncand = ncand; ch.n_sort = nrank; ch.n_mincover = nmin; ch.max_cover = max_cover; ch.max2nd_cover = max2nd;
     ch.err = err;
     ch.rc_off = atomic_add_u32(b.rc_count, ch.n_sort);
     if (ch.rc_off + ch.n_sort > b.rccap) { ch.err = SMG_ERR_CAP; ch.n_sort = 0; }
   }
   SMG_SYNC();
-  if (skeys != x.sort_keys) {               // ranked part back to the slot (S7 below, diagnostics)
+  {                                         // ranked part to the slot (S7 below, diagnostics)
     const uint32_t ns = ch.n_sort;
-    SMG_PAR_CHUNKS(base, ns) { const uint32_t i = base + SMG_LANE; if (i < ns) { x.sort_keys[i] = skeys[i]; x.sort_idx[i] = sidx[i]; } }
+    SMG_PAR_CHUNKS(base, ns) { const uint32_t i = base + SMG_LANE; if (i < ns) { const uint32_t v = kv[i]; x.sort_idx[i] = v & ((1u << WSORT_IDXBITS) - 1u); } }
+    SMG_SYNC();
+    SMG_PAR_CHUNKS(base, ns) { const uint32_t i = base + SMG_LANE; if (i < ns) x.sort_keys[i] = kv[i] >> WSORT_IDXBITS; }
   }
   SMG_SYNC();
   SMG_PH(7)

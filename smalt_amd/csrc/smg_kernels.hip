@@ -30,9 +30,15 @@ __global__ void __launch_bounds__(64) k_encode(const uint8_t *bases, const uint6
 // ---------------------------------------------------------------------------------------
 // S1 + S2: one wave per (read, strand); scratch in LDS when it fits, else in HBM slots
 // ---------------------------------------------------------------------------------------
+// Stage code reaches its LDS arrays through generic pointers (the same source serves HBM slots).  A flat
+// access whose register address lies below the LDS aperture faults even if the instruction offset
+// brings it back inside (e.g. a[i + 1] with i == -1 compiled as base a + 4*i, offset 4), so no array
+// starts at LDS offset 0.
+enum : uint32_t { LDS_GUARD = 64 };
+
 __global__ void __launch_bounds__(64) k_seed(Batch b, DevIndex ix, MapPar p, uint8_t *gscratch, size_t gbytes, int use_lds) {
   extern __shared__ __align__(16) uint8_t lds[];
-  uint8_t *base = use_lds ? lds : gscratch + gbytes * blockIdx.x;
+  uint8_t *base = use_lds ? lds + LDS_GUARD : gscratch + gbytes * blockIdx.x;
   SeedScratch x = seed_scratch_carve(base, b.qmax, ix.s);
   unsigned long long nlook = 0;
   for (uint32_t rs = blockIdx.x; rs < 2 * b.nreads; rs += gridDim.x) {
@@ -51,7 +57,7 @@ __global__ void __launch_bounds__(64) k_cands(Batch b, DevIndex ix, MapPar p, ui
   for (uint32_t r = blockIdx.x; r < b.nreads; r += gridDim.x) {
     uint8_t *base = gscratch + g.slot_bytes * (g.debug ? r : blockIdx.x);
     if (cands_v2_applicable(p, ix.k, ix.s, read_len(b, r))) {
-      CandsV2Scratch x = cands_v2_carve(lds, lds_bytes, base, b.qmax, ix.s, g.hcap_strand, g.ngrp, g.candcap, g.debug != 0);
+      CandsV2Scratch x = cands_v2_carve(lds + LDS_GUARD, lds_bytes, base, b.qmax, ix.s, g.hcap_strand, g.ngrp, g.candcap, g.debug != 0);
       nhit += stage_cands_v2(b, ix, p, r, x, ph);
     } else {
       CandScratch x = cand_scratch_carve(base, b.qmax, ix.s, g.hcap, g.ngrp, g.segcap, g.candcap);
@@ -77,7 +83,7 @@ __global__ void __launch_bounds__(64) k_align(Batch b, DevIndex ix, MapPar p, ui
                                               uint64_t dircap, uint32_t rescap, uint32_t dstrcap, uint32_t lds_bytes) {
   extern __shared__ __align__(16) uint8_t lds[];
   uint8_t *base = gscratch + gbytes * blockIdx.x;
-  AlignScratch x = align_scratch_carve_lds(lds_bytes ? lds : nullptr, lds_bytes, base, b.qmax, wincap, dircap, rescap, dstrcap);
+  AlignScratch x = align_scratch_carve_lds(lds_bytes ? lds + LDS_GUARD : nullptr, lds_bytes, base, b.qmax, wincap, dircap, rescap, dstrcap);
   for (uint32_t r = blockIdx.x; r < b.nreads; r += gridDim.x) {
     stage_align(b, ix, p, r, x);
     __syncthreads();
@@ -321,7 +327,7 @@ int launch_seed(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar 
   const int use_lds = sbytes <= 48 * 1024;
   uint32_t items = 2 * b.nreads;
   uint32_t grid = use_lds ? (items < 32768u ? items : 32768u) : (items < nslots ? items : nslots);
-  hipLaunchKernelGGL(k_seed, dim3(grid), dim3(64), use_lds ? sbytes : 0, s, b, ix, p, scratch, sbytes, use_lds);
+  hipLaunchKernelGGL(k_seed, dim3(grid), dim3(64), use_lds ? sbytes + LDS_GUARD : 0, s, b, ix, p, scratch, sbytes, use_lds);
   SMG_LAUNCH_CHECK();
   return 0;
 }
@@ -330,7 +336,7 @@ int launch_cands(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar
   if (!b.nreads) return 0;
   uint32_t grid = b.nreads < nslots ? b.nreads : nslots;
   const uint32_t lds_bytes = (uint32_t)strand_work_bytes<uint16_t>(CANDS_LDS_HITS);
-  hipLaunchKernelGGL(k_cands, dim3(grid), dim3(64), lds_bytes, s, b, ix, p, scratch, g, lds_bytes);
+  hipLaunchKernelGGL(k_cands, dim3(grid), dim3(64), lds_bytes + LDS_GUARD, s, b, ix, p, scratch, g, lds_bytes);
   SMG_LAUNCH_CHECK();
   return 0;
 }
@@ -347,8 +353,8 @@ int launch_align(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar
   if (!b.nreads) return 0;
   uint32_t grid = b.nreads < nslots ? b.nreads : nslots;
   size_t small = align_lds_small_bytes(b.qmax, wincap);
-  uint32_t lds_bytes = small + 4096 <= 40 * 1024 ? 40 * 1024 : 0;      // rows + window + 30-odd KB of direction bytes
-  hipLaunchKernelGGL(k_align, dim3(grid), dim3(64), lds_bytes, s, b, ix, p, scratch, sbytes, wincap, dircap, rescap, dstrcap, lds_bytes);
+  uint32_t lds_bytes = small + 4096 <= 40 * 1024 ? 40 * 1024 - LDS_GUARD : 0;      // rows + window + 30-odd KB of direction bytes
+  hipLaunchKernelGGL(k_align, dim3(grid), dim3(64), lds_bytes ? lds_bytes + LDS_GUARD : 0, s, b, ix, p, scratch, sbytes, wincap, dircap, rescap, dstrcap, lds_bytes);
   SMG_LAUNCH_CHECK();
   return 0;
 }
@@ -393,6 +399,31 @@ template <int G, int C>
 static void launch_sw_raw_t(hipStream_t s, const uint8_t *q, const uint32_t *qo, const uint8_t *r, const uint32_t *ro, uint32_t n,
                             const MapPar &p, int32_t *sc, uint32_t grid) {
   hipLaunchKernelGGL((k_sw_full_raw<G, C>), dim3(grid), dim3(64), 0, s, q, qo, r, ro, n, p, sc);
+}
+
+// test entry of the candidate ranking sort (smg_wsort.hpp): one wave per array of keys
+__global__ void __launch_bounds__(64) k_rank_sort_raw(const uint32_t *keys, const uint32_t *off, uint32_t narr, int nneed, int in_lds,
+                                                      uint32_t *kv, uint32_t *out_key, uint32_t *out_idx) {
+  __shared__ uint32_t sh[16 + WSORT_WORDS + 8192];
+  uint32_t *wk = sh + 16, *arr = wk + WSORT_WORDS;
+  for (uint32_t t = blockIdx.x; t < narr; t += gridDim.x) {
+    const uint32_t o = off[t], n = off[t + 1] - o;
+    uint32_t *a = (in_lds && n <= 8192) ? arr : kv + o;
+    for (uint32_t i = threadIdx.x; i < n; i += 64) a[i] = (keys[o + i] << WSORT_IDXBITS) | i;
+    __syncthreads();
+    wave_sort_kv(a, (int)n, nneed < 0 ? (int)n : nneed, wk);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 64) { out_key[o + i] = a[i] >> WSORT_IDXBITS; out_idx[o + i] = a[i] & ((1u << WSORT_IDXBITS) - 1u); }
+    __syncthreads();
+  }
+}
+
+int launch_rank_sort_raw(hipStream_t s, const uint32_t *keys, const uint32_t *off, uint32_t narr, int nneed, int in_lds, uint32_t *kv,
+                         uint32_t *out_key, uint32_t *out_idx) {
+  if (!narr) return 0;
+  hipLaunchKernelGGL(k_rank_sort_raw, dim3(narr < 4096 ? narr : 4096), dim3(64), 0, s, keys, off, narr, nneed, in_lds, kv, out_key, out_idx);
+  SMG_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_sw_full_raw(hipStream_t s, const uint8_t *q, const uint32_t *qo, const uint8_t *r, const uint32_t *ro, uint32_t n,
