@@ -240,6 +240,7 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
     m->cg.ngrp = d.nseq < 512 ? (uint32_t)d.nseq : 1u;  // both modes fit: concatenated mode uses group 0
     m->cg.segcap = m->cg.hcap / 2;
     m->cg.candcap = m->cg.hcap;                         // every hit can be a candidate of its own (mincover = k)
+    { const char *e = getenv("SMALTGPU_CANDS_WINDOW"); m->cg.window = e ? (uint32_t)atoi(e) : 0; }   // test hook (tests/test_gpu_large.py)
     m->cg.slot_bytes = m->cand_bytes = cand_slot_bytes(m->cg, m->qmax, d.s);
     uint64_t budget = 24ull << 30;
     uint64_t slots = budget / m->cand_bytes;

@@ -20,7 +20,10 @@
 
 namespace smg {
 
-enum : uint32_t { CANDS_LDS_HITS = 2048 };
+enum : uint32_t { CANDS_LDS_HITS = 2048,       // hits of the LDS working set (one strand, or one window of a strand)
+                  CANDS_TAB = 264,             // per-list tables: a read of the wave-parallel form has <= 256 seeds
+                  CANDS_TAB_BYTES = 5 * CANDS_TAB * 4 };
+enum : int { SMG_WINDOW_FALLBACK = 1000 };      // internal: a hit region does not fit a window
 
 template <class IT>
 struct StrandWork {           // one strand's working set; IT = uint16_t (LDS) or uint32_t (HBM)
@@ -148,7 +151,9 @@ SMG_HD inline int derive_cand_c(SegCand &c, const StrandWork<IT> &w, uint32_t m0
 template <class IT>
 SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, bool seqbyseq, uint32_t qlen, int k, int s,
                                uint32_t mincover, SegCand *cand_tmp, SegCand *cand, uint32_t candcap, uint32_t *ncand_io,
-                               uint32_t *max_cover_io, uint32_t *max2nd_io, unsigned long long *ph) {
+                               uint32_t *max_cover_io, uint32_t *max2nd_io, unsigned long long *ph,
+                               bool hold_tail, uint32_t *nproc_out, uint32_t *reg_base_io) {
+  *nproc_out = n;
   if (!n) return 0;
   unsigned long long t0 = phase_clock(), t1;
 #define SMG_PH(i) { t1 = phase_clock(); ph[i] += t1 - t0; t0 = t1; }
@@ -158,6 +163,18 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
   uint32_t max_dshift = (uint32_t)(k * SEGMENTING_DIFFSHIFT / s) & 0xffffu;     // segment.c:426-429
   { uint32_t ds = (qlen - (uint32_t)k) / (uint32_t)s + 1; if (ds < max_dshift) max_dshift = ds & 0xffffu; }
   const uint64_t dsthresh = ((uint64_t)max_dshift) << HALFBIT;
+  if (hold_tail) {           // more hits follow: stop at the last region boundary, the caller keeps the rest
+    uint32_t last = 0;
+    SMG_PAR_CHUNKS(base, n) {
+      const uint32_t i = base + SMG_LANE;
+      if (i > 0 && i < n && region_break(w.dat[i - 1], w.dat[i], dsthresh)) last = i;
+    }
+    last = wave_max_u32(last);
+    if (!last) return SMG_WINDOW_FALLBACK;
+    n = last;
+    *nproc_out = n;
+  }
+  const uint32_t reg_base = *reg_base_io;
 
   // hits -> seeds
   uint32_t nseed = 0;
@@ -243,7 +260,7 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
         }
         if (cover >= mincover) {
           SegCand c;
-          if (derive_cand_c(c, w, m0, (int)(j - i), k, s, cover, mincover, r, is_reverse, seqidx)) err = SMG_ERR_ASSERT;
+          if (derive_cand_c(c, w, m0, (int)(j - i), k, s, cover, mincover, reg_base + r, is_reverse, seqidx)) err = SMG_ERR_ASSERT;
           cand_tmp[m0] = c;
           w.cflag[m0] = 1;
           if (cover > mx2) { if (cover > mx) { mx2 = mx; mx = cover; } else if (cover != mx) mx2 = cover; }
@@ -264,6 +281,7 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
   }
 #endif
   *max_cover_io = mx; *max2nd_io = mx2;
+  *reg_base_io = reg_base + nreg;
   if (wave_any(err != 0)) return SMG_ERR_ASSERT;
   SMG_SYNC();
   SMG_PH(4)
@@ -284,7 +302,8 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
 }
 
 struct CandsV2Scratch {
-  uint8_t *lds; size_t lds_bytes;        // per-workgroup LDS block (null on the host build -> HBM is used)
+  uint8_t *lds; size_t lds_bytes;        // per-workgroup LDS block (the host build passes plain memory)
+  uint32_t window;                       // test hook: hits per window (0: CANDS_LDS_HITS)
   uint8_t *hbm;                          // HBM slot: strand work for large strands + cand_tmp + candidates
   uint32_t hcap_strand;                  // capacity of the HBM strand work (hits per strand)
   SegCand *cand_tmp; SegCand *cand; uint32_t candcap;
@@ -305,7 +324,7 @@ SMG_HD inline size_t cands_v2_hbm_bytes(uint32_t qmax, int s, uint32_t hcap_stra
 SMG_HD inline CandsV2Scratch cands_v2_carve(uint8_t *lds, size_t lds_bytes, uint8_t *hbm, uint32_t qmax, int s, uint32_t hcap_strand,
                                             uint32_t ngrp, uint32_t candcap, bool debug) {
   CandsV2Scratch x;
-  x.lds = lds; x.lds_bytes = lds_bytes; x.hcap_strand = hcap_strand; x.candcap = candcap; x.ngrp = ngrp;
+  x.lds = lds; x.lds_bytes = lds_bytes; x.window = 0; x.hcap_strand = hcap_strand; x.candcap = candcap; x.ngrp = ngrp;
   uint8_t *b = hbm;
   x.hbm = b; b += (strand_work_bytes<uint32_t>(hcap_strand) + 63) & ~(size_t)63;
   x.cand_tmp = (SegCand *)b; b += (size_t)hcap_strand * sizeof(SegCand);
@@ -325,6 +344,25 @@ SMG_HD inline CandsV2Scratch cands_v2_carve(uint8_t *lds, size_t lds_bytes, uint
     x.dbg_cnt = (uint32_t *)b;
   } else { x.dbg_words = nullptr; x.dbg_first = x.dbg_cnt = nullptr; }
   return x;
+}
+
+// debug: processed hits in the layout of the reference's per-sequence hit lists
+SMG_HD inline void dbg_hits(const CandsV2Scratch &x, const uint64_t *dat, uint32_t n, uint32_t gbase, uint32_t st, uint32_t ngrp, bool seqbyseq,
+                            uint64_t *dw, uint32_t &last_grp) {
+  SMG_PAR_CHUNKS(base, n) {
+    const uint32_t i = base + SMG_LANE;
+    if (i < n) {
+      const uint64_t key = dat[i];
+      const uint32_t grp = key_grp(key), prev = i ? key_grp(dat[i - 1]) : last_grp;
+      const uint32_t gi = st * ngrp + (seqbyseq ? (grp & ((1u << KEY_SEQBITS) - 1)) : 0u);
+      if (prev != grp) x.dbg_first[gi] = gbase + i + st * x.hcap_strand;
+      (void)atomic_add_u32(&x.dbg_cnt[gi], 1u);
+      dw[gbase + i] = key_packed(key);
+    }
+  }
+  SMG_SYNC();
+  if (n) last_grp = key_grp(dat[n - 1]);
+  SMG_SYNC();
 }
 
 // true when the parallel form applies to this read
@@ -368,6 +406,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
 
   for (uint32_t st = 0; st < 2 && !err; st++) {
     const uint32_t rs = 2 * r + st;
+    const unsigned long long ts = phase_clock();
     const HitInfoHdr hdr = b.hi[rs];
     const SeedRec *seeds = b.seeds + (size_t)rs * b.qmax;
     uint8_t *qmask = b.qmask + (size_t)rs * b.qmax;
@@ -418,84 +457,228 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     }
     SMG_SYNC();
     SMG_PH(0)
-    // choose the working set: LDS for small strands
-    // `tot` bounds the gathered hits unless the allocation-boundary protocol is active (then every
-    // sequence may contribute up to nhits_alloc): that case is range-checked while gathering
-    const bool in_lds = x.lds && (all_in || !seqbyseq) && tot <= CANDS_LDS_HITS && strand_work_bytes<uint16_t>(CANDS_LDS_HITS) <= x.lds_bytes;
-    const uint32_t gcap = in_lds ? CANDS_LDS_HITS : x.hcap_strand;
-    if ((all_in || !seqbyseq) && tot > gcap) { err = SMG_ERR_CAP; break; }
+    // ---- working set --------------------------------------------------------------------------
+    //  mode 0: the whole strand fits the LDS working set
+    //  mode 1: larger strands are streamed through the LDS working set in windows of ascending diagonal;
+    //          a window ends at a hit-region boundary, so every later stage sees complete regions
+    //  mode 2: HBM working set (allocation-boundary protocol active, or a region larger than a window)
+    const bool simple = all_in || !seqbyseq;
+    const size_t wl_bytes = (strand_work_bytes<uint16_t>(CANDS_LDS_HITS) + 15) & ~(size_t)15;
+    const bool lds_ok = x.lds && wl_bytes + CANDS_TAB_BYTES <= x.lds_bytes;
+    uint32_t W = CANDS_LDS_HITS;
+    if (x.window && x.window < W) W = x.window;
     StrandWork<uint16_t> wl = strand_work_carve<uint16_t>(x.lds, CANDS_LDS_HITS);
     StrandWork<uint32_t> wg = strand_work_carve<uint32_t>(x.hbm, x.hcap_strand);
-    uint64_t *dat = in_lds ? wl.dat : wg.dat;
-    // gather (hashhit.c:1416-1546): lanes stride over the position list of one seed at a time
-    uint32_t nkeys = 0;
-    for (uint32_t n = 0; n < n_use; n++) {
-      const SeedRec sd = seeds[n];
-      if (ncut > 0 && sd.nhits > ncut && seqbyseq) continue;
-      const uint32_t *posp;
-      const uint32_t nh = index_positions(ix, sd.posidx, &posp);
-      if (!seqbyseq) {
-        if (n >= dec[0].n_used || (dec[0].m_final > 0 && sd.nhits > dec[0].m_final) || sd.nhits < 1) continue;
-        SMG_PAR_CHUNKS(base, nh) {
-          uint32_t i = base + SMG_LANE;
-          if (i < nh) dat[nkeys + i] = (hit_diag(st != 0, posp[i], sd.qoffs, s) << KEY_QBITS) | sd.qoffs;
-        }
-        nkeys += nh;
-      } else if (all_in) {
-        SMG_PAR_CHUNKS(base, nh) {
-          uint32_t i = base + SMG_LANE;
-          if (i < nh) {
-            const uint32_t pos = posp[i];
-            const uint32_t g = seq_of_pos(ix.seqlo, ix.nseq, pos);
-            dat[nkeys + i] = ((uint64_t)g << (KEY_DIAGBITS + KEY_QBITS)) | (hit_diag(st != 0, pos, sd.qoffs, s) << KEY_QBITS) | sd.qoffs;
+    uint32_t *gt = lds_ok ? (uint32_t *)(x.lds + wl_bytes) : x.sort_keys;        // per-list tables (sort arrays are dead here)
+    uint32_t *g_pfx = gt, *g_poff = gt + CANDS_TAB, *g_qo = gt + 2 * CANDS_TAB, *g_len = gt + 3 * CANDS_TAB;
+    uint32_t nlist = 0, total = 0;
+    if (simple) {
+      // Seeds that contribute become "lists" (position lists of the index, ascending); hit h of the strand
+      // belongs to the list whose exclusive length prefix holds h.
+      SMG_PAR_CHUNKS(base, n_use) {
+        const uint32_t n = base + SMG_LANE;
+        bool take = false;
+        uint32_t nh = 0, poff = 0, qo = 0;
+        if (n < n_use) {
+          const SeedRec sd = seeds[n];
+          if (seqbyseq) take = !(ncut > 0 && sd.nhits > ncut);
+          else take = !(n >= dec[0].n_used || (dec[0].m_final > 0 && sd.nhits > dec[0].m_final) || sd.nhits < 1);
+          if (take) {
+            const uint32_t *posp;
+            nh = index_positions(ix, sd.posidx, &posp);
+            poff = (uint32_t)(posp - ix.pos); qo = sd.qoffs;
+            take = nh > 0;
           }
         }
-        nkeys += nh;
-      } else {
-        uint32_t cnt = 0;
-        SMG_PAR_CHUNKS(base, nh) {
-          uint32_t i = base + SMG_LANE;
-          bool take = false;
-          uint64_t key = 0;
-          if (i < nh) {
-            const uint32_t pos = posp[i];
-            const uint32_t g = seq_of_pos(ix.seqlo, ix.nseq, pos);
-            const FillDecision d = dec[g];
-            take = n < d.n_used && !(d.m_final > 0 && sd.nhits > d.m_final);
-            key = ((uint64_t)g << (KEY_DIAGBITS + KEY_QBITS)) | (hit_diag(st != 0, pos, sd.qoffs, s) << KEY_QBITS) | sd.qoffs;
-          }
-          const uint32_t slot = compact_slot(take, cnt);
-          if (take && nkeys + slot < gcap) dat[nkeys + slot] = key;
-        }
-        nkeys += cnt;
-        if (nkeys > gcap) { err = SMG_ERR_CAP; break; }
-      }
-    }
-    SMG_SYNC();
-    SMG_PH(1)
-    if (err) break;
-    SMG_LANE0 { ch.nhits[st] = nkeys; }
-    nhits_total += nkeys;
-    int rv;
-    if (in_lds) rv = strand_cands(wl, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph);
-    else rv = strand_cands(wg, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph);
-    t0 = phase_clock();
-    if (rv) { err = rv; break; }
-    if (x.dbg_words) {       // debug: the hit lists in the layout of the reference's per-sequence hit lists
-      uint64_t *dw = x.dbg_words + (size_t)st * x.hcap_strand;
-      SMG_PAR_CHUNKS(base, nkeys) {
-        uint32_t i = base + SMG_LANE;
-        if (i < nkeys) {
-          const uint64_t key = dat[i];
-          const uint32_t gi = st * ngrp + (seqbyseq ? (key_grp(key) & ((1u << KEY_SEQBITS) - 1)) : 0u);
-          if (i == 0 || key_grp(dat[i - 1]) != key_grp(key)) x.dbg_first[gi] = i + st * x.hcap_strand;
-          if (i + 1 == nkeys || key_grp(dat[i + 1]) != key_grp(key)) x.dbg_cnt[gi] = i + 1;
-          dw[i] = key_packed(key);
-        }
+        uint32_t incl = nh;
+#if defined(__HIP_DEVICE_COMPILE__)
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if ((int)SMG_LANE >= o) incl += v; }
+#endif
+        const uint32_t slot = compact_slot(take, nlist);
+        if (take) { g_pfx[slot] = total + incl - nh; g_poff[slot] = poff; g_qo[slot] = qo; g_len[slot] = nh; }
+#if defined(__HIP_DEVICE_COMPILE__)
+        total += (uint32_t)__shfl((int)incl, 63);
+#else
+        total += incl;
+#endif
       }
       SMG_SYNC();
-      SMG_PAR_CHUNKS(base, ngrp) { uint32_t g = base + SMG_LANE; if (g < ngrp && x.dbg_cnt[st * ngrp + g]) x.dbg_cnt[st * ngrp + g] -= x.dbg_first[st * ngrp + g] - st * x.hcap_strand; }
     }
+    int mode = !simple ? 2 : ((lds_ok && total <= W) ? 0 : (lds_ok ? 1 : 2));
+    const uint32_t ncand0 = ncand, mx0 = max_cover, mx20 = max2nd;
+    uint32_t nkeys = 0;
+    uint64_t *dbg_w = x.dbg_words ? x.dbg_words + (size_t)st * x.hcap_strand : nullptr;
+
+    if (mode == 1) {
+      uint32_t *g_cur = gt + 4 * CANDS_TAB;            // per-list cursor
+      SMG_PAR_CHUNKS(base, nlist) { const uint32_t l = base + SMG_LANE; if (l < nlist) g_cur[l] = 0; }
+      SMG_SYNC();
+      uint32_t carry = 0, remaining = total, reg_base = 0, gproc = 0, last_grp = ~0u;
+      int rv = 0;
+      while (remaining > 0 || carry > 0) {
+        if (carry + nlist + 64 > W) { rv = SMG_WINDOW_FALLBACK; break; }
+        const uint32_t room = W - carry - nlist;
+        // window end: smallest (sequence, diagonal) reached by any list after its proportional share
+        uint64_t bound = ~0ull;
+        SMG_PAR_CHUNKS(base, nlist) {
+          const uint32_t l = base + SMG_LANE;
+          if (l < nlist) {
+            const uint32_t cur = g_cur[l], rem = g_len[l] - cur;
+            if (rem) {
+              const uint32_t t = (uint32_t)(((uint64_t)room * rem) / remaining) + 1;
+              if (t < rem) {
+                const uint32_t pos = ix.pos[g_poff[l] + cur + t];
+                uint64_t kh = hit_diag(st != 0, pos, g_qo[l], s);
+                if (seqbyseq) kh |= (uint64_t)seq_of_pos(ix.seqlo, ix.nseq, pos) << KEY_DIAGBITS;
+                if (kh < bound) bound = kh;
+              }
+            }
+          }
+        }
+        bound = wave_min_u64(bound);
+        // per list: elements below the bound
+        uint32_t cnt_tot = 0;
+        SMG_PAR_CHUNKS(base, nlist) {
+          const uint32_t l = base + SMG_LANE;
+          uint32_t cnt = 0;
+          if (l < nlist) {
+            const uint32_t cur = g_cur[l], rem = g_len[l] - cur;
+            if (rem) {
+              const uint32_t t = (uint32_t)(((uint64_t)room * rem) / remaining) + 1;
+              uint32_t lo = 0, hi = t < rem ? t : rem;       // first offset whose key is not below the bound
+              const uint32_t *pp = ix.pos + g_poff[l] + cur;
+              const uint32_t qo = g_qo[l];
+              while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1, pos = pp[mid];
+                uint64_t kh = hit_diag(st != 0, pos, qo, s);
+                if (seqbyseq) kh |= (uint64_t)seq_of_pos(ix.seqlo, ix.nseq, pos) << KEY_DIAGBITS;
+                if (kh < bound) lo = mid + 1; else hi = mid;
+              }
+              cnt = lo;
+            }
+          }
+          uint32_t incl = cnt;
+#if defined(__HIP_DEVICE_COMPILE__)
+          for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if ((int)SMG_LANE >= o) incl += v; }
+#endif
+          if (l < nlist) g_pfx[l] = cnt_tot + incl - cnt;
+#if defined(__HIP_DEVICE_COMPILE__)
+          cnt_tot += (uint32_t)__shfl((int)incl, 63);
+#else
+          cnt_tot += incl;
+#endif
+        }
+        SMG_SYNC();
+        if (carry + cnt_tot > W || (cnt_tot == 0 && remaining > 0)) { rv = SMG_ERR_ASSERT; break; }
+        SMG_PAR_CHUNKS(base, cnt_tot) {
+          const uint32_t h = base + SMG_LANE;
+          if (h < cnt_tot) {
+            uint32_t lo = 0, hi = nlist;
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g_pfx[mid] <= h) lo = mid; else hi = mid; }
+            const uint32_t pos = ix.pos[g_poff[lo] + g_cur[lo] + (h - g_pfx[lo])], qo = g_qo[lo];
+            uint64_t key = (hit_diag(st != 0, pos, qo, s) << KEY_QBITS) | qo;
+            if (seqbyseq) key |= (uint64_t)seq_of_pos(ix.seqlo, ix.nseq, pos) << (KEY_DIAGBITS + KEY_QBITS);
+            wl.dat[carry + h] = key;
+          }
+        }
+        SMG_SYNC();
+        SMG_PAR_CHUNKS(base, nlist) {
+          const uint32_t l = base + SMG_LANE;
+          if (l < nlist) g_cur[l] += (l + 1 < nlist ? g_pfx[l + 1] : cnt_tot) - g_pfx[l];
+        }
+        remaining -= cnt_tot;
+        const uint32_t n = carry + cnt_tot;
+        SMG_SYNC();
+        SMG_PH(1)
+        uint32_t nproc = n;
+        rv = strand_cands(wl, n, st != 0, seqbyseq, qlen, k, s, min_cover, x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph,
+                          remaining > 0, &nproc, &reg_base);
+        t0 = phase_clock();
+        if (rv) break;
+        if (dbg_w) dbg_hits(x, wl.dat, nproc, gproc, st, ngrp, seqbyseq, dbg_w, last_grp);
+        gproc += nproc;
+        // the unfinished last region opens the next window
+        carry = n - nproc;
+        for (uint32_t base = 0; base < carry; base += SMG_NLANES) {
+          const uint32_t i = base + SMG_LANE;
+          uint64_t v = 0;
+          if (i < carry) v = wl.dat[nproc + i];
+          SMG_SYNC();
+          if (i < carry) wl.dat[i] = v;
+          SMG_SYNC();
+        }
+        if (remaining == 0) carry = 0;
+      }
+      if (rv == SMG_WINDOW_FALLBACK) {           // a hit region larger than the window: redo the strand in HBM
+        ncand = ncand0; max_cover = mx0; max2nd = mx20;
+        mode = 2;
+        SMG_SYNC();
+        SMG_LANE0 { uint32_t c = 0; for (uint32_t l = 0; l < nlist; l++) { g_pfx[l] = c; c += g_len[l]; } }   // the windows reused the prefix table
+        SMG_SYNC();
+        if (x.dbg_first) { SMG_SYNC(); SMG_PAR_CHUNKS(base, ngrp) { uint32_t g = base + SMG_LANE; if (g < ngrp) { x.dbg_first[st * ngrp + g] = 0; x.dbg_cnt[st * ngrp + g] = 0; } } SMG_SYNC(); }
+      } else if (rv) { err = rv; break; }
+      else nkeys = total;
+      ph[11]++; ph[12] += total; ph[13] += t0 - ts;
+    }
+
+    if (mode != 1) {
+      const bool in_lds = mode == 0;
+      const uint32_t gcap = in_lds ? CANDS_LDS_HITS : x.hcap_strand;
+      uint64_t *dat = in_lds ? wl.dat : wg.dat;
+      if (simple) {
+        if (total > gcap) { err = SMG_ERR_CAP; break; }
+        nkeys = total;
+        SMG_PAR_CHUNKS(base, nkeys) {
+          const uint32_t h = base + SMG_LANE;
+          if (h < nkeys) {
+            uint32_t lo = 0, hi = nlist;                       // last list with prefix <= h
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g_pfx[mid] <= h) lo = mid; else hi = mid; }
+            const uint32_t pos = ix.pos[g_poff[lo] + (h - g_pfx[lo])], qo = g_qo[lo];
+            uint64_t key = (hit_diag(st != 0, pos, qo, s) << KEY_QBITS) | qo;
+            if (seqbyseq) key |= (uint64_t)seq_of_pos(ix.seqlo, ix.nseq, pos) << (KEY_DIAGBITS + KEY_QBITS);
+            dat[h] = key;
+          }
+        }
+      } else {
+        // gather under the allocation-boundary protocol (hashhit.c:1416-1546): per-sequence decisions
+        for (uint32_t n = 0; n < n_use; n++) {
+          const SeedRec sd = seeds[n];
+          if (ncut > 0 && sd.nhits > ncut) continue;
+          const uint32_t *posp;
+          const uint32_t nh = index_positions(ix, sd.posidx, &posp);
+          uint32_t cnt = 0;
+          SMG_PAR_CHUNKS(base, nh) {
+            uint32_t i = base + SMG_LANE;
+            bool take = false;
+            uint64_t key = 0;
+            if (i < nh) {
+              const uint32_t pos = posp[i];
+              const uint32_t g = seq_of_pos(ix.seqlo, ix.nseq, pos);
+              const FillDecision d = dec[g];
+              take = n < d.n_used && !(d.m_final > 0 && sd.nhits > d.m_final);
+              key = ((uint64_t)g << (KEY_DIAGBITS + KEY_QBITS)) | (hit_diag(st != 0, pos, sd.qoffs, s) << KEY_QBITS) | sd.qoffs;
+            }
+            const uint32_t slot = compact_slot(take, cnt);
+            if (take && nkeys + slot < gcap) dat[nkeys + slot] = key;
+          }
+          nkeys += cnt;
+          if (nkeys > gcap) { err = SMG_ERR_CAP; break; }
+        }
+        if (err) break;
+      }
+      SMG_SYNC();
+      SMG_PH(1)
+      int rv;
+      uint32_t nproc = nkeys, reg_base = 0, last_grp = ~0u;
+      if (in_lds) rv = strand_cands(wl, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph, false, &nproc, &reg_base);
+      else rv = strand_cands(wg, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph, false, &nproc, &reg_base);
+      t0 = phase_clock();
+      if (!in_lds) { ph[14]++; ph[15] += t0 - ts; }
+      if (rv) { err = rv; break; }
+      if (dbg_w) dbg_hits(x, dat, nkeys, 0, st, ngrp, seqbyseq, dbg_w, last_grp);
+    }
+    SMG_LANE0 { ch.nhits[st] = nkeys; }
+    nhits_total += nkeys;
     SMG_SYNC();
   }
 

@@ -63,6 +63,24 @@ SMG_HD inline uint32_t wave_sum_u32(uint32_t v) {
 #endif
 }
 
+SMG_HD inline uint32_t wave_max_u32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t u = (uint32_t)__shfl_xor((int)v, o); if (u > v) v = u; }
+#endif
+  return v;
+}
+
+SMG_HD inline uint64_t wave_min_u64(uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o);
+    const uint64_t u = ((uint64_t)hi << 32) | lo;
+    if (u < v) v = u;
+  }
+#endif
+  return v;
+}
+
 SMG_HD inline bool wave_any(bool f) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __ballot(f) != 0ull;

@@ -15,6 +15,7 @@ struct CandGeom {              // scratch geometry of the candidate stage (both 
   uint32_t ngrp, segcap, candcap;
   size_t slot_bytes;
   int debug;                   // keep per-read slots + the grouped hit words for smaltgpu_dump_read
+  uint32_t window;             // test hook: hits per LDS window of the candidate stage (0 = default)
 };
 inline size_t cand_slot_bytes(const CandGeom &g, uint32_t qmax, int s) {
   size_t a = cand_scratch_bytes(qmax, s, g.hcap, g.ngrp, g.segcap, g.candcap);

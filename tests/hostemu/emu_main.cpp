@@ -103,6 +103,8 @@ int main(int argc, char **argv) {
   std::vector<uint8_t> sscr(seed_scratch_bytes(qmax, ix.s));
   const uint32_t hcap = 1u << 16, segcap = 1u << 15, candcap = 1u << 16;
   const uint32_t hcap_strand = hcap / 2;
+  std::vector<uint8_t> ldsmem(((strand_work_bytes<uint16_t>(CANDS_LDS_HITS) + 15) & ~(size_t)15) + CANDS_TAB_BYTES);   // stands for the workgroup's LDS block
+  const uint32_t window = getenv("EMU_WINDOW") ? (uint32_t)atoi(getenv("EMU_WINDOW")) : 0;   // hits per window of the candidate stage
   const char *force = getenv("EMU_CANDS");       // "v1": sequential restatement only; default: as the kernel chooses
   size_t cbytes = cand_scratch_bytes(qmax, ix.s, hcap, ngrp, segcap, candcap);
   { size_t b2 = cands_v2_hbm_bytes(qmax, ix.s, hcap_strand, ngrp, candcap, true); if (b2 > cbytes) cbytes = b2; }
@@ -114,6 +116,7 @@ int main(int argc, char **argv) {
   int8_t M[64];
   score_matrix(M, p.match, p.mismatch);
 
+  unsigned long long nwin_strands = 0, nhbm_strands = 0;
   for (uint32_t r = 0; r < n; r++) {
     const uint32_t len = (uint32_t)(off[r + 1] - off[r]);
     if (mincover < 1.01) { p.min_cover = (uint32_t)(mincover * len); if (p.min_cover > len) p.min_cover = len; }
@@ -122,9 +125,11 @@ int main(int argc, char **argv) {
     stage_seed(b, ix, p, r, 0, sx);
     stage_seed(b, ix, p, r, 1, sx);
     if (cands_v2_applicable(p, ix.k, ix.s, len) && !(force && !strcmp(force, "v1"))) {
-      CandsV2Scratch c2 = cands_v2_carve(nullptr, 0, cscr.data() + cbytes * r, qmax, ix.s, hcap_strand, ngrp, candcap, true);
-      unsigned long long ph[12] = {0};
+      CandsV2Scratch c2 = cands_v2_carve(ldsmem.data(), ldsmem.size(), cscr.data() + cbytes * r, qmax, ix.s, hcap_strand, ngrp, candcap, true);
+      c2.window = window;
+      unsigned long long ph[16] = {0};
       stage_cands_v2(b, ix, p, r, c2, ph);
+      nwin_strands += ph[11]; nhbm_strands += ph[14];
     } else {
       CandScratch cx = cand_scratch_carve(cscr.data() + cbytes * r, qmax, ix.s, hcap, ngrp, segcap, candcap);
       stage_cands(b, ix, p, r, cx);
@@ -166,5 +171,6 @@ int main(int argc, char **argv) {
     fwrite(out.data(), 1, out.size(), stdout);
   }
   if (err_flag) fprintf(stderr, "emu: %d reads with errors\n", err_flag);
+  if (getenv("EMU_STATS")) fprintf(stderr, "windowed strands %llu, HBM strands %llu\n", nwin_strands, nhbm_strands);
   return 0;
 }

@@ -24,8 +24,13 @@ def _oracle_map_all(oix, reads, par):
     return out
 
 
-def test_repeat_rich_genome_matches_oracle(oracle_built, tmp_path):
+@pytest.mark.parametrize("window", [0, 300], ids=["w-default", "w300"])
+def test_repeat_rich_genome_matches_oracle(window, oracle_built, tmp_path, monkeypatch):
+    """window=300 shrinks the LDS window of the candidate stage so that most strands are streamed in
+    several windows and a few fall back to the HBM working set (a hit region larger than the window)."""
     from smalt_amd import api, synth
+    if window:
+        monkeypatch.setenv("SMALTGPU_CANDS_WINDOW", str(window))
     ch = synth.make_reference(4, 2_500_000, seed=21, repeat_frac=0.15, n_fam=1, cons_len=300, divergence=0.05)
     reads, _ = synth.make_reads(ch, 1500, 100, seed=22, sub_rate=0.01, indel_read_frac=0.05)
     seqs = [synth.codes_to_ascii(c) for c in ch]

@@ -18,10 +18,14 @@ def emu_bin():
     return out
 
 
+@pytest.mark.parametrize("window", [0, 160], ids=["w-default", "w160"])
 @pytest.mark.parametrize("entry", gu.MANIFEST, ids=[e["tag"] for e in gu.MANIFEST])
-def test_stage_logic_matches_reference_dump(entry, emu_bin, oracle_built, tmp_path):
+def test_stage_logic_matches_reference_dump(entry, window, emu_bin, oracle_built, tmp_path):
+    """window=160: strands with more hits stream through the candidate stage in windows of ascending
+    diagonal (and fall back to the HBM working set when a hit region exceeds the window)."""
     fx = gu.unpack(entry, tmp_path)
-    out = subprocess.run([emu_bin] + entry["opts"].split() + [fx["prefix"], fx["fq"]], check=True, capture_output=True, text=True).stdout
+    env = dict(os.environ, EMU_WINDOW=str(window))
+    out = subprocess.run([emu_bin] + entry["opts"].split() + [fx["prefix"], fx["fq"]], check=True, capture_output=True, text=True, env=env).stdout
     a, b = out.split("\n"), fx["expected"].split("\n")
     for i, (x, y) in enumerate(zip(a, b)):
         assert x == y, "line %d" % (i + 1)
