@@ -301,6 +301,71 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
   return 0;
 }
 
+// hashCalcHitInfoCoverDeficit (hashhit.c:1096-1169) by the wave.  With a seed-rank cut the per-frame
+// coverage is a union of k-base intervals (order-free): lanes OR the intervals of the seeds below the
+// rank into one 256-bit mask per sampling frame.  wk: >= 9 * s words of scratch.
+SMG_HD inline uint32_t wave_cover_deficit(const HitInfoHdr &hdr, const SeedRec *seeds, const uint8_t *qmask, uint32_t qlen, int k, int s, uint32_t *wk) {
+  uint32_t *mask = wk, *val = wk + 8 * (uint32_t)s;        // mask[s][8]; val[s]: frame has seeds / per-frame result
+  SMG_SYNC();
+  SMG_PAR_CHUNKS(base, 9u * (uint32_t)s) { const uint32_t i = base + SMG_LANE; if (i < 9u * (uint32_t)s) wk[i] = 0; }
+  SMG_SYNC();
+  uint32_t deficit = 0;
+  if (hdr.status & HI_RANK) {
+    SMG_PAR_CHUNKS(base, hdr.n_seeds) {
+      const uint32_t i = base + SMG_LANE;
+      if (i < hdr.n_seeds) {
+        const uint32_t q0 = seeds[i].qoffs, f = q0 % (uint32_t)s;
+        atomic_or_u32(&val[f], 1u);
+        if (i < hdr.seed_rank) {
+          for (uint32_t w = q0 >> 5; w <= (q0 + (uint32_t)k - 1) >> 5; w++) {
+            const uint32_t lo = w << 5, a = q0 > lo ? q0 - lo : 0, e = q0 + (uint32_t)k - lo;
+            const uint32_t bits = (e >= 32 ? 0xFFFFFFFFu : ((1u << e) - 1u)) & ~((1u << a) - 1u);
+            atomic_or_u32(&mask[f * 8 + (w & 7)], bits);
+          }
+        }
+      }
+    }
+    SMG_SYNC();
+    uint32_t d = qlen, maxcover = 0;
+    SMG_PAR_CHUNKS(base, (uint32_t)s) {
+      const uint32_t f = base + SMG_LANE;
+      if (f < (uint32_t)s && val[f]) {
+        uint32_t cover = 0;
+        for (int w = 0; w < 8; w++) cover += (uint32_t)__builtin_popcount(mask[f * 8 + (uint32_t)w]);
+        if (cover < d) d = cover;
+        if (cover > maxcover) maxcover = cover;
+      }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t od = (uint32_t)__shfl_xor((int)d, o), om = (uint32_t)__shfl_xor((int)maxcover, o);
+      if (od < d) d = od;
+      if (om > maxcover) maxcover = om;
+    }
+#endif
+    deficit = maxcover - d + 1;
+  } else {
+    uint8_t kk = (uint8_t)(k / s);
+    if (kk > 0) kk--;
+    SMG_PAR_CHUNKS(base, (uint32_t)s) {
+      const uint32_t f = base + SMG_LANE;
+      if (f < (uint32_t)s) {
+        uint8_t ctr = 0;
+        uint32_t d = 0;
+        for (uint32_t i = f; i < qlen; i += (uint32_t)s) {
+          if (qmask[i] == HQ_NORMHIT) ctr = kk;
+          else if (ctr) ctr--;
+          else d += (uint32_t)s;
+        }
+        if (d > deficit) deficit = d;
+      }
+    }
+    deficit = wave_max_u32(deficit);
+  }
+  SMG_SYNC();
+  return deficit;
+}
+
 struct CandsV2Scratch {
   uint8_t *lds; size_t lds_bytes;        // per-workgroup LDS block (the host build passes plain memory)
   uint32_t window;                       // test hook: hits per window (0: CANDS_LDS_HITS)
@@ -683,45 +748,27 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   }
 
   // ---- S6: cover deficits (hashhit.c:1096), threshold, ranking (segment.c:1616-1785) ----
-  // The strand working set is dead now: its LDS block hosts the small scratch arrays and, when the
-  // kept candidates fit, the two arrays of the sequential tie-order-preserving sort.
-  uint32_t *qbr = x.qbr, *frame_cnt = x.frame_cnt, *frame_rank = x.frame_rank;
-  uint8_t *qbuf = x.qbuf;
+  // The strand working set is dead now: its LDS block hosts the work words of the ranking sort, the key
+  // histogram and, when the candidates fit, the packed sort array itself.
   uint32_t *kv = x.sort_keys;             // packed (key << 22) | candidate index
   uint32_t *wk = x.sort_idx;              // work words of the wave sort + key histogram
   uint32_t lds_sort_cap = 0;
   if (x.lds) {
-    const size_t small = ((size_t)b.qmax * 5 + (size_t)s * 4 + (size_t)s * x.stride * 4 + 63) & ~(size_t)63;
     const size_t wkb = ((size_t)WSORT_WORDS + WSORT_NBINS) * 4;
-    if (small + wkb + 4096 <= x.lds_bytes) {
-      uint8_t *l = x.lds;
-      qbr = (uint32_t *)l; l += (size_t)b.qmax * 4;
-      frame_cnt = (uint32_t *)l; l += (size_t)s * 4;
-      frame_rank = (uint32_t *)l; l += (size_t)s * x.stride * 4;
-      qbuf = l;
-      wk = (uint32_t *)(x.lds + small);
-      lds_sort_cap = (uint32_t)((x.lds_bytes - small - wkb) / 4);
+    if (wkb + 4096 <= x.lds_bytes) {
+      wk = (uint32_t *)x.lds;
+      lds_sort_cap = (uint32_t)((x.lds_bytes - wkb) / 4);
       kv = wk + WSORT_WORDS + WSORT_NBINS;
     }
   }
   uint32_t *hist = wk + WSORT_WORDS;
   SMG_SYNC();
   uint32_t cdf[2] = {0, 0};
-  SMG_LANE0 {
-    for (uint32_t st = 0; st < 2; st++) {
-      const uint32_t rs = 2 * r + st;
-      const HitInfoHdr hdr = b.hi[rs];
-      const SeedRec *seeds = b.seeds + (size_t)rs * b.qmax;
-      if (hdr.status & HI_RANK) {
-        for (uint32_t i = 0; i < hdr.n_seeds; i++) qbr[i] = seeds[i].qoffs;
-        build_frames(hdr.n_seeds, qbr, s, frame_cnt, frame_rank, x.stride);
-      }
-      cdf[st] = cover_deficit(hdr.status, hdr.seed_rank, qlen, b.qmask + (size_t)rs * b.qmax, qbr, k, s, frame_cnt, frame_rank, x.stride, qbuf);
-    }
-    ch.cover_deficit[0] = cdf[0]; ch.cover_deficit[1] = cdf[1];
+  for (uint32_t st = 0; st < 2; st++) {
+    const uint32_t rs = 2 * r + st;
+    cdf[st] = wave_cover_deficit(b.hi[rs], b.seeds + (size_t)rs * b.qmax, b.qmask + (size_t)rs * b.qmax, qlen, k, s, wk);
   }
-  SMG_SYNC();
-  cdf[0] = ch.cover_deficit[0];
+  SMG_LANE0 { ch.cover_deficit[0] = cdf[0]; ch.cover_deficit[1] = cdf[1]; }
   uint32_t target_depth = (uint32_t)p.target_depth, max_depth = (uint32_t)p.max_depth;
   if (max_depth < 1 || max_depth > (uint32_t)MAXIMUM_DEPTH) max_depth = MAXIMUM_DEPTH;
   if (target_depth < 1) target_depth = DEFAULT_TARGET_DEPTH;
@@ -732,25 +779,22 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   uint32_t nmin = 0;
   if (!err && (ncand > (1u << WSORT_IDXBITS) || max_cover >= (uint32_t)WSORT_NBINS)) err = SMG_ERR_CAP;
   if (!err) {
-    SMG_PAR_CHUNKS(base, ncand) {           // count the candidates that pass (:1700-1730)
-      const uint32_t i = base + SMG_LANE;
-      const bool keep = i < ncand && !(x.cand[i].cover + adj < min_cov_thr);
-      (void)compact_slot(keep, nmin);
-    }
-    if (nmin > lds_sort_cap) kv = x.sort_keys;
+    if (ncand > lds_sort_cap) kv = x.sort_keys;
     SMG_PAR_CHUNKS(base, (uint32_t)WSORT_NBINS) { const uint32_t i = base + SMG_LANE; if (i < (uint32_t)WSORT_NBINS) hist[i] = 0; }
     SMG_SYNC();
-    uint32_t w2 = 0;
-    SMG_PAR_CHUNKS(base, ncand) {           // ... and list them in candidate order
-      const uint32_t i = base + SMG_LANE;
-      bool keep = false;
-      uint32_t cov = 0;
-      if (i < ncand) { cov = x.cand[i].cover; keep = !(cov + adj < min_cov_thr); }
-      const uint32_t slot = compact_slot(keep, w2);
-      if (keep) {
-        const uint32_t key = max_cover - cov;
-        kv[slot] = (key << WSORT_IDXBITS) | i;
-        atomic_add_u32(&hist[key < (uint32_t)WSORT_NBINS ? key : (uint32_t)WSORT_NBINS - 1], 1u);
+    // candidates that pass the cover threshold, in candidate order (:1700-1730); four independent loads per lane
+    for (uint32_t base = 0; base < ncand; base += 4 * SMG_NLANES) {
+      uint32_t cov[4];
+      for (int u = 0; u < 4; u++) { const uint32_t i = base + (uint32_t)u * SMG_NLANES + SMG_LANE; cov[u] = i < ncand ? x.cand[i].cover : 0; }
+      for (int u = 0; u < 4; u++) {
+        const uint32_t i = base + (uint32_t)u * SMG_NLANES + SMG_LANE;
+        const bool keep = i < ncand && !(cov[u] + adj < min_cov_thr);
+        const uint32_t slot = compact_slot(keep, nmin);
+        if (keep) {
+          const uint32_t key = max_cover - cov[u];
+          kv[slot] = (key << WSORT_IDXBITS) | i;
+          atomic_add_u32(&hist[key < (uint32_t)WSORT_NBINS ? key : (uint32_t)WSORT_NBINS - 1], 1u);
+        }
       }
     }
   }
