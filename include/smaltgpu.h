@@ -136,8 +136,11 @@ int smaltgpu_set_debug(smaltgpu_mapper *m, int level);
 long smaltgpu_dump_read(smaltgpu_mapper *m, uint32_t i, const char *name, char *buf, size_t bufsiz);
 
 /* Stand-alone kernel entry points used by the parity tests (host pointers in, host out). */
+/* K2a (swsimd.c:868, un-banded score pass) over explicit 3-bit code arrays.  packed16 = 1: the kernel that scores two
+ * tasks per lane group in 16-bit halves (a task whose query holds non-ACGT codes reports -2: the mapper routes those
+ * to the 32-bit kernel); packed16 = 0: the 32-bit kernel.  -1: task too long for the register tiling. */
 int smaltgpu_sw_full_batch(smaltgpu_mapper *m, const uint8_t *qcodes, const uint32_t *q_off, const uint8_t *rcodes,
-                           const uint32_t *r_off, uint32_t ntask, const smaltgpu_params *par, int32_t *scores);
+                           const uint32_t *r_off, uint32_t ntask, const smaltgpu_params *par, int32_t *scores, int packed16);
 
 /* The candidate ranking sort of segAliCandsStats (segment.c:1733 -> sort.c:233): `narr` arrays of keys (< 1024), array t
  * in keys[off[t]..off[t+1]); returns the keys and the permutation (index into the array) in the reference's tie order

@@ -89,7 +89,7 @@ def lib():
         L.smaltgpu_dump_read.restype = C.c_long
         L.smaltgpu_dump_read.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_size_t]
         L.smaltgpu_sw_full_batch.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32), C.c_char_p,
-                                             C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(Params), C.POINTER(C.c_int32)]
+                                             C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(Params), C.POINTER(C.c_int32), C.c_int]
         L.smaltgpu_rank_sort_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -213,8 +213,9 @@ class Mapper:
         lib().smaltgpu_dump_read(self.h, i, name.encode(), buf, n + 1)
         return buf.value.decode()
 
-    def sw_full_batch(self, queries: Sequence[bytes], windows: Sequence[bytes], params: Params) -> List[int]:
-        """Stand-alone K2a over explicit 3-bit code arrays (bytes of codes 0..7)."""
+    def sw_full_batch(self, queries: Sequence[bytes], windows: Sequence[bytes], params: Params, packed16: bool = False) -> List[int]:
+        """Stand-alone K2a over explicit 3-bit code arrays (bytes of codes 0..7); packed16 selects the
+        two-tasks-per-lane-group 16-bit kernel (-2 for queries with non-ACGT codes)."""
         n = len(queries)
         qo = (C.c_uint32 * (n + 1))()
         ro = (C.c_uint32 * (n + 1))()
@@ -225,7 +226,7 @@ class Mapper:
             b += len(windows[i])
         qo[n], ro[n] = a, b
         sc = (C.c_int32 * n)()
-        _check(lib().smaltgpu_sw_full_batch(self.h, b"".join(queries), qo, b"".join(windows), ro, n, C.byref(params), sc))
+        _check(lib().smaltgpu_sw_full_batch(self.h, b"".join(queries), qo, b"".join(windows), ro, n, C.byref(params), sc, int(packed16)))
         return list(sc)
 
     def rank_sort_batch(self, arrays, nneed: int = -1, in_lds: bool = True):

@@ -489,7 +489,7 @@ extern "C" long smaltgpu_dump_read(smaltgpu_mapper *m, uint32_t i, const char *n
 }
 
 extern "C" int smaltgpu_sw_full_batch(smaltgpu_mapper *m, const uint8_t *qcodes, const uint32_t *q_off, const uint8_t *rcodes,
-                                       const uint32_t *r_off, uint32_t ntask, const smaltgpu_params *par, int32_t *scores) {
+                                       const uint32_t *r_off, uint32_t ntask, const smaltgpu_params *par, int32_t *scores, int packed16) {
   if (!m || !qcodes || !q_off || !rcodes || !r_off || !par || !scores) return fail(SMALTGPU_EARG, "null argument");
   HIPCHK(hipSetDevice(m->device));
   uint8_t *dq = nullptr, *dr = nullptr; uint32_t *dqo = nullptr, *dro = nullptr; int32_t *dsc = nullptr;
@@ -502,8 +502,8 @@ extern "C" int smaltgpu_sw_full_batch(smaltgpu_mapper *m, const uint8_t *qcodes,
     (void)hipMemcpy(dr, rcodes, r_off[ntask], hipMemcpyHostToDevice);
     (void)hipMemcpy(dqo, q_off, ((size_t)ntask + 1) * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(dro, r_off, ((size_t)ntask + 1) * 4, hipMemcpyHostToDevice);
-    int lr = launch_sw_full_raw(m->stream, dq, dqo, dr, dro, ntask, to_par(par), dsc, qmaxlen);
-    if (lr) rv = fail(SMALTGPU_EARG, "query longer than the register-tiled kernel supports");
+    int lr = launch_sw_full_raw(m->stream, dq, dqo, dr, dro, ntask, to_par(par), dsc, qmaxlen, packed16);
+    if (lr) rv = fail(SMALTGPU_EARG, lr == -2 ? "scores do not fit the packed 16-bit kernel" : "query longer than the register-tiled kernel supports");
     else if (hipStreamSynchronize(m->stream) != hipSuccess) rv = fail(SMALTGPU_ENODEV, "kernel failed");
     else (void)hipMemcpy(scores, dsc, (size_t)ntask * 4, hipMemcpyDeviceToHost);
   }

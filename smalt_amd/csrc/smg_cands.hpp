@@ -849,11 +849,16 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   ph[9] += ncand; ph[10] += nmin;
   // ---- S7 ----
   const uint32_t n_sort = ch.n_sort, rc_off = ch.rc_off;
+  bool qn = false;                          // reads with non-ACGT codes are scored in 32-bit lanes (k_sw_full)
+  SMG_PAR_CHUNKS(base, qlen) { const uint32_t i = base + SMG_LANE; if (i < qlen && b.codes[b.read_off[r] + i] >= 4) qn = true; }
+  qn = wave_any(qn);
+  SMG_LANE0 { if (qn && n_sort) (void)atomic_add_u64(b.work + WK_QN_TASKS, n_sort); }
   SMG_PAR_CHUNKS(base, n_sort) {
     uint32_t i = base + SMG_LANE;
     if (i < n_sort) {
       RCand c;
       if (cand_offsets(c, x.cand[x.sort_idx[i]], ix, qlen)) { c.flags |= RCF_ERR; c.rs = c.re = 0; c.qs = c.qe = 0; c.band_l = c.band_r = 0; }
+      if (qn) c.flags |= RCF_QN;
       c.rid = r; c.pad = 0;
       b.rcpool[rc_off + i] = c;
     }

@@ -31,7 +31,7 @@ int launch_sw_full(hipStream_t s, const Batch &b, const DevIndex &ix, const MapP
 int launch_sw_scalar(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, int *rows, uint32_t rowlen, uint32_t nthreads,
                      uint32_t qmax_len);
 int launch_sw_full_raw(hipStream_t s, const uint8_t *q, const uint32_t *qo, const uint8_t *r, const uint32_t *ro, uint32_t n,
-                       const MapPar &p, int32_t *sc, uint32_t qmax_len);
+                       const MapPar &p, int32_t *sc, uint32_t qmax_len, int packed16);
 int launch_rank_sort_raw(hipStream_t s, const uint32_t *keys, const uint32_t *off, uint32_t narr, int nneed, int in_lds, uint32_t *kv,
                          uint32_t *out_key, uint32_t *out_idx);
 

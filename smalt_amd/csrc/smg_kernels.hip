@@ -77,7 +77,10 @@ __global__ void __launch_bounds__(64) k_cands(Batch b, DevIndex ix, MapPar p, ui
 // O1: one thread per read
 __global__ void __launch_bounds__(256) k_replay(Batch b, DevIndex ix, MapPar p) {
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < b.nreads) stage_replay(b, ix, p, r);
+  if (r < b.nreads) {
+    stage_replay(b, ix, p, r);
+    atomicAdd(b.work + WK_CELLS_BAND, (unsigned long long)b.ctl[r].n_scored);     // candidates the reference would have scored
+  }
 }
 
 // K3: one wave per read; hot arrays in LDS, results and oversized direction matrices in the HBM slot
@@ -112,7 +115,9 @@ __device__ inline int shr1(int v) {          // value of the lane to the left in
 }
 
 template <int G, int C>
-__global__ void __launch_bounds__(64) k_sw_full(Batch b, DevIndex ix, MapPar p, uint32_t ntask_cap) {
+__global__ void __launch_bounds__(64) k_sw_full(Batch b, DevIndex ix, MapPar p, uint32_t ntask_cap, int after16) {
+  // after16: the packed 16-bit kernel ran first; what is left are the candidates of reads with non-ACGT codes
+  if (after16 && b.work[WK_QN_TASKS] == 0) return;
   constexpr int NG = 64 / G;                 // tasks in flight per wave
   constexpr int WMAX = SW_FULL_WMAX;         // longest window handled here
   __shared__ uint8_t win[NG][WMAX + 8];
@@ -143,7 +148,7 @@ __global__ void __launch_bounds__(64) k_sw_full(Batch b, DevIndex ix, MapPar p, 
       c = b.rcpool[t];
       qlen = read_len(b, c.rid);
       wlen = (uint32_t)(c.re - c.rs + 1);
-      live = !(c.flags & (RCF_BANDED | RCF_ERR)) && wlen <= (uint32_t)WMAX && qlen <= (uint32_t)(G * C);
+      live = !(c.flags & (RCF_BANDED | RCF_ERR | RCF_SCORED)) && wlen <= (uint32_t)WMAX && qlen <= (uint32_t)(G * C);
       gbase = (c.sqidx < 0 ? 0ull : ix.sop[c.sqidx]) + c.rs;
     }
     if (!live) { qlen = 0; wlen = 0; }
@@ -202,6 +207,212 @@ __global__ void __launch_bounds__(64) k_sw_full(Batch b, DevIndex ix, MapPar p, 
   }
   for (int o = 32; o > 0; o >>= 1) { cells += __shfl_xor(cells, o); ntasks_done += __shfl_xor(ntasks_done, o); }
   if (lane == 0 && cells) { atomicAdd(b.work + WK_CELLS_FULL, cells); atomicAdd(b.work + WK_TASKS_FULL, ntasks_done); }
+}
+
+// ---------------------------------------------------------------------------------------
+// K2a, two tasks per lane group in packed 16-bit halves (v_pk_*_u16).
+//
+// Same tiling as k_sw_full; every register holds the cell of task A in its low half and the cell of
+// task B (the next ranked candidate) in its high half.  All quantities are kept non-negative and
+// subtractions saturate at 0, which is the recurrence of the 32-bit kernel with its max(.., 0)
+// folded into the subtract: H = max(sat(Hdiag + (w + bias) - bias), E, F), E = max(sat(E - ge),
+// sat(H - gi)).  One v_perm_b32 yields both substitution scores from an 8-byte source holding the
+// ACGT row of either task (selector bytes {qA, 0x0c, 4 + qB, 0x0c}).  That leaves no byte for a
+// query 'N' (score 0), so reads with non-ACGT codes stay with the 32-bit kernel (RCF_QN); columns
+// beyond the read take the constant 0 (score -bias <= 0) and rows beyond the window an all-'N' row,
+// neither of which can raise a maximum.  Requires match * 512 + bias < 65535 (checked by the launcher).
+// ---------------------------------------------------------------------------------------
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ inline us2 as_us2(uint32_t v) { return __builtin_bit_cast(us2, v); }
+__device__ inline uint32_t as_u32(us2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ inline us2 pk_max(us2 a, us2 b) { return __builtin_elementwise_max(a, b); }
+__device__ inline us2 pk_subs(us2 a, us2 b) { return __builtin_elementwise_sub_sat(a, b); }
+__device__ inline uint32_t shr1_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, true); }
+
+struct Sw16Par { uint32_t mm4, dlt, n4; us2 bias, gi, ge; };
+__device__ inline Sw16Par sw16_par(const MapPar &p) {
+  Sw16Par s;
+  const int bias = (p.mismatch < p.mismatch - p.match ? -p.mismatch : -(p.mismatch - p.match));
+  s.mm4 = (uint32_t)((p.mismatch + bias) & 0xff) * 0x01010101u;      // a row of mismatches ...
+  s.dlt = (uint32_t)(p.match - p.mismatch);                          // ... plus this at the byte of the matching base
+  s.n4 = (uint32_t)(bias & 0xff) * 0x01010101u;                      // reference 'N': score 0 against everything
+  s.bias = us2{(unsigned short)bias, (unsigned short)bias};
+  s.gi = us2{(unsigned short)(-p.gap_init), (unsigned short)(-p.gap_init)};
+  s.ge = us2{(unsigned short)(-p.gap_ext), (unsigned short)(-p.gap_ext)};
+  return s;
+}
+
+// wrow: per-row code pairs (low byte task A, high byte task B) of this lane group, nrow valid rows
+template <int G, int C>
+__device__ inline uint32_t sw16_core(const uint16_t *wrow, int nrow, int nstep, const uint32_t (&sel)[C], int g, const Sw16Par &sp, const uint32_t *rowtab) {
+  us2 H[C], E[C];
+#pragma unroll
+  for (int cc = 0; cc < C; cc++) { H[cc] = us2{0, 0}; E[cc] = us2{0, 0}; }
+  us2 best = us2{0, 0}, F = us2{0, 0}, prev_hl = us2{0, 0};
+  const uint32_t gmask = g == 0 ? 0u : 0xffffffffu;       // the first lane of a group has no left neighbour
+  for (int step = 0; step < nstep; step++) {
+    const int row = step - g;
+    const uint32_t rp = (row >= 0 && row < nrow) ? wrow[row] : 0x0505u;
+    const uint32_t rowA = rowtab[rp & 0xffu], rowB = rowtab[rp >> 8];     // ACGT scores (+ bias) against this reference base
+    const uint32_t hl = shr1_u32(as_u32(H[C - 1])) & gmask;
+    const uint32_t fin = shr1_u32(as_u32(F)) & gmask;
+    us2 diag = prev_hl;
+    prev_hl = as_us2(hl);
+    F = as_us2(fin);
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) {
+      const us2 w = as_us2(__builtin_amdgcn_perm(rowB, rowA, sel[cc]));
+      const us2 h = pk_subs(diag + w, sp.bias);
+      const us2 hh = pk_max(pk_max(h, E[cc]), F);
+      best = pk_max(best, hh);
+      diag = H[cc];
+      H[cc] = hh;
+      const us2 tt = pk_subs(hh, sp.gi);
+      E[cc] = pk_max(pk_subs(E[cc], sp.ge), tt);
+      F = pk_max(pk_subs(F, sp.ge), tt);
+    }
+  }
+  uint32_t bb = as_u32(best);
+  for (int o = G / 2; o > 0; o >>= 1) bb = as_u32(pk_max(as_us2(bb), as_us2((uint32_t)__shfl_xor((int)bb, o))));
+  return bb;
+}
+
+// rowtab[code]: the four biased ACGT scores against reference code 0..7 (4, 5, 6: 'N' -> score 0; 7 decodes as A upstream)
+__device__ inline void sw16_rowtab(uint32_t *rowtab, const Sw16Par &sp) {
+  if (threadIdx.x < 8) rowtab[threadIdx.x] = threadIdx.x < 4 ? sp.mm4 + (sp.dlt << (8 * threadIdx.x)) : sp.n4;
+}
+
+template <int G, int C>
+__global__ void __launch_bounds__(64) k_sw_full16(Batch b, DevIndex ix, MapPar p, uint32_t ntask_cap) {
+  constexpr int NG = 64 / G;
+  constexpr int WMAX = SW_FULL_WMAX;
+  __shared__ uint16_t win[NG][WMAX + 8];
+  __shared__ uint32_t rowtab[8];
+  const int lane = threadIdx.x, g = lane % G, grp = lane / G;
+  const uint32_t ntask = min(*b.rc_count, ntask_cap), npair = (ntask + 1) / 2;
+  const Sw16Par sp = sw16_par(p);
+  sw16_rowtab(rowtab, sp);
+  const uint32_t ngroups = gridDim.x * NG;
+  unsigned long long cells = 0, ntasks_done = 0;
+  for (uint32_t t0 = blockIdx.x * NG; t0 < npair; t0 += ngroups) {
+    const uint32_t tp = t0 + grp;
+    RCand c[2];
+    bool live[2] = {false, false};
+    uint32_t qlen[2] = {0, 0}, wlen[2] = {0, 0};
+    uint64_t gbase[2] = {0, 0};
+    const uint8_t *q[2] = {b.codes, b.codes};
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const uint32_t t = 2 * tp + (uint32_t)u;
+      if (tp < npair && t < ntask) {
+        c[u] = b.rcpool[t];
+        qlen[u] = read_len(b, c[u].rid);
+        wlen[u] = (uint32_t)(c[u].re - c[u].rs + 1);
+        live[u] = !(c[u].flags & (RCF_BANDED | RCF_ERR | RCF_QN)) && wlen[u] <= (uint32_t)WMAX && qlen[u] <= (uint32_t)(G * C);
+        gbase[u] = (c[u].sqidx < 0 ? 0ull : ix.sop[c[u].sqidx]) + c[u].rs;
+        q[u] = ((c[u].flags & RCF_REVERSE) ? b.codes_rc : b.codes) + b.read_off[c[u].rid];
+      }
+      if (!live[u]) { qlen[u] = 0; wlen[u] = 0; }
+    }
+    const uint32_t wmax = wlen[0] > wlen[1] ? wlen[0] : wlen[1];
+    for (uint32_t i = g; i < wmax; i += G) {
+      const uint32_t a = i < wlen[0] ? ref_code(ix.packed, gbase[0] + i) : 5u, bb = i < wlen[1] ? ref_code(ix.packed, gbase[1] + i) : 5u;
+      win[grp][i] = (uint16_t)(a | (bb << 8));
+    }
+    uint32_t sel[C];
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) {
+      const uint32_t j = (uint32_t)(g * C + cc);
+      const uint32_t sa = j < qlen[0] ? (uint32_t)q[0][j] : 0x0cu, sb = j < qlen[1] ? 4u + (uint32_t)q[1][j] : 0x0cu;
+      sel[cc] = 0x0c000c00u | sa | (sb << 16);
+    }
+    int nstep = (int)wmax + G - 1;
+    for (int o = 32; o > 0; o >>= 1) nstep = max(nstep, __shfl_xor(nstep, o));
+    __syncthreads();
+    const uint32_t bb = sw16_core<G, C>(win[grp], (int)wmax, nstep, sel, g, sp, rowtab);
+    if (g == 0) {
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if (live[u]) {
+          const int best = (int)((bb >> (16 * u)) & 0xffffu);
+          const uint32_t t = 2 * tp + (uint32_t)u;
+          b.rcpool[t].swscor = best;
+          b.rcpool[t].flags = c[u].flags | RCF_SCORED | (best >= 65535 ? RCF_BANDED : 0u);   // ERRCODE_SWATEXCEED -> K2b
+          cells += (unsigned long long)qlen[u] * wlen[u];
+          ntasks_done++;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int o = 32; o > 0; o >>= 1) { cells += __shfl_xor(cells, o); ntasks_done += __shfl_xor(ntasks_done, o); }
+  if (lane == 0 && cells) { atomicAdd(b.work + WK_CELLS_FULL, cells); atomicAdd(b.work + WK_TASKS_FULL, ntasks_done); }
+}
+
+// stand-alone form over explicit code arrays (tasks with non-ACGT query codes report -2: not handled here)
+template <int G, int C>
+__global__ void __launch_bounds__(64) k_sw_full16_raw(const uint8_t *qcodes, const uint32_t *q_off, const uint8_t *rcodes,
+                                                       const uint32_t *r_off, uint32_t ntask, MapPar p, int32_t *scores) {
+  constexpr int NG = 64 / G;
+  constexpr int WMAX = SW_FULL_WMAX;
+  __shared__ uint16_t win[NG][WMAX + 8];
+  __shared__ uint32_t rowtab[8];
+  const int lane = threadIdx.x, g = lane % G, grp = lane / G;
+  const uint32_t npair = (ntask + 1) / 2;
+  const Sw16Par sp = sw16_par(p);
+  sw16_rowtab(rowtab, sp);
+  const uint32_t ngroups = gridDim.x * NG;
+  for (uint32_t t0 = blockIdx.x * NG; t0 < npair; t0 += ngroups) {
+    const uint32_t tp = t0 + grp;
+    bool live[2] = {false, false};
+    uint32_t qlen[2] = {0, 0}, wlen[2] = {0, 0};
+    const uint8_t *q[2] = {qcodes, qcodes}, *r[2] = {rcodes, rcodes};
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const uint32_t t = 2 * tp + (uint32_t)u;
+      if (tp < npair && t < ntask) {
+        qlen[u] = q_off[t + 1] - q_off[t]; wlen[u] = r_off[t + 1] - r_off[t];
+        q[u] += q_off[t]; r[u] += r_off[t];
+        live[u] = wlen[u] <= (uint32_t)WMAX && qlen[u] <= (uint32_t)(G * C);
+      }
+      if (!live[u]) { qlen[u] = 0; wlen[u] = 0; }
+    }
+    const uint32_t wmax = wlen[0] > wlen[1] ? wlen[0] : wlen[1];
+    for (uint32_t i = g; i < wmax; i += G) {
+      uint32_t cd[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) { const uint32_t x = i < wlen[u] ? (r[u][i] & 7u) : 5u; cd[u] = x == 7 ? 0 : ((x == 6 || x == 4) ? 5 : x); }
+      win[grp][i] = (uint16_t)(cd[0] | (cd[1] << 8));
+    }
+    uint32_t sel[C];
+    bool qn[2] = {false, false};
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) {
+      const uint32_t j = (uint32_t)(g * C + cc);
+      uint32_t s2[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const uint32_t qc = j < qlen[u] ? (q[u][j] & 7u) : 0x0cu;
+        if (j < qlen[u] && qc >= 4) qn[u] = true;
+        s2[u] = qc == 0x0cu ? 0x0cu : (uint32_t)(4 * u) + (qc & 3u);
+      }
+      sel[cc] = 0x0c000c00u | s2[0] | (s2[1] << 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) for (int o = G / 2; o > 0; o >>= 1) { const int other = __shfl_xor((int)qn[u], o); qn[u] = qn[u] || other != 0; }
+    int nstep = (int)wmax + G - 1;
+    for (int o = 32; o > 0; o >>= 1) nstep = max(nstep, __shfl_xor(nstep, o));
+    __syncthreads();
+    const uint32_t bb = sw16_core<G, C>(win[grp], (int)wmax, nstep, sel, g, sp, rowtab);
+    if (g == 0) {
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const uint32_t t = 2 * tp + (uint32_t)u;
+        if (tp < npair && t < ntask) scores[t] = !live[u] ? -1 : (qn[u] ? -2 : (int)((bb >> (16 * u)) & 0xffffu));
+      }
+    }
+    __syncthreads();
+  }
 }
 
 // K2a for tasks the register-tiled kernel does not cover (long reads / long windows) and
@@ -371,9 +582,18 @@ int sw_full_geometry(uint32_t qmax_len, int *G, int *C) {
   return 0;
 }
 
+// the packed kernel's 16-bit lanes hold any score of a read of up to 512 bases
+static bool sw16_ok(const MapPar &p) {
+  const int bias = (p.mismatch < p.mismatch - p.match ? -p.mismatch : -(p.mismatch - p.match));
+  return p.match > 0 && p.match * 512 + bias < 60000 && bias >= 0 && p.match + bias < 256 && p.mismatch + bias >= 0 &&
+         -p.gap_init >= 0 && -p.gap_init < 30000 && -p.gap_ext >= 0 && -p.gap_ext < 30000;
+}
+
 template <int G, int C>
 static void launch_sw_full_t(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t ntask_cap, uint32_t grid) {
-  hipLaunchKernelGGL((k_sw_full<G, C>), dim3(grid), dim3(64), 0, s, b, ix, p, ntask_cap);
+  const int use16 = sw16_ok(p);
+  if (use16) hipLaunchKernelGGL((k_sw_full16<G, C>), dim3(grid), dim3(64), 0, s, b, ix, p, ntask_cap);
+  hipLaunchKernelGGL((k_sw_full<G, C>), dim3(grid), dim3(64), 0, s, b, ix, p, ntask_cap, use16);
 }
 
 int launch_sw_full(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t qmax_len, uint32_t ntask_cap, uint32_t grid) {
@@ -399,8 +619,9 @@ int launch_sw_scalar(hipStream_t s, const Batch &b, const DevIndex &ix, const Ma
 
 template <int G, int C>
 static void launch_sw_raw_t(hipStream_t s, const uint8_t *q, const uint32_t *qo, const uint8_t *r, const uint32_t *ro, uint32_t n,
-                            const MapPar &p, int32_t *sc, uint32_t grid) {
-  hipLaunchKernelGGL((k_sw_full_raw<G, C>), dim3(grid), dim3(64), 0, s, q, qo, r, ro, n, p, sc);
+                            const MapPar &p, int32_t *sc, uint32_t grid, int packed16) {
+  if (packed16) hipLaunchKernelGGL((k_sw_full16_raw<G, C>), dim3(grid), dim3(64), 0, s, q, qo, r, ro, n, p, sc);
+  else hipLaunchKernelGGL((k_sw_full_raw<G, C>), dim3(grid), dim3(64), 0, s, q, qo, r, ro, n, p, sc);
 }
 
 // test entry of the candidate ranking sort (smg_wsort.hpp): one wave per array of keys
@@ -429,17 +650,18 @@ int launch_rank_sort_raw(hipStream_t s, const uint32_t *keys, const uint32_t *of
 }
 
 int launch_sw_full_raw(hipStream_t s, const uint8_t *q, const uint32_t *qo, const uint8_t *r, const uint32_t *ro, uint32_t n,
-                       const MapPar &p, int32_t *sc, uint32_t qmax_len) {
+                       const MapPar &p, int32_t *sc, uint32_t qmax_len, int packed16) {
   int G, C;
   if (!n) return 0;
   if (sw_full_geometry(qmax_len, &G, &C)) return -1;
+  if (packed16 && !sw16_ok(p)) return -2;
   uint32_t grid = (n + (64 / G) - 1) / (64 / G);
   if (grid > 8192) grid = 8192;
-  if (G == 4) launch_sw_raw_t<4, 16>(s, q, qo, r, ro, n, p, sc, grid);
-  else if (G == 8 && C == 13) launch_sw_raw_t<8, 13>(s, q, qo, r, ro, n, p, sc, grid);
-  else if (G == 8) launch_sw_raw_t<8, 20>(s, q, qo, r, ro, n, p, sc, grid);
-  else if (C == 16) launch_sw_raw_t<16, 16>(s, q, qo, r, ro, n, p, sc, grid);
-  else launch_sw_raw_t<16, 32>(s, q, qo, r, ro, n, p, sc, grid);
+  if (G == 4) launch_sw_raw_t<4, 16>(s, q, qo, r, ro, n, p, sc, grid, packed16);
+  else if (G == 8 && C == 13) launch_sw_raw_t<8, 13>(s, q, qo, r, ro, n, p, sc, grid, packed16);
+  else if (G == 8) launch_sw_raw_t<8, 20>(s, q, qo, r, ro, n, p, sc, grid, packed16);
+  else if (C == 16) launch_sw_raw_t<16, 16>(s, q, qo, r, ro, n, p, sc, grid, packed16);
+  else launch_sw_raw_t<16, 32>(s, q, qo, r, ro, n, p, sc, grid, packed16);
   SMG_LAUNCH_CHECK();
   return 0;
 }

@@ -37,6 +37,7 @@ struct Batch {                          // one block of reads resident in HBM
   unsigned long long *work;             // [WK_NWORK] work counters (WK_*), one atomic per workgroup
 };
 enum : int { WK_LOOKUPS = 0, WK_HITS = 1, WK_CELLS_FULL = 2, WK_TASKS_FULL = 3, WK_CELLS_BAND = 4, WK_NCAND = 5, WK_NKEPT = 6,
+              WK_QN_TASKS = 7 /* ranked candidates of reads with non-ACGT codes */,
               WK_PHASE0 = 8 /* .. 23: shader-clock ticks per phase of k_cands (diagnostic) */, WK_NWORK = 24 };
 
 SMG_HD inline uint32_t read_len(const Batch &b, uint32_t r) { return (uint32_t)(b.read_off[r + 1] - b.read_off[r]); }
@@ -475,11 +476,16 @@ SMG_HD inline uint32_t stage_cands(const Batch &b, const DevIndex &ix, const Map
   SMG_SYNC();
   // ---- S7: windows and bands of the ranked candidates ----
   const uint32_t n_sort = ch.n_sort, rc_off = ch.rc_off;
+  bool qn = false;                          // reads with non-ACGT codes are scored in 32-bit lanes (k_sw_full)
+  SMG_PAR_CHUNKS(base, qlen) { const uint32_t i = base + SMG_LANE; if (i < qlen && b.codes[b.read_off[r] + i] >= 4) qn = true; }
+  qn = wave_any(qn);
+  SMG_LANE0 { if (qn && n_sort) (void)atomic_add_u64(b.work + WK_QN_TASKS, n_sort); }
   SMG_PAR_CHUNKS(base, n_sort) {
     uint32_t i = base + SMG_LANE;
     if (i < n_sort) {
       RCand c;
       if (cand_offsets(c, x.cand[x.sort_idx[i]], ix, qlen)) { c.flags |= RCF_ERR; c.rs = c.re = 0; c.qs = c.qe = 0; c.band_l = c.band_r = 0; }
+      if (qn) c.flags |= RCF_QN;
       c.rid = r; c.pad = 0;
       b.rcpool[rc_off + i] = c;
     }

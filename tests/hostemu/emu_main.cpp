@@ -99,6 +99,8 @@ int main(int argc, char **argv) {
   b.hi = hi.data(); b.seeds = seeds.data(); b.qmask = qmask.data(); b.ch = ch.data(); b.rcpool = rcpool.data(); b.rccap = rccap;
   b.rc_count = &rc_count; b.ctl = ctl.data(); b.stat = stat.data(); b.respool = respool.data(); b.rescap = respool.size();
   b.res_count = &res_count; b.dstrpool = dstrpool.data(); b.dstrcap = dstrpool.size(); b.dstr_count = &dstr_count; b.err_flag = &err_flag;
+  unsigned long long workctr[WK_NWORK] = {0};
+  b.work = workctr;
 
   std::vector<uint8_t> sscr(seed_scratch_bytes(qmax, ix.s));
   const uint32_t hcap = 1u << 16, segcap = 1u << 15, candcap = 1u << 16;

@@ -57,9 +57,14 @@ def test_sw_full_kernel_matches_oracle(qlo, qhi, oracle_built):
         for with_n in (False, True):
             qs, ws = _pairs(rng, 700, qlo, qhi, with_n)
             got = mp.sw_full_batch(qs, ws, par)
+            got16 = mp.sw_full_batch(qs, ws, par, packed16=True)
             for i, (q, w) in enumerate(zip(qs, ws)):
                 exp = ol.lib().or_sw_full(q, len(q), w, len(w), M, -4, -3)
                 assert got[i] == exp, (i, len(q), len(w), got[i], exp)
+                if any(c >= 4 for c in q):
+                    assert got16[i] == -2, (i, got16[i])       # non-ACGT query: left to the 32-bit kernel
+                else:
+                    assert got16[i] == exp, (i, len(q), len(w), got16[i], exp)
     finally:
         mp.close()
         gix.close()
