@@ -25,9 +25,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12     # int32 lane-ops/s: 256 CU x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md)
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12     # lane-ops/s: 256 CU x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md); a packed 16-bit
+                                                  # instruction issues every 4 cycles for 64 lanes x 2 halves = the same 32 cell-ops/clk/SIMD
 HBM_PEAK_GBS = 8000.0
-OPS_PER_CELL = 12                                 # integer VALU ops per Gotoh cell
+OPS_PER_CELL = 11                                 # VALU ops per Gotoh cell of the packed kernel: 11 instructions per cell pair,
+                                                  # each instruction counting as 2 cell-ops
 
 
 def parse_args():
@@ -244,7 +246,7 @@ def main():
         line = {
             "metric": "mapped reads/sec (1Mx150bp vs 3Gbp ref)", "value": value, "unit": "mapped reads/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "config": {"workload": "configs[1]: %d x %d bp single-end reads per GPU vs %d x %.0f Mbp synthetic reference (15%% repeats), k=%d s=%d, best-only"
                        % (args.reads, args.read_len, nchr, args.chr_mbp, k, s),
                        "reads_per_gpu_per_step": args.reads, "sub_batch": sub, "mapped_fraction": mapped_all / (world * args.steps * args.reads),
