@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--sub-batch", type=int, default=131072)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-buffers", action="store_true", help="also time smaltgpu_map_batch on pageable host buffers (PCIe-inclusive rate, extra field)")
     ap.add_argument("--cpu-sample", type=int, default=150000)
     return ap.parse_args()
 
@@ -111,7 +112,7 @@ def main():
     args = parse_args()
     import torch
     import torch.distributed as dist
-    from smalt_amd import api, gpuindex
+    from smalt_amd import api, gpuindex, shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -132,27 +133,15 @@ def main():
 
     # ---- setup (untimed): reference + index image in HBM; rank 0 builds, RCCL broadcast ----
     t0 = time.time()
+    image = {}
     if rank == 0:
         ref = gpuindex.make_reference_gpu(nchr, chrlen, 20261004, dev)
         packed = gpuindex.pack_reference(ref)
         idx, pos = gpuindex.build_perfect_index(ref, sop, k, s)
-        npos = torch.tensor([pos.numel()], dtype=torch.int64, device=dev)
-    else:
-        ref = torch.empty(tot, dtype=torch.uint8, device=dev)
-        packed = torch.empty(tot // 10 + 1, dtype=torch.int32, device=dev)
-        idx = torch.empty(4 ** k + 1, dtype=torch.int32, device=dev)
-        npos = torch.zeros(1, dtype=torch.int64, device=dev)
-    bcast_ms = 0.0
-    if world > 1:
-        dist.broadcast(npos, 0)
-        if rank != 0:
-            pos = torch.empty(int(npos.item()), dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
-        tb = time.time()
-        for tns in (idx, pos, packed, ref):
-            dist.broadcast(tns, 0)
-        torch.cuda.synchronize()
-        bcast_ms = (time.time() - tb) * 1e3
+        image = {"idx": idx, "pos": pos, "packed": packed, "ref": ref}
+    image, bcast_s = shard.broadcast_image(image, dev, 0, order=("idx", "pos", "packed", "ref"))     # RCCL over xGMI for N > 1
+    idx, pos, packed, ref = image["idx"], image["pos"], image["packed"], image["ref"]
+    bcast_ms = bcast_s * 1e3
     # reads of this rank (weak scaling: every rank maps args.reads reads of its own)
     torch.cuda.synchronize()
     t_idx = time.time() - t0
@@ -219,13 +208,7 @@ def main():
         mapped += m_
     barrier()
     dt = time.time() - t1
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    mp_t = torch.tensor([mapped], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(mp_t, op=dist.ReduceOp.SUM)
-    dt = float(tmax.item())
-    mapped_all = float(mp_t.item())
+    dt, (mapped_all,) = shard.reduce_step(dt, [mapped], dev)      # max over ranks, whole-job count
 
     if rank == 0:
         value = mapped_all / dt
@@ -263,6 +246,13 @@ def main():
             "ranked_per_read": work_acc[3] / max(1, world * args.steps * args.reads), "scored_in_reference_order_per_read": work_acc[4] / max(1, world * args.steps * args.reads),
             "hits_per_read": work_acc[1] / max(1, world * args.steps * args.reads),
         }
+        if args.host_buffers:       # the boundary's host-buffer entry point: H2D of the reads + D2H of the results inside the timing
+            hb = reads_ascii[:sub * args.read_len].cpu().numpy()
+            ho = (np.arange(sub + 1, dtype=np.uint64) * np.uint64(args.read_len))
+            mapper.map_batch_raw(hb, ho, None, par)
+            th = time.time()
+            mapper.map_batch_raw(hb, ho, None, par)
+            line["host_buffers"] = {"reads_per_s": sub / (time.time() - th), "reads": sub, "note": "PCIe-inclusive, not `value`"}
         if not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args, packed.cpu().numpy(), idx.cpu().numpy(), pos.cpu().numpy(), sop, names, k, s,

@@ -172,6 +172,14 @@ class Mapper:
         _check(lib().smaltgpu_map_batch(self.h, bases, q, off, len(reads), C.byref(params), C.byref(out)))
         return self._unpack(out)
 
+    def map_batch_raw(self, bases, off, quals, params: Params) -> BatchOut:
+        """smaltgpu_map_batch on contiguous host arrays (numpy uint8 bases / uint64 offsets); the returned
+        views stay valid until the next call on this mapper."""
+        out = BatchOut()
+        _check(lib().smaltgpu_map_batch(self.h, C.cast(bases.ctypes.data, C.c_char_p), None if quals is None else C.cast(quals.ctypes.data, C.c_char_p),
+                                        C.cast(off.ctypes.data, C.POINTER(C.c_uint64)), len(off) - 1, C.byref(params), C.byref(out)))
+        return out
+
     @staticmethod
     def _unpack(out: BatchOut):
         res, stats = [], []

@@ -1,0 +1,86 @@
+"""Multi-GPU plumbing of the read-mapping hot path: one process per GPU, reads sharded, no data-path
+collective.
+
+The reference parallelises `smalt map -n T` with threads that pull read blocks from one queue and
+share one read-only index (threads.c / rmap.c:1480-1560).  The MI355X form is
+one process per GPU: the index image is built (or loaded) once on rank 0 and broadcast over
+RCCL/xGMI, after which every rank maps its own contiguous shard of the reads; per-read results are
+independent, so ranks only meet again to reduce the step statistics.  With `backend="gloo"` the same
+code runs on CPU tensors (tests/test_shard_gloo.py).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Sequence, Tuple
+
+
+def env_world() -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from the torch.distributed.run environment."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of `n_items` reads for `rank`: sizes differ by at most one and the
+    shards tile the input in rank order (so concatenating per-rank outputs restores the read order)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def broadcast_image(tensors: Dict[str, "object"], device, src: int = 0, order: Sequence[str] = ()):  # noqa: F821
+    """Broadcast the index image (dict name -> tensor on rank `src`, anything elsewhere) to all ranks.
+    Shapes and dtypes travel first (one int64 tensor), then each array in one collective.  Returns
+    (dict name -> tensor on `device`, seconds spent in the data broadcasts)."""
+    import time
+
+    import torch
+    import torch.distributed as dist
+    names = list(order) or sorted(tensors.keys())
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return {n: tensors[n] for n in names}, 0.0
+    rank = dist.get_rank()
+    dtypes = [torch.uint8, torch.int32, torch.int64, torch.uint32] if hasattr(torch, "uint32") else [torch.uint8, torch.int32, torch.int64]
+    meta = torch.zeros(2 * len(names), dtype=torch.int64, device=device)
+    if rank == src:
+        for i, n in enumerate(names):
+            t = tensors[n]
+            assert t.dim() == 1 and t.dtype in dtypes, (n, t.dtype, t.shape)
+            meta[2 * i] = t.numel()
+            meta[2 * i + 1] = dtypes.index(t.dtype)
+    dist.broadcast(meta, src)
+    m = meta.cpu().tolist()
+    out = {}
+    sync = torch.cuda.synchronize if getattr(device, "type", str(device)) == "cuda" else (lambda: None)
+    sync()
+    t0 = time.time()
+    for i, n in enumerate(names):
+        t = tensors[n] if rank == src else torch.empty(int(m[2 * i]), dtype=dtypes[int(m[2 * i + 1])], device=device)
+        dist.broadcast(t, src)
+        out[n] = t
+    sync()
+    return out, time.time() - t0
+
+
+def reduce_step(dt: float, counts: Sequence[float], device) -> Tuple[float, List[float]]:
+    """Max of the step time over ranks and the sum of the per-rank counters (bench.py contract)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return dt, list(counts)
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    c = torch.tensor(list(counts), dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    return float(t.item()), [float(x) for x in c.cpu().tolist()]
+
+
+def gather_in_rank_order(obj):
+    """All ranks' per-shard result objects, in rank order (a list of length world on every rank)."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
