@@ -244,7 +244,7 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
     m->cg.slot_bytes = m->cand_bytes = cand_slot_bytes(m->cg, m->qmax, d.s);
     uint64_t budget = 24ull << 30;
     uint64_t slots = budget / m->cand_bytes;
-    if (slots > 1024) slots = 1024;                     // LDS admits 3 workgroups per CU: 768 run at a time
+    if (slots > 1536) slots = 1536;                     // LDS admits 4 workgroups per CU: 1024 run at a time
     if (slots < 64) slots = 64;
     if (slots > max_batch_reads) slots = max_batch_reads;
     m->cand_slots = (uint32_t)slots;

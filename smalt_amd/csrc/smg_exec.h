@@ -97,23 +97,30 @@ SMG_HD inline uint32_t bcast_lane0(uint32_t v) {
 #endif
 }
 
-// In-place ascending sort of n 64-bit keys by the whole wave (n need not be a power of two;
-// the caller provides capacity for the next power of two, padded here with ~0).
+// In-place ascending sort of n 64-bit keys by the whole wave: bitonic network in its normalised form (every
+// comparator puts the smaller key at the lower index: the first step of a merge pairs i with its mirror
+// image in the block, the others pair i with i + j).  Keys beyond n are virtual +inf: a comparator that
+// touches one never swaps, so no padding is stored and only comparators below n are visited.
 SMG_HD inline void wave_sort_u64(uint64_t *a, uint32_t n) {
   if (n < 2) return;
 #if defined(__HIP_DEVICE_COMPILE__)
   uint32_t np = 1;
   while (np < n) np <<= 1;
-  for (uint32_t i = n + SMG_LANE; i < np; i += SMG_NLANES) a[i] = ~0ull;
-  SMG_SYNC();
   for (uint32_t k = 2; k <= np; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t t = SMG_LANE; t < (np >> 1); t += SMG_NLANES) {
-        uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // index with bit j clear
-        uint32_t p = i | j;
-        uint64_t x = a[i], y = a[p];
-        bool up = ((i & k) == 0);
-        if ((x > y) == up) { a[i] = y; a[p] = x; }
+    const uint32_t h = k >> 1;
+    {                                                           // mirror step
+      const uint32_t tmax = (n / k) * h + ((n % k) < h ? (n % k) : h);
+      for (uint32_t t = SMG_LANE; t < tmax; t += SMG_NLANES) {
+        const uint32_t blk = t / h, off = t % h, i = blk * k + off, p = blk * k + (k - 1 - off);
+        if (p < n) { const uint64_t x = a[i], y = a[p]; if (x > y) { a[i] = y; a[p] = x; } }
+      }
+      SMG_SYNC();
+    }
+    for (uint32_t j = h >> 1; j > 0; j >>= 1) {
+      const uint32_t tmax = (n / (2 * j)) * j + ((n % (2 * j)) < j ? (n % (2 * j)) : j);
+      for (uint32_t t = SMG_LANE; t < tmax; t += SMG_NLANES) {
+        const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+        if (p < n) { const uint64_t x = a[i], y = a[p]; if (x > y) { a[i] = y; a[p] = x; } }
       }
       SMG_SYNC();
     }
