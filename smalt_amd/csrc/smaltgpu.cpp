@@ -244,7 +244,7 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
     m->cg.slot_bytes = m->cand_bytes = cand_slot_bytes(m->cg, m->qmax, d.s);
     uint64_t budget = 24ull << 30;
     uint64_t slots = budget / m->cand_bytes;
-    if (slots > 1536) slots = 1536;                     // LDS admits 4 workgroups per CU: 1024 run at a time
+    if (slots > 2048) slots = 2048;                     // LDS admits 4 workgroups per CU: 1024 run at a time
     if (slots < 64) slots = 64;
     if (slots > max_batch_reads) slots = max_batch_reads;
     m->cand_slots = (uint32_t)slots;
@@ -257,9 +257,9 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
     m->dircap = (uint64_t)(m->qmax + 64) * (m->wincap + 8);
     m->rescap_slot = 512; m->dstrcap_slot = 512 * (m->qmax / 4 + 48);
     m->align_bytes = align_scratch_bytes(m->qmax, m->wincap, m->dircap, m->rescap_slot, m->dstrcap_slot);
-    uint64_t budget = 4ull << 30;
+    uint64_t budget = 8ull << 30;
     uint64_t slots = budget / m->align_bytes;
-    if (slots > 2048) slots = 2048;
+    if (slots > 8192) slots = 8192;
     if (slots < 16) slots = 16;
     if (slots > max_batch_reads) slots = max_batch_reads;
     m->align_slots = (uint32_t)slots;

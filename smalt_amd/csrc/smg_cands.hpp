@@ -20,7 +20,7 @@
 
 namespace smg {
 
-enum : uint32_t { CANDS_LDS_HITS = 1280,       // hits of the LDS working set (one strand, or one window of a strand)
+enum : uint32_t { CANDS_LDS_HITS = 1152,       // hits of the LDS working set (one strand, or one window of a strand)
                   CANDS_TAB = 264,             // per-list tables: a read of the wave-parallel form has <= 256 seeds
                   CANDS_TAB_BYTES = 5 * CANDS_TAB * 4 };
 enum : int { SMG_WINDOW_FALLBACK = 1000 };      // internal: a hit region does not fit a window

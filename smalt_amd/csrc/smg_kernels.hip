@@ -1,6 +1,7 @@
 // smg_kernels.hip -- gfx950 kernels of libsmaltgpu: thin wave-per-read wrappers around the
 // stage functions of smg_stages.hpp, and the wide Smith-Waterman score pass (K2a).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "smg_kernels.h"
 #include "smg_stages.hpp"
 
@@ -566,7 +567,8 @@ int launch_align(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar
   if (!b.nreads) return 0;
   uint32_t grid = b.nreads < nslots ? b.nreads : nslots;
   size_t small = align_lds_small_bytes(b.qmax, wincap);
-  uint32_t lds_bytes = small + 4096 <= 40 * 1024 ? 40 * 1024 - LDS_GUARD : 0;      // rows + window + 30-odd KB of direction bytes
+  static const uint32_t lds_kb = getenv("SMALTGPU_ALIGN_LDS_KB") ? (uint32_t)atoi(getenv("SMALTGPU_ALIGN_LDS_KB")) : 8u;   // tuning hook; 8 KB = 20 workgroups per CU
+  uint32_t lds_bytes = small + 4096 <= lds_kb * 1024 ? lds_kb * 1024 - LDS_GUARD : 0;      // rows + window + direction bytes
   hipLaunchKernelGGL(k_align, dim3(grid), dim3(64), lds_bytes ? lds_bytes + LDS_GUARD : 0, s, b, ix, p, scratch, sbytes, wincap, dircap, rescap, dstrcap, lds_bytes);
   SMG_LAUNCH_CHECK();
   return 0;

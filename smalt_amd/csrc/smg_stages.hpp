@@ -586,6 +586,7 @@ struct AlignScratch {
   int *ivstack;               // [2 * 64] pending reference intervals
   int32_t *state;             // [16] lane-0 state visible to the wave
   uint8_t *qcodes; uint32_t qstride;   // [2][qstride] the read in both orientations
+  uint8_t *win_lds, *dtmp_lds; uint32_t win_lds_cap;   // LDS copies for windows of ordinary length (else the HBM arrays)
 };
 
 SMG_HD inline size_t align_scratch_bytes(uint32_t qmax, uint32_t wincap, uint64_t dircap, uint32_t rescap, uint32_t dstrcap) {
@@ -608,13 +609,20 @@ SMG_HD inline AlignScratch align_scratch_carve(uint8_t *base, uint32_t qmax, uin
   x.dstr = base; base += dstrcap; x.dstrcap = dstrcap;
   x.dir = base; x.dircap = dircap;
   x.dir_lds = nullptr; x.dir_lds_cap = 0;
+  x.win_lds = x.dtmp_lds = nullptr; x.win_lds_cap = 0;
   return x;
 }
 
-// Same, with the small hot arrays (DP rows, window, reversed DiffStr, interval stack, state) and the
-// direction matrix of ordinary-sized bands in the workgroup's LDS block.
+// Same, with the small hot arrays (window and reversed DiffStr of ordinary-sized candidates, interval stack, state,
+// read codes) and the direction matrix of ordinary-sized bands in the workgroup's LDS block.  The block is kept
+// small (launch_align): the kernel is LDS-latency bound and gains from every additional resident wave.
+SMG_HD inline uint32_t align_lds_wincap(uint32_t qmax, uint32_t wincap) {
+  uint32_t w = qmax + qmax / 2 + 96;                 // read + band + edges of an ordinary candidate
+  return w < wincap ? w : wincap;
+}
 SMG_HD inline size_t align_lds_small_bytes(uint32_t qmax, uint32_t wincap) {
-  return (((size_t)qmax + 2) * 8 + 128 * 4 + 64 + 2 * ((size_t)qmax + 8) + wincap + ((size_t)qmax + wincap + 16) + 63) & ~(size_t)63;
+  const uint32_t wl = align_lds_wincap(qmax, wincap);
+  return (128 * 4 + 64 + 2 * ((size_t)qmax + 8) + wl + ((size_t)qmax + wl + 16) + 63) & ~(size_t)63;
 }
 SMG_HD inline AlignScratch align_scratch_carve_lds(uint8_t *lds, size_t lds_bytes, uint8_t *base, uint32_t qmax, uint32_t wincap,
                                                    uint64_t dircap, uint32_t rescap, uint32_t dstrcap) {
@@ -622,13 +630,12 @@ SMG_HD inline AlignScratch align_scratch_carve_lds(uint8_t *lds, size_t lds_byte
   const size_t small = align_lds_small_bytes(qmax, wincap);
   if (lds && small + 1024 <= lds_bytes) {
     uint8_t *l = lds;
-    x.Hp = (int *)l; l += ((size_t)qmax + 2) * 4;
-    x.Ep = (int *)l; l += ((size_t)qmax + 2) * 4;
     x.ivstack = (int *)l; l += 128 * 4;
     x.state = (int32_t *)l; l += 64;
     x.qcodes = l; l += 2 * (size_t)x.qstride;
-    x.win = l; l += wincap;
-    x.dtmp = l;
+    x.win_lds_cap = align_lds_wincap(qmax, wincap);
+    x.win_lds = l; l += x.win_lds_cap;
+    x.dtmp_lds = l;
     x.dir_lds = lds + small;
     x.dir_lds_cap = (uint32_t)(lds_bytes - small);
   }
@@ -784,9 +791,12 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
     const uint32_t wlen = (uint32_t)(c.re - c.rs + 1);
     if (wlen > x.wincap || c.qs > c.qe || c.qe >= qlen || (c.flags & RCF_ERR)) { SMG_SYNC(); SMG_LANE0 { x.state[S_ERR] = (wlen > x.wincap) ? SMG_ERR_CAP : SMG_ERR_ASSERT; } SMG_SYNC(); break; }
     const uint64_t gbase = (c.sqidx < 0 ? 0ull : ix.sop[c.sqidx]) + c.rs;
+    uint8_t *const win = wlen <= x.win_lds_cap ? x.win_lds : x.win;
+    uint8_t *const dtmp = wlen <= x.win_lds_cap ? x.dtmp_lds : x.dtmp;
+    const uint32_t dtmpcap = wlen <= x.win_lds_cap ? qlen + x.win_lds_cap + 16 : x.dtmpcap;
     SMG_PAR_CHUNKS(base, wlen) {                           // fetch + decode the reference window (rmap.c:831-845)
       uint32_t i = base + SMG_LANE;
-      if (i < wlen) x.win[i] = (uint8_t)ref_code(ix.packed, gbase + i);
+      if (i < wlen) win[i] = (uint8_t)ref_code(ix.packed, gbase + i);
     }
     // scalars of this candidate: every lane computes the same values from shared state
     const uint8_t *q = x.qcodes + ((c.flags & RCF_REVERSE) ? x.qstride : 0);
@@ -833,14 +843,14 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
       if (!nerr && !skip) {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (band.band_width >= 1 && band.band_width <= 64) {
-          max_scor = band_track_wave(band, q, x.win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j);
+          max_scor = band_track_wave(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j);
         } else {
-          SMG_LANE0 { x.state[8] = band_track_scalar(band, q, x.win, M, gi, ge, x.Hp, x.Ep, dirm, &max_i, &max_j); x.state[9] = max_i; x.state[10] = max_j; }
+          SMG_LANE0 { x.state[8] = band_track_scalar(band, q, win, M, gi, ge, x.Hp, x.Ep, dirm, &max_i, &max_j); x.state[9] = max_i; x.state[10] = max_j; }
           SMG_SYNC();
           max_scor = x.state[8]; max_i = x.state[9]; max_j = x.state[10];
         }
 #else
-        max_scor = band_track_scalar(band, q, x.win, M, gi, ge, x.Hp, x.Ep, dirm, &max_i, &max_j);
+        max_scor = band_track_scalar(band, q, win, M, gi, ge, x.Hp, x.Ep, dirm, &max_i, &max_j);
 #endif
       }
       SMG_SYNC();
@@ -848,7 +858,7 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
         int nsp = sp - 1, err = nerr;
         if (!err && !skip && max_scor >= minscore) {
           int qs, rs;
-          const int dn = traceback_scalar(x.dtmp, x.dtmpcap, &qs, &rs, band, dirm, max_i, max_j, max_scor, q, x.win, M, gi, ge);
+          const int dn = traceback_scalar(dtmp, dtmpcap, &qs, &rs, band, dirm, max_i, max_j, max_scor, q, win, M, gi, ge);
           if (dn < 0) err = (dn == -2) ? SMG_ERR_CAP : SMG_ERR_ASSERT;
           const int qe = max_j, re = max_i;
           if (!err && !(qs + minscorlen > qe + 1)) {
@@ -859,7 +869,7 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
               Result &a = x.res[res_first + nali];
               a.swatscor = max_scor; a.q_start = (uint32_t)qs; a.q_end = (uint32_t)qe; a.s_start = (uint64_t)rs; a.s_end = (uint64_t)re;
               a.stroffs = (uint32_t)x.state[S_NDSTR];
-              const int fl = diffstr_reverse(x.dstr + a.stroffs, x.dtmp, dn);
+              const int fl = diffstr_reverse(x.dstr + a.stroffs, dtmp, dn);
               if (fl < 0) err = SMG_ERR_ASSERT;
               else {
                 a.strlen = (uint32_t)fl;
