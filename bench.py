@@ -243,7 +243,7 @@ def main():
             "cands_hbm_strands": {"strands": work_acc[19], "hits": work_acc[20], "cycle_share": round(work_acc[21] / max(1, sum(work_acc[8:17])), 4),
                                   "over_8192": work_acc[22]},
             "cands_per_read": work_acc[5] / max(1, world * args.steps * args.reads), "kept_per_read": work_acc[6] / max(1, world * args.steps * args.reads),
-            "ranked_per_read": work_acc[3] / max(1, world * args.steps * args.reads), "scored_in_reference_order_per_read": work_acc[4] / max(1, world * args.steps * args.reads),
+            "long_window_tasks_per_read": work_acc[17] / max(1, world * args.steps * args.reads), "ranked_per_read": work_acc[3] / max(1, world * args.steps * args.reads), "scored_in_reference_order_per_read": work_acc[4] / max(1, world * args.steps * args.reads),
             "hits_per_read": work_acc[1] / max(1, world * args.steps * args.reads),
         }
         if args.host_buffers:       # the boundary's host-buffer entry point: H2D of the reads + D2H of the results inside the timing

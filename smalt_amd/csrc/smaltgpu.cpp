@@ -211,6 +211,8 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
     b.rccap = (uint32_t)cap;
   }
   DA(b.rcpool, b.rccap);
+  b.long_cap = b.rccap / 8 + 1024;
+  DA(b.long_list, b.long_cap);
   b.rescap = (uint64_t)max_batch_reads * 8 + 4096;
   DA(b.respool, b.rescap);
   b.dstrcap = b.rescap * (uint64_t)(m->qmax / 4 + 48);
@@ -275,7 +277,7 @@ extern "C" void smaltgpu_mapper_free(smaltgpu_mapper *m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   void *ps[] = {m->d_bases, m->d_quals, m->d_codes, m->d_codes_rc, m->d_off, m->b.hi, m->b.seeds, m->b.qmask, m->b.ch, m->b.ctl,
-                m->b.stat, m->b.rcpool, m->b.respool, m->b.dstrpool, m->d_counters, m->seed_scr, m->cand_scr, m->cand_scr_dbg,
+                m->b.stat, m->b.rcpool, m->b.long_list, m->b.respool, m->b.dstrpool, m->d_counters, m->seed_scr, m->cand_scr, m->cand_scr_dbg,
                 m->sw_rows, m->align_scr};
   for (void *p : ps) if (p) (void)hipFree(p);
   for (int i = 0; i <= T_NUM; i++) if (m->ev[i]) (void)hipEventDestroy(m->ev[i]);

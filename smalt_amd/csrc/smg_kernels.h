@@ -5,7 +5,8 @@
 
 namespace smg {
 
-enum : int { SW_FULL_WMAX = 1016 };   // longest reference window of the register-tiled K2a kernel
+enum : int { SW_FULL_WMAX = 1016,   // longest reference window of the register-tiled K2a kernels
+             SW_SHORT_WMAX = 248 };  // windows up to here take the small-LDS instance of the packed kernel (more resident waves)
 
 int launch_encode(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint32_t n, uint8_t *codes, uint8_t *codes_rc);
 int launch_seed(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint8_t *scratch, size_t sbytes, uint32_t nslots);

@@ -283,14 +283,18 @@ __device__ inline void sw16_rowtab(uint32_t *rowtab, const Sw16Par &sp) {
   if (threadIdx.x < 8) rowtab[threadIdx.x] = threadIdx.x < 4 ? sp.mm4 + (sp.dlt << (8 * threadIdx.x)) : sp.n4;
 }
 
-template <int G, int C>
+template <int G, int C, int WMAX>
 __global__ void __launch_bounds__(64) k_sw_full16(Batch b, DevIndex ix, MapPar p, uint32_t ntask_cap) {
+  // the small-LDS instance (WMAX = SW_SHORT_WMAX) runs first; the large one only sees what is left
+  // (through the list S7 made of them; if the list overflowed, by scanning all candidates)
+  const unsigned long long nlong = WMAX > SW_SHORT_WMAX ? b.work[WK_LONG_TASKS] : 0;
+  if (WMAX > SW_SHORT_WMAX && nlong == 0) return;
+  const uint32_t *list = (WMAX > SW_SHORT_WMAX && b.long_list && nlong <= b.long_cap) ? b.long_list : nullptr;
   constexpr int NG = 64 / G;
-  constexpr int WMAX = SW_FULL_WMAX;
   __shared__ uint16_t win[NG][WMAX + 8];
   __shared__ uint32_t rowtab[8];
   const int lane = threadIdx.x, g = lane % G, grp = lane / G;
-  const uint32_t ntask = min(*b.rc_count, ntask_cap), npair = (ntask + 1) / 2;
+  const uint32_t ntask = list ? (uint32_t)nlong : min(*b.rc_count, ntask_cap), npair = (ntask + 1) / 2;
   const Sw16Par sp = sw16_par(p);
   sw16_rowtab(rowtab, sp);
   const uint32_t ngroups = gridDim.x * NG;
@@ -299,17 +303,18 @@ __global__ void __launch_bounds__(64) k_sw_full16(Batch b, DevIndex ix, MapPar p
     const uint32_t tp = t0 + grp;
     RCand c[2];
     bool live[2] = {false, false};
-    uint32_t qlen[2] = {0, 0}, wlen[2] = {0, 0};
+    uint32_t qlen[2] = {0, 0}, wlen[2] = {0, 0}, tix[2] = {0, 0};
     uint64_t gbase[2] = {0, 0};
     const uint8_t *q[2] = {b.codes, b.codes};
 #pragma unroll
     for (int u = 0; u < 2; u++) {
-      const uint32_t t = 2 * tp + (uint32_t)u;
-      if (tp < npair && t < ntask) {
-        c[u] = b.rcpool[t];
+      const uint32_t tl = 2 * tp + (uint32_t)u;
+      if (tp < npair && tl < ntask) {
+        tix[u] = list ? list[tl] : tl;
+        c[u] = b.rcpool[tix[u]];
         qlen[u] = read_len(b, c[u].rid);
         wlen[u] = (uint32_t)(c[u].re - c[u].rs + 1);
-        live[u] = !(c[u].flags & (RCF_BANDED | RCF_ERR | RCF_QN)) && wlen[u] <= (uint32_t)WMAX && qlen[u] <= (uint32_t)(G * C);
+        live[u] = !(c[u].flags & (RCF_BANDED | RCF_ERR | RCF_QN | RCF_SCORED)) && wlen[u] <= (uint32_t)WMAX && qlen[u] <= (uint32_t)(G * C);
         gbase[u] = (c[u].sqidx < 0 ? 0ull : ix.sop[c[u].sqidx]) + c[u].rs;
         q[u] = ((c[u].flags & RCF_REVERSE) ? b.codes_rc : b.codes) + b.read_off[c[u].rid];
       }
@@ -336,7 +341,7 @@ __global__ void __launch_bounds__(64) k_sw_full16(Batch b, DevIndex ix, MapPar p
       for (int u = 0; u < 2; u++) {
         if (live[u]) {
           const int best = (int)((bb >> (16 * u)) & 0xffffu);
-          const uint32_t t = 2 * tp + (uint32_t)u;
+          const uint32_t t = tix[u];
           b.rcpool[t].swscor = best;
           b.rcpool[t].flags = c[u].flags | RCF_SCORED | (best >= 65535 ? RCF_BANDED : 0u);   // ERRCODE_SWATEXCEED -> K2b
           cells += (unsigned long long)qlen[u] * wlen[u];
@@ -577,6 +582,7 @@ int launch_align(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar
 int sw_full_geometry(uint32_t qmax_len, int *G, int *C) {
   if (qmax_len <= 64) { *G = 4; *C = 16; }
   else if (qmax_len <= 104) { *G = 8; *C = 13; }
+  else if (qmax_len <= 152) { *G = 8; *C = 19; }
   else if (qmax_len <= 160) { *G = 8; *C = 20; }
   else if (qmax_len <= 256) { *G = 16; *C = 16; }
   else if (qmax_len <= 512) { *G = 16; *C = 32; }
@@ -594,7 +600,10 @@ static bool sw16_ok(const MapPar &p) {
 template <int G, int C>
 static void launch_sw_full_t(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t ntask_cap, uint32_t grid) {
   const int use16 = sw16_ok(p);
-  if (use16) hipLaunchKernelGGL((k_sw_full16<G, C>), dim3(grid), dim3(64), 0, s, b, ix, p, ntask_cap);
+  if (use16) {
+    hipLaunchKernelGGL((k_sw_full16<G, C, SW_SHORT_WMAX>), dim3(grid), dim3(64), 0, s, b, ix, p, ntask_cap);
+    hipLaunchKernelGGL((k_sw_full16<G, C, SW_FULL_WMAX>), dim3(grid), dim3(64), 0, s, b, ix, p, ntask_cap);
+  }
   hipLaunchKernelGGL((k_sw_full<G, C>), dim3(grid), dim3(64), 0, s, b, ix, p, ntask_cap, use16);
 }
 
@@ -603,6 +612,7 @@ int launch_sw_full(hipStream_t s, const Batch &b, const DevIndex &ix, const MapP
   if (sw_full_geometry(qmax_len, &G, &C)) return 0;    // nothing for the register-tiled kernel: k_sw_scalar takes all
   if (G == 4) launch_sw_full_t<4, 16>(s, b, ix, p, ntask_cap, grid);
   else if (G == 8 && C == 13) launch_sw_full_t<8, 13>(s, b, ix, p, ntask_cap, grid);
+  else if (G == 8 && C == 19) launch_sw_full_t<8, 19>(s, b, ix, p, ntask_cap, grid);
   else if (G == 8) launch_sw_full_t<8, 20>(s, b, ix, p, ntask_cap, grid);
   else if (C == 16) launch_sw_full_t<16, 16>(s, b, ix, p, ntask_cap, grid);
   else launch_sw_full_t<16, 32>(s, b, ix, p, ntask_cap, grid);
@@ -661,6 +671,7 @@ int launch_sw_full_raw(hipStream_t s, const uint8_t *q, const uint32_t *qo, cons
   if (grid > 8192) grid = 8192;
   if (G == 4) launch_sw_raw_t<4, 16>(s, q, qo, r, ro, n, p, sc, grid, packed16);
   else if (G == 8 && C == 13) launch_sw_raw_t<8, 13>(s, q, qo, r, ro, n, p, sc, grid, packed16);
+  else if (G == 8 && C == 19) launch_sw_raw_t<8, 19>(s, q, qo, r, ro, n, p, sc, grid, packed16);
   else if (G == 8) launch_sw_raw_t<8, 20>(s, q, qo, r, ro, n, p, sc, grid, packed16);
   else if (C == 16) launch_sw_raw_t<16, 16>(s, q, qo, r, ro, n, p, sc, grid, packed16);
   else launch_sw_raw_t<16, 32>(s, q, qo, r, ro, n, p, sc, grid, packed16);

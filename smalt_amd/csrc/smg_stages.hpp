@@ -27,6 +27,7 @@ struct Batch {                          // one block of reads resident in HBM
   // S3-S7 outputs
   CandHdr *ch;                          // [nreads]
   RCand *rcpool; uint32_t rccap; uint32_t *rc_count;    // bump-allocated ranked candidates
+  uint32_t *long_list; uint32_t long_cap;               // ranked candidates with windows > SW_SHORT_WMAX (count: work[WK_LONG_TASKS])
   // O1
   ReadCtl *ctl;                         // [nreads]
   // K3 outputs
@@ -37,7 +38,7 @@ struct Batch {                          // one block of reads resident in HBM
   unsigned long long *work;             // [WK_NWORK] work counters (WK_*), one atomic per workgroup
 };
 enum : int { WK_LOOKUPS = 0, WK_HITS = 1, WK_CELLS_FULL = 2, WK_TASKS_FULL = 3, WK_CELLS_BAND = 4, WK_NCAND = 5, WK_NKEPT = 6,
-              WK_QN_TASKS = 7 /* ranked candidates of reads with non-ACGT codes */,
+              WK_QN_TASKS = 7 /* ranked candidates of reads with non-ACGT codes */, WK_LONG_TASKS = 17 /* windows > SW_SHORT_WMAX */,
               WK_PHASE0 = 8 /* .. 23: shader-clock ticks per phase of k_cands (diagnostic) */, WK_NWORK = 24 };
 
 SMG_HD inline uint32_t read_len(const Batch &b, uint32_t r) { return (uint32_t)(b.read_off[r + 1] - b.read_off[r]); }
@@ -486,6 +487,10 @@ SMG_HD inline uint32_t stage_cands(const Batch &b, const DevIndex &ix, const Map
       RCand c;
       if (cand_offsets(c, x.cand[x.sort_idx[i]], ix, qlen)) { c.flags |= RCF_ERR; c.rs = c.re = 0; c.qs = c.qe = 0; c.band_l = c.band_r = 0; }
       if (qn) c.flags |= RCF_QN;
+      if (!(c.flags & RCF_ERR) && (uint32_t)(c.re - c.rs + 1) > 248u) {                 // SW_SHORT_WMAX: listed for the large-LDS instance of K2a
+        const unsigned long long li = atomic_add_u64(b.work + WK_LONG_TASKS, 1ull);
+        if (b.long_list && li < b.long_cap) b.long_list[li] = rc_off + i;
+      }
       c.rid = r; c.pad = 0;
       b.rcpool[rc_off + i] = c;
     }

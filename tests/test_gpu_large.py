@@ -56,6 +56,39 @@ def test_repeat_rich_genome_matches_oracle(window, oracle_built, tmp_path, monke
             assert stats[i][kk] == v, (i, kk)
 
 
+def test_mid_length_reads_take_the_long_window_kernels(oracle_built, tmp_path):
+    """220 bp reads: every reference window exceeds the small-LDS instance of the packed K2a kernel, so the ranked
+    candidates go through the listed large-window instance; a tenth of the reads carry an N (32-bit kernel)."""
+    from smalt_amd import api, synth
+    ch = synth.make_reference(3, 400_000, seed=31, repeat_frac=0.1, n_fam=3, cons_len=300, divergence=0.05)
+    reads, _ = synth.make_reads(ch, 300, 220, seed=32, sub_rate=0.02, indel_read_frac=0.3)
+    seqs = [synth.codes_to_ascii(c) for c in ch]
+    rb = []
+    rng = np.random.default_rng(33)
+    for i, r in enumerate(reads):
+        a = bytearray(synth.codes_to_ascii(r))
+        if i % 10 == 0:
+            a[int(rng.integers(0, len(a)))] = ord("N")
+        rb.append(bytes(a))
+    oix0 = ol.build_index(seqs, ["c%d" % i for i in range(3)], 13, 6)
+    pre = str(tmp_path / "mid")
+    assert ol.lib().or_index_write(oix0, pre.encode()) == 0
+    oix = ol.lib().or_index_read(pre.encode())
+    exp = _oracle_map_all(oix, rb, ol.default_params(oix))
+    gix = api.Index.load(pre, 0)
+    mp = api.Mapper(gix, len(rb), 220)
+    try:
+        res, stats = mp.map_batch(rb, [b"I" * len(r) for r in rb], gix.default_params())
+    finally:
+        mp.close()
+        gix.close()
+    for i in range(len(rb)):
+        assert stats[i]["err"] == 0
+        assert res[i] == exp[i][0], i
+        for kk, v in exp[i][1].items():
+            assert stats[i][kk] == v, (i, kk)
+
+
 def test_torch_index_equals_oracle_index(oracle_built, tmp_path):
     import torch
     from smalt_amd import api, gpuindex, synth

@@ -38,7 +38,7 @@ def _pairs(rng, n, qlen_lo, qlen_hi, with_n):
     return qs, ws
 
 
-@pytest.mark.parametrize("qlo,qhi", [(32, 64), (65, 104), (105, 160), (161, 256), (257, 512)])
+@pytest.mark.parametrize("qlo,qhi", [(32, 64), (65, 104), (105, 152), (153, 160), (161, 256), (257, 512)])
 def test_sw_full_kernel_matches_oracle(qlo, qhi, oracle_built):
     from smalt_amd import api
     rng = np.random.default_rng(qlo * 7919 + qhi)
