@@ -223,6 +223,7 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
     b.res_count = (unsigned long long *)(m->d_counters + 8);
     b.dstr_count = (unsigned long long *)(m->d_counters + 16);
     b.err_flag = (int32_t *)(m->d_counters + 24);
+    b.next_item = (uint32_t *)(m->d_counters + 32);
     b.work = (unsigned long long *)(m->d_counters + 64);
   }
   // scratch geometry -------------------------------------------------------------------
@@ -244,7 +245,7 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
     m->cg.candcap = m->cg.hcap;                         // every hit can be a candidate of its own (mincover = k)
     { const char *e = getenv("SMALTGPU_CANDS_WINDOW"); m->cg.window = e ? (uint32_t)atoi(e) : 0; }   // test hook (tests/test_gpu_large.py)
     m->cg.slot_bytes = m->cand_bytes = cand_slot_bytes(m->cg, m->qmax, d.s);
-    uint64_t budget = 24ull << 30;
+    uint64_t budget = 64ull << 30;     // of 288 GB: more slots than resident workgroups lets the hardware balance uneven reads
     uint64_t slots = budget / m->cand_bytes;
     if (slots > 2048) slots = 2048;                     // LDS admits 4 workgroups per CU: 1024 run at a time
     if (slots < 64) slots = 64;

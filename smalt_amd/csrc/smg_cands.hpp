@@ -26,12 +26,13 @@ enum : uint32_t { CANDS_LDS_HITS = 1152,       // hits of the LDS working set (o
 enum : int { SMG_WINDOW_FALLBACK = 1000 };      // internal: a hit region does not fit a window
 
 template <class IT>
-struct StrandWork {           // one strand's working set; IT = uint16_t (LDS) or uint32_t (HBM)
-  uint64_t *dat;              // [cap]  sorted keys: seq(10) | diagonal(33) | q(20)  (strand bit cleared)
-  IT *seed_first, *seed_len;  // [cap]
-  IT *segm_first, *segm_nseed, *segm_cover;   // [cap]
-  IT *reg_first, *reg_num;    // [cap]
-  uint8_t *cflag;             // [cap]  1: a candidate starts at this segment
+struct StrandWork {           // one strand's working set; IT = uint16_t (LDS, LDS-typed pointers) or uint32_t (HBM)
+  static constexpr bool L = sizeof(IT) == 2;
+  typename ptr_of<uint64_t, L>::type dat;              // [cap]  sorted keys: seq(10) | diagonal(33) | q(20)  (strand bit cleared)
+  typename ptr_of<IT, L>::type seed_first, seed_len;   // [cap]
+  typename ptr_of<IT, L>::type segm_first, segm_nseed, segm_cover;   // [cap]
+  typename ptr_of<IT, L>::type reg_first, reg_num;     // [cap]
+  typename ptr_of<uint8_t, L>::type cflag;             // [cap]  1: a candidate starts at this segment
   uint32_t cap;
 };
 
@@ -41,16 +42,19 @@ SMG_HD inline size_t strand_work_bytes(uint32_t cap) { return (size_t)cap * (8 +
 template <class IT>
 SMG_HD inline StrandWork<IT> strand_work_carve(uint8_t *base, uint32_t cap) {
   StrandWork<IT> w;
+  typedef typename ptr_of<uint64_t, StrandWork<IT>::L>::type P64;
+  typedef typename ptr_of<IT, StrandWork<IT>::L>::type PIT;
+  typedef typename ptr_of<uint8_t, StrandWork<IT>::L>::type P8;
   w.cap = cap;
-  w.dat = (uint64_t *)base; base += (size_t)cap * 8;
-  w.seed_first = (IT *)base; base += (size_t)cap * sizeof(IT);
-  w.seed_len = (IT *)base; base += (size_t)cap * sizeof(IT);
-  w.segm_first = (IT *)base; base += (size_t)cap * sizeof(IT);
-  w.segm_nseed = (IT *)base; base += (size_t)cap * sizeof(IT);
-  w.segm_cover = (IT *)base; base += (size_t)cap * sizeof(IT);
-  w.reg_first = (IT *)base; base += (size_t)cap * sizeof(IT);
-  w.reg_num = (IT *)base; base += (size_t)cap * sizeof(IT);
-  w.cflag = base;
+  w.dat = (P64)base; base += (size_t)cap * 8;
+  w.seed_first = (PIT)base; base += (size_t)cap * sizeof(IT);
+  w.seed_len = (PIT)base; base += (size_t)cap * sizeof(IT);
+  w.segm_first = (PIT)base; base += (size_t)cap * sizeof(IT);
+  w.segm_nseed = (PIT)base; base += (size_t)cap * sizeof(IT);
+  w.segm_cover = (PIT)base; base += (size_t)cap * sizeof(IT);
+  w.reg_first = (PIT)base; base += (size_t)cap * sizeof(IT);
+  w.reg_num = (PIT)base; base += (size_t)cap * sizeof(IT);
+  w.cflag = (P8)base;
   return w;
 }
 
@@ -635,15 +639,25 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
         }
         SMG_SYNC();
         if (carry + cnt_tot > W || (cnt_tot == 0 && remaining > 0)) { rv = SMG_ERR_ASSERT; break; }
-        SMG_PAR_CHUNKS(base, cnt_tot) {
-          const uint32_t h = base + SMG_LANE;
-          if (h < cnt_tot) {
-            uint32_t lo = 0, hi = nlist;
-            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g_pfx[mid] <= h) lo = mid; else hi = mid; }
-            const uint32_t pos = ix.pos[g_poff[lo] + g_cur[lo] + (h - g_pfx[lo])], qo = g_qo[lo];
-            uint64_t key = (hit_diag(st != 0, pos, qo, s) << KEY_QBITS) | qo;
-            if (seqbyseq) key |= (uint64_t)seq_of_pos(ix.seqlo, ix.nseq, pos) << (KEY_DIAGBITS + KEY_QBITS);
-            wl.dat[carry + h] = key;
+        for (uint32_t base = 0; base < cnt_tot; base += 4 * SMG_NLANES) {      // four independent index reads in flight per lane
+          uint32_t pos[4], qo[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint32_t h = base + (uint32_t)u * SMG_NLANES + SMG_LANE;
+            if (h < cnt_tot) {
+              uint32_t lo = 0, hi = nlist;
+              while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g_pfx[mid] <= h) lo = mid; else hi = mid; }
+              pos[u] = ix.pos[g_poff[lo] + g_cur[lo] + (h - g_pfx[lo])]; qo[u] = g_qo[lo];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint32_t h = base + (uint32_t)u * SMG_NLANES + SMG_LANE;
+            if (h < cnt_tot) {
+              uint64_t key = (hit_diag(st != 0, pos[u], qo[u], s) << KEY_QBITS) | qo[u];
+              if (seqbyseq) key |= (uint64_t)seq_of_pos(ix.seqlo, ix.nseq, pos[u]) << (KEY_DIAGBITS + KEY_QBITS);
+              wl.dat[carry + h] = key;
+            }
           }
         }
         SMG_SYNC();
@@ -660,7 +674,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
                           remaining > 0, &nproc, &reg_base);
         t0 = phase_clock();
         if (rv) break;
-        if (dbg_w) dbg_hits(x, wl.dat, nproc, gproc, st, ngrp, seqbyseq, dbg_w, last_grp);
+        if (dbg_w) dbg_hits(x, (const uint64_t *)wl.dat, nproc, gproc, st, ngrp, seqbyseq, dbg_w, last_grp);
         gproc += nproc;
         // the unfinished last region opens the next window
         carry = n - nproc;
@@ -689,19 +703,29 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     if (mode != 1) {
       const bool in_lds = mode == 0;
       const uint32_t gcap = in_lds ? CANDS_LDS_HITS : x.hcap_strand;
-      uint64_t *dat = in_lds ? wl.dat : wg.dat;
+      uint64_t *dat = in_lds ? (uint64_t *)wl.dat : wg.dat;
       if (simple) {
         if (total > gcap) { err = SMG_ERR_CAP; break; }
         nkeys = total;
-        SMG_PAR_CHUNKS(base, nkeys) {
-          const uint32_t h = base + SMG_LANE;
-          if (h < nkeys) {
-            uint32_t lo = 0, hi = nlist;                       // last list with prefix <= h
-            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g_pfx[mid] <= h) lo = mid; else hi = mid; }
-            const uint32_t pos = ix.pos[g_poff[lo] + (h - g_pfx[lo])], qo = g_qo[lo];
-            uint64_t key = (hit_diag(st != 0, pos, qo, s) << KEY_QBITS) | qo;
-            if (seqbyseq) key |= (uint64_t)seq_of_pos(ix.seqlo, ix.nseq, pos) << (KEY_DIAGBITS + KEY_QBITS);
-            dat[h] = key;
+        for (uint32_t base = 0; base < nkeys; base += 4 * SMG_NLANES) {        // four independent index reads in flight per lane
+          uint32_t pos[4], qo[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint32_t h = base + (uint32_t)u * SMG_NLANES + SMG_LANE;
+            if (h < nkeys) {
+              uint32_t lo = 0, hi = nlist;                     // last list with prefix <= h
+              while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g_pfx[mid] <= h) lo = mid; else hi = mid; }
+              pos[u] = ix.pos[g_poff[lo] + (h - g_pfx[lo])]; qo[u] = g_qo[lo];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint32_t h = base + (uint32_t)u * SMG_NLANES + SMG_LANE;
+            if (h < nkeys) {
+              uint64_t key = (hit_diag(st != 0, pos[u], qo[u], s) << KEY_QBITS) | qo[u];
+              if (seqbyseq) key |= (uint64_t)seq_of_pos(ix.seqlo, ix.nseq, pos[u]) << (KEY_DIAGBITS + KEY_QBITS);
+              dat[h] = key;
+            }
           }
         }
       } else {

@@ -25,6 +25,18 @@
 #define SMG_SYNC() do {} while (0)
 #endif
 
+// Pointers that are known to address the workgroup's LDS block carry the LDS address space on the device, so that
+// the compiler emits ds_* instructions (32-bit addresses) instead of flat ones; plain pointers on the host build.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SMG_LDSQ __attribute__((address_space(3)))
+#else
+#define SMG_LDSQ
+#endif
+namespace smg {
+template <class T, bool IN_LDS> struct ptr_of { typedef T *type; };
+template <class T> struct ptr_of<T, true> { typedef SMG_LDSQ T *type; };
+}
+
 #define SMG_PAR_CHUNKS(base, n) for (uint32_t base = 0; base < (uint32_t)(n); base += SMG_NLANES)
 #define SMG_LANE0 if (SMG_LANE == 0)
 
@@ -101,33 +113,57 @@ SMG_HD inline uint32_t bcast_lane0(uint32_t v) {
 // comparator puts the smaller key at the lower index: the first step of a merge pairs i with its mirror
 // image in the block, the others pair i with i + j).  Keys beyond n are virtual +inf: a comparator that
 // touches one never swaps, so no padding is stored and only comparators below n are visited.
-SMG_HD inline void wave_sort_u64(uint64_t *a, uint32_t n) {
+template <class P>
+SMG_HD inline void wave_sort_u64(P a, uint32_t n) {
   if (n < 2) return;
 #if defined(__HIP_DEVICE_COMPILE__)
   uint32_t np = 1;
   while (np < n) np <<= 1;
+  // Each step loads the operands of up to four comparators per lane before it stores any: the step is bound by
+  // LDS latency, and four independent round trips overlap.
   for (uint32_t k = 2; k <= np; k <<= 1) {
     const uint32_t h = k >> 1;
     {                                                           // mirror step
       const uint32_t tmax = (n / k) * h + ((n % k) < h ? (n % k) : h);
-      for (uint32_t t = SMG_LANE; t < tmax; t += SMG_NLANES) {
-        const uint32_t blk = t / h, off = t % h, i = blk * k + off, p = blk * k + (k - 1 - off);
-        if (p < n) { const uint64_t x = a[i], y = a[p]; if (x > y) { a[i] = y; a[p] = x; } }
+      for (uint32_t t0 = 0; t0 < tmax; t0 += 4 * SMG_NLANES) {
+        uint32_t ii[4], pp[4];
+        uint64_t x[4], y[4];
+        bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t t = t0 + (uint32_t)u * SMG_NLANES + SMG_LANE;
+          const uint32_t blk = t / h, off = t % h;
+          ii[u] = blk * k + off; pp[u] = blk * k + (k - 1 - off);
+          on[u] = t < tmax && pp[u] < n;
+          if (on[u]) { x[u] = a[ii[u]]; y[u] = a[pp[u]]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (on[u] && x[u] > y[u]) { a[ii[u]] = y[u]; a[pp[u]] = x[u]; }
       }
       SMG_SYNC();
     }
     for (uint32_t j = h >> 1; j > 0; j >>= 1) {
       const uint32_t tmax = (n / (2 * j)) * j + ((n % (2 * j)) < j ? (n % (2 * j)) : j);
-      for (uint32_t t = SMG_LANE; t < tmax; t += SMG_NLANES) {
-        const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
-        if (p < n) { const uint64_t x = a[i], y = a[p]; if (x > y) { a[i] = y; a[p] = x; } }
+      for (uint32_t t0 = 0; t0 < tmax; t0 += 4 * SMG_NLANES) {
+        uint32_t ii[4];
+        uint64_t x[4], y[4];
+        bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t t = t0 + (uint32_t)u * SMG_NLANES + SMG_LANE;
+          ii[u] = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          on[u] = t < tmax && (ii[u] | j) < n;
+          if (on[u]) { x[u] = a[ii[u]]; y[u] = a[ii[u] | j]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (on[u] && x[u] > y[u]) { a[ii[u]] = y[u]; a[ii[u] | j] = x[u]; }
       }
       SMG_SYNC();
     }
   }
 #else
   // host build: any correct sort gives the same array (keys are plain integers)
-  std::sort(a, a + n);
+  std::sort((uint64_t *)a, (uint64_t *)a + n);
 #endif
 }
 

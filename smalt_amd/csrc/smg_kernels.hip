@@ -37,12 +37,22 @@ __global__ void __launch_bounds__(64) k_encode(const uint8_t *bases, const uint6
 // starts at LDS offset 0.
 enum : uint32_t { LDS_GUARD = 64 };
 
+// Persistent workgroups take the next item from a batch-wide cursor: per-read cost is heavy-tailed (repeat-rich
+// reads), a static stride leaves most of the chip idle behind the slowest workgroup.
+__device__ inline uint32_t next_item(uint32_t *cursor, uint32_t *lds_slot) {
+  __syncthreads();
+  if (threadIdx.x == 0) *lds_slot = atomicAdd(cursor, 1u);
+  __syncthreads();
+  return *lds_slot;
+}
+
 __global__ void __launch_bounds__(64) k_seed(Batch b, DevIndex ix, MapPar p, uint8_t *gscratch, size_t gbytes, int use_lds) {
   extern __shared__ __align__(16) uint8_t lds[];
   uint8_t *base = use_lds ? lds + LDS_GUARD : gscratch + gbytes * blockIdx.x;
   SeedScratch x = seed_scratch_carve(base, b.qmax, ix.s);
   unsigned long long nlook = 0;
-  for (uint32_t rs = blockIdx.x; rs < 2 * b.nreads; rs += gridDim.x) {
+  __shared__ uint32_t qslot;
+  for (uint32_t rs = next_item(b.next_item + 0, &qslot); rs < 2 * b.nreads; rs = next_item(b.next_item + 0, &qslot)) {
     nlook += stage_seed(b, ix, p, rs >> 1, rs & 1, x);
     __syncthreads();
   }
@@ -55,7 +65,8 @@ __global__ void __launch_bounds__(64) k_cands(Batch b, DevIndex ix, MapPar p, ui
   extern __shared__ __align__(16) uint8_t lds[];
   unsigned long long nhit = 0;
   unsigned long long ph[16] = {0};
-  for (uint32_t r = blockIdx.x; r < b.nreads; r += gridDim.x) {
+  __shared__ uint32_t qslot;
+  for (uint32_t r = next_item(b.next_item + 1, &qslot); r < b.nreads; r = next_item(b.next_item + 1, &qslot)) {
     uint8_t *base = gscratch + g.slot_bytes * (g.debug ? r : blockIdx.x);
     if (cands_v2_applicable(p, ix.k, ix.s, read_len(b, r))) {
       CandsV2Scratch x = cands_v2_carve(lds + LDS_GUARD, lds_bytes, base, b.qmax, ix.s, g.hcap_strand, g.ngrp, g.candcap, g.debug != 0);
@@ -90,7 +101,8 @@ __global__ void __launch_bounds__(64) k_align(Batch b, DevIndex ix, MapPar p, ui
   extern __shared__ __align__(16) uint8_t lds[];
   uint8_t *base = gscratch + gbytes * blockIdx.x;
   AlignScratch x = align_scratch_carve_lds(lds_bytes ? lds + LDS_GUARD : nullptr, lds_bytes, base, b.qmax, wincap, dircap, rescap, dstrcap);
-  for (uint32_t r = blockIdx.x; r < b.nreads; r += gridDim.x) {
+  __shared__ uint32_t qslot;
+  for (uint32_t r = next_item(b.next_item + 2, &qslot); r < b.nreads; r = next_item(b.next_item + 2, &qslot)) {
     stage_align(b, ix, p, r, x);
     __syncthreads();
   }

@@ -35,6 +35,7 @@ struct Batch {                          // one block of reads resident in HBM
   Result *respool; uint64_t rescap; unsigned long long *res_count;
   uint8_t *dstrpool; uint64_t dstrcap; unsigned long long *dstr_count;
   int32_t *err_flag;                    // batch-wide first error
+  uint32_t *next_item;                  // [4] work-queue cursors of the persistent kernels (seed, cands, align)
   unsigned long long *work;             // [WK_NWORK] work counters (WK_*), one atomic per workgroup
 };
 enum : int { WK_LOOKUPS = 0, WK_HITS = 1, WK_CELLS_FULL = 2, WK_TASKS_FULL = 3, WK_CELLS_BAND = 4, WK_NCAND = 5, WK_NKEPT = 6,
