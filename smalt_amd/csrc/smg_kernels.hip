@@ -242,6 +242,7 @@ __device__ inline us2 pk_max(us2 a, us2 b) { return __builtin_elementwise_max(a,
 __device__ inline us2 pk_subs(us2 a, us2 b) { return __builtin_elementwise_sub_sat(a, b); }
 __device__ inline uint32_t shr1_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, true); }
 
+enum : int { SW16_BLK = 5 };
 struct Sw16Par { uint32_t mm4, dlt, n4; us2 bias, gi, ge; };
 __device__ inline Sw16Par sw16_par(const MapPar &p) {
   Sw16Par s;
@@ -269,20 +270,37 @@ __device__ inline uint32_t sw16_core(const uint16_t *wrow, int nrow, int nstep, 
     const uint32_t rowA = rowtab[rp & 0xffu], rowB = rowtab[rp >> 8];     // ACGT scores (+ bias) against this reference base
     const uint32_t hl = shr1_u32(as_u32(H[C - 1])) & gmask;
     const uint32_t fin = shr1_u32(as_u32(F)) & gmask;
-    us2 diag = prev_hl;
+    us2 carry = prev_hl;                       // H[row-1] of the column left of the block
     prev_hl = as_us2(hl);
     F = as_us2(fin);
+    // Blocks of SW16_BLK columns: first everything that does not depend on the running F (independent across the
+    // columns, so the packed-op forwarding hazards are filled with useful work), then the F chain.
 #pragma unroll
-    for (int cc = 0; cc < C; cc++) {
-      const us2 w = as_us2(__builtin_amdgcn_perm(rowB, rowA, sel[cc]));
-      const us2 h = pk_subs(diag + w, sp.bias);
-      const us2 hh = pk_max(pk_max(h, E[cc]), F);
-      best = pk_max(best, hh);
-      diag = H[cc];
-      H[cc] = hh;
-      const us2 tt = pk_subs(hh, sp.gi);
-      E[cc] = pk_max(pk_subs(E[cc], sp.ge), tt);
-      F = pk_max(pk_subs(F, sp.ge), tt);
+    for (int c0 = 0; c0 < C; c0 += SW16_BLK) {
+      us2 t3[SW16_BLK];
+      const us2 last_old = H[(c0 + SW16_BLK - 1 < C) ? c0 + SW16_BLK - 1 : C - 1];
+#pragma unroll
+      for (int u = 0; u < SW16_BLK; u++) {
+        const int cc = c0 + u;
+        if (cc < C) {
+          const us2 w = as_us2(__builtin_amdgcn_perm(rowB, rowA, sel[cc]));
+          const us2 dg = u == 0 ? carry : H[cc - 1];
+          t3[u] = pk_max(pk_subs(dg + w, sp.bias), E[cc]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < SW16_BLK; u++) {
+        const int cc = c0 + u;
+        if (cc < C) {
+          const us2 hh = pk_max(t3[u], F);
+          best = pk_max(best, hh);
+          H[cc] = hh;
+          const us2 tt = pk_subs(hh, sp.gi);
+          E[cc] = pk_max(pk_subs(E[cc], sp.ge), tt);
+          F = pk_max(pk_subs(F, sp.ge), tt);
+        }
+      }
+      carry = last_old;
     }
   }
   uint32_t bb = as_u32(best);
