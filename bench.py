@@ -220,11 +220,19 @@ def main():
         seed_bytes = work_acc[0] * 8 + work_acc[1] * 12
         seed_ms = ms_acc.get("seed", 0.0) + ms_acc.get("cands", 0.0)
         seed_gbs = seed_bytes / (seed_ms * 1e-3) / 1e9 if seed_ms > 0 else 0.0
-        roof_sw = dict(kernel="k_sw_full", bound="valu", achieved=sw_tops, peak=VALU_PEAK_TOPS, unit="TOP/s",
-                       frac=sw_tops / VALU_PEAK_TOPS, traffic=None, gcups=cells / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else 0.0,
+        traffic_sw = traffic_seed = None          # HBM bytes per launch from the committed PMC passes (profiles/), scaled to this sub-batch
+        try:
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            sc = sub / float(pt["reads_per_launch"])
+            traffic_sw = (pt["kernels"]["sw_full"]["fetch"] + pt["kernels"]["sw_full"]["write"]) * sc
+            traffic_seed = sum(pt["kernels"][kk]["fetch"] + pt["kernels"][kk]["write"] for kk in ("seed", "cands")) * sc
+        except Exception:
+            pass
+        roof_sw = dict(kernel="k_sw_full16", bound="valu", achieved=sw_tops, peak=VALU_PEAK_TOPS, unit="TOP/s",
+                       frac=sw_tops / VALU_PEAK_TOPS, traffic=traffic_sw, gcups=cells / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else 0.0,
                        avg_launch_ms=sw_ms / nlaunch, cells_per_launch=cells / nlaunch)
         roof_seed = dict(kernel="k_seed+k_cands", bound="hbm", achieved=seed_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
-                         frac=seed_gbs / HBM_PEAK_GBS, traffic=None, avg_launch_ms=seed_ms / nlaunch,
+                         frac=seed_gbs / HBM_PEAK_GBS, traffic=traffic_seed, avg_launch_ms=seed_ms / nlaunch,
                          bytes_per_launch=seed_bytes / nlaunch)
         line = {
             "metric": "mapped reads/sec (1Mx150bp vs 3Gbp ref)", "value": value, "unit": "mapped reads/s", "n_gpus": world,
@@ -254,7 +262,7 @@ def main():
             th = time.time()
             mapper.map_batch_raw(hb, ho, None, par)
             line["host_buffers"] = {"reads_per_s": sub / (time.time() - th), "reads": sub, "note": "PCIe-inclusive, not `value`"}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
             try:
                 line["cpu_baseline"] = cpu_baseline(args, packed.cpu().numpy(), idx.cpu().numpy(), pos.cpu().numpy(), sop, names, k, s,
                                                     reads_ascii.cpu().numpy(), args.reads, args.read_len)
