@@ -448,7 +448,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   const bool seqbyseq = (p.flags & FLG_SEQBYSEQ) != 0;
   const uint32_t ngrp = x.ngrp;
   if (qlen < (uint32_t)k) {
-    SMG_LANE0 { ch.ncand = ch.n_sort = ch.n_mincover = ch.max_cover = ch.max2nd_cover = 0; ch.cover_deficit[0] = ch.cover_deficit[1] = 0; ch.rc_off = 0; ch.err = 0; ch.nhits[0] = ch.nhits[1] = 0; }
+    SMG_LANE0 { ch.ncand = ch.n_sort = ch.n_mincover = ch.max_cover = ch.max2nd_cover = 0; ch.cover_deficit[0] = ch.cover_deficit[1] = 0; ch.rc_off = 0; ch.err = 0; ch.nhits[0] = ch.nhits[1] = 0; ch.n_reserved = 0; }
     return 0;
   }
   const uint32_t min_cover = (uint32_t)k;                         // (min_ktup - 1) * s + k with min_ktup == 1
@@ -573,6 +573,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
       }
       SMG_SYNC();
     }
+    { const unsigned long long tq = phase_clock(); ph[11] += tq - t0; }
     int mode = !simple ? 2 : ((lds_ok && total <= W) ? 0 : (lds_ok ? 1 : 2));
     const uint32_t ncand0 = ncand, mx0 = max_cover, mx20 = max2nd;
     uint32_t nkeys = 0;
@@ -638,6 +639,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
 #endif
         }
         SMG_SYNC();
+        const unsigned long long tb0 = phase_clock();
         if (carry + cnt_tot > W || (cnt_tot == 0 && remaining > 0)) { rv = SMG_ERR_ASSERT; break; }
         for (uint32_t base = 0; base < cnt_tot; base += 4 * SMG_NLANES) {      // four independent index reads in flight per lane
           uint32_t pos[4], qo[4];
@@ -668,6 +670,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
         remaining -= cnt_tot;
         const uint32_t n = carry + cnt_tot;
         SMG_SYNC();
+        ph[13] += phase_clock() - tb0;
         SMG_PH(1)
         uint32_t nproc = n;
         rv = strand_cands(wl, n, st != 0, seqbyseq, qlen, k, s, min_cover, x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph,
@@ -697,7 +700,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
         if (x.dbg_first) { SMG_SYNC(); SMG_PAR_CHUNKS(base, ngrp) { uint32_t g = base + SMG_LANE; if (g < ngrp) { x.dbg_first[st * ngrp + g] = 0; x.dbg_cnt[st * ngrp + g] = 0; } } SMG_SYNC(); }
       } else if (rv) { err = rv; break; }
       else nkeys = total;
-      ph[11]++; ph[12] += total; ph[13] += t0 - ts;
+      ph[12] += total;
     }
 
     if (mode != 1) {
@@ -858,8 +861,9 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   SMG_LANE0 {
     ch.ncand = ncand; ch.n_sort = nrank; ch.n_mincover = nmin; ch.max_cover = max_cover; ch.max2nd_cover = max2nd;
     ch.err = err;
+    ch.n_reserved = ch.n_sort;
     ch.rc_off = atomic_add_u32(b.rc_count, ch.n_sort);
-    if (ch.rc_off + ch.n_sort > b.rccap) { ch.err = SMG_ERR_CAP; ch.n_sort = 0; }
+    if ((uint64_t)ch.rc_off + ch.n_sort > b.rccap) { ch.err = SMG_ERR_CAP; ch.n_sort = 0; }
   }
   SMG_SYNC();
   {                                         // ranked part to the slot (S7 below, diagnostics)
@@ -873,6 +877,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   ph[9] += ncand; ph[10] += nmin;
   // ---- S7 ----
   const uint32_t n_sort = ch.n_sort, rc_off = ch.rc_off;
+  if (ch.err == SMG_ERR_CAP && ch.n_reserved > n_sort) rc_pool_fill_inert(b, rc_off, ch.n_reserved, r);
   bool qn = false;                          // reads with non-ACGT codes are scored in 32-bit lanes (k_sw_full)
   SMG_PAR_CHUNKS(base, qlen) { const uint32_t i = base + SMG_LANE; if (i < qlen && b.codes[b.read_off[r] + i] >= 4) qn = true; }
   qn = wave_any(qn);

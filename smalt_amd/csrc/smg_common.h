@@ -102,7 +102,7 @@ struct CandHdr {                                                    // segment.c
   uint32_t rc_off;          // first RCand of this read in the pool
   int32_t err;
   uint32_t nhits[2];        // collected hits per strand (diagnostic)
-  uint32_t pad;
+  uint32_t n_reserved;      // pool entries reserved for this read (= n_sort unless the pool overflowed)
 };
 
 struct ReadCtl {                                                    // scalars of mapSingleRead (rmap.c:1373-1400)

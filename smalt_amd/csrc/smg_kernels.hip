@@ -455,7 +455,7 @@ __global__ void __launch_bounds__(64) k_sw_full16_raw(const uint8_t *qcodes, con
 // K2b (banded score-only pass, alignment.c:1029) -- one lane per task, rows in HBM scratch.
 __global__ void __launch_bounds__(64) k_sw_scalar(Batch b, DevIndex ix, MapPar p, int *rows, uint32_t rowlen, int full_gc) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
-  const uint32_t ntask = *b.rc_count;
+  const uint32_t ntask = min(*b.rc_count, b.rccap);      // the cursor runs past the pool when it overflows (reads keep SMG_ERR_CAP)
   int *Hp = rows + (size_t)tid * 2 * rowlen, *Ep = Hp + rowlen;
   int8_t M[64];
   score_matrix(M, p.match, p.mismatch);

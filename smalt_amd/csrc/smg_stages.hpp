@@ -42,6 +42,19 @@ enum : int { WK_LOOKUPS = 0, WK_HITS = 1, WK_CELLS_FULL = 2, WK_TASKS_FULL = 3, 
               WK_QN_TASKS = 7 /* ranked candidates of reads with non-ACGT codes */, WK_LONG_TASKS = 17 /* windows > SW_SHORT_WMAX */,
               WK_PHASE0 = 8 /* .. 23: shader-clock ticks per phase of k_cands (diagnostic) */, WK_NWORK = 24 };
 
+// The score kernels walk the candidate pool linearly.  A read whose ranked candidates do not fit keeps none
+// (SMG_ERR_CAP); the part of its reservation that still lies inside the pool is filled with inert entries.
+SMG_HD inline void rc_pool_fill_inert(const Batch &b, uint32_t rc_off, uint32_t n_reserved, uint32_t r) {
+  const uint64_t lo = rc_off < b.rccap ? rc_off : b.rccap;
+  const uint64_t hi = (uint64_t)rc_off + n_reserved < b.rccap ? (uint64_t)rc_off + n_reserved : b.rccap;
+  for (uint64_t i = lo + SMG_LANE; i < hi; i += SMG_NLANES) {
+    RCand c;
+    c.flags = RCF_ERR | RCF_SCORED; c.qs = c.qe = 0; c.rs = c.re = 0; c.band_l = c.band_r = 0; c.sqidx = 0; c.swscor = 0; c.cover = 0;
+    c.rid = r; c.pad = 0;
+    b.rcpool[i] = c;
+  }
+}
+
 SMG_HD inline uint32_t read_len(const Batch &b, uint32_t r) { return (uint32_t)(b.read_off[r + 1] - b.read_off[r]); }
 
 SMG_HD inline uint32_t atomic_add_u32(uint32_t *p, uint32_t v) {
@@ -280,7 +293,7 @@ SMG_HD inline uint32_t stage_cands(const Batch &b, const DevIndex &ix, const Map
   const uint32_t ngrp = x.ngrp;
 
   if (qlen < (uint32_t)k) {
-    SMG_LANE0 { ch.ncand = ch.n_sort = ch.n_mincover = ch.max_cover = ch.max2nd_cover = 0; ch.cover_deficit[0] = ch.cover_deficit[1] = 0; ch.rc_off = 0; ch.err = 0; ch.nhits[0] = ch.nhits[1] = 0; }
+    SMG_LANE0 { ch.ncand = ch.n_sort = ch.n_mincover = ch.max_cover = ch.max2nd_cover = 0; ch.cover_deficit[0] = ch.cover_deficit[1] = 0; ch.rc_off = 0; ch.err = 0; ch.nhits[0] = ch.nhits[1] = 0; ch.n_reserved = 0; }
     return 0;
   }
   // calcMinKtup (rmap.c:240-247) and the coverage threshold of mapSingleRead (:1283-1289)
@@ -472,12 +485,14 @@ SMG_HD inline uint32_t stage_cands(const Batch &b, const DevIndex &ix, const Map
     ch.max_cover = cs.max_cover; ch.max2nd_cover = cs.max2nd_cover;
     ch.cover_deficit[0] = cdf[0]; ch.cover_deficit[1] = cdf[1];
     ch.err = err;
+    ch.n_reserved = ch.n_sort;
     ch.rc_off = atomic_add_u32(b.rc_count, ch.n_sort);
-    if (ch.rc_off + ch.n_sort > b.rccap) { ch.err = SMG_ERR_CAP; ch.n_sort = 0; }
+    if ((uint64_t)ch.rc_off + ch.n_sort > b.rccap) { ch.err = SMG_ERR_CAP; ch.n_sort = 0; }
   }
   SMG_SYNC();
   // ---- S7: windows and bands of the ranked candidates ----
   const uint32_t n_sort = ch.n_sort, rc_off = ch.rc_off;
+  if (ch.err == SMG_ERR_CAP && ch.n_reserved > n_sort) rc_pool_fill_inert(b, rc_off, ch.n_reserved, r);
   bool qn = false;                          // reads with non-ACGT codes are scored in 32-bit lanes (k_sw_full)
   SMG_PAR_CHUNKS(base, qlen) { const uint32_t i = base + SMG_LANE; if (i < qlen && b.codes[b.read_off[r] + i] >= 4) qn = true; }
   qn = wave_any(qn);

@@ -128,3 +128,28 @@ def test_torch_index_equals_oracle_index(oracle_built, tmp_path):
     exp = _oracle_map_all(oix, rb, ol.default_params(oix))
     for i in range(len(rb)):
         assert res[i] == exp[i][0], i
+
+
+def test_candidate_pool_overflow_is_reported_per_read(oracle_built, tmp_path, monkeypatch):
+    """Device-side capacity limits must fail loudly and cleanly: with a pool of 4 ranked candidates per read the
+    batch returns SMALTGPU_ECAP, names the number of affected reads, and the mapper stays usable."""
+    from smalt_amd import api, synth
+    monkeypatch.setenv("SMALTGPU_CANDS_PER_READ", "4")
+    ch = synth.make_reference(2, 600_000, seed=41, repeat_frac=0.3, n_fam=1, cons_len=300, divergence=0.03)
+    reads, _ = synth.make_reads(ch, 6000, 100, seed=42, sub_rate=0.01, indel_read_frac=0.05)
+    seqs = [synth.codes_to_ascii(c) for c in ch]
+    rb = [synth.codes_to_ascii(r) for r in reads]
+    oix = ol.build_index(seqs, ["c0", "c1"], 11, 3)
+    pre = str(tmp_path / "ovf")
+    assert ol.lib().or_index_write(oix, pre.encode()) == 0
+    gix = api.Index.load(pre, 0)
+    mp = api.Mapper(gix, len(rb), 100)
+    try:
+        with pytest.raises(api.SmaltGpuError) as e:
+            mp.map_batch(rb, None, gix.default_params())
+        assert e.value.code == -5 and ("pool overflow" in str(e.value) or "device-side limit" in str(e.value))
+        with pytest.raises(api.SmaltGpuError):            # and again: the mapper is still in a defined state
+            mp.map_batch(rb[:100] * 50, None, gix.default_params())
+    finally:
+        mp.close()
+        gix.close()
