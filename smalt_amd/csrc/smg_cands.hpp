@@ -246,7 +246,6 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
     const uint32_t r = base + SMG_LANE;
     if (r < nreg) {
       const uint32_t first = w.reg_first[r], num = (r + 1 < nreg ? (uint32_t)w.reg_first[r + 1] : nsegm) - first;
-      const int32_t seqidx = seqbyseq ? (int32_t)(key_grp(w.dat[w.seed_first[w.segm_first[first]]]) & ((1u << KEY_SEQBITS) - 1)) : -1;
       for (uint32_t i = 0; i < num;) {
         const uint32_t m0 = first + i;
         uint32_t cover = w.segm_cover[m0], j = i + 1;
@@ -262,11 +261,9 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
             cover += cover_new;
           }
         }
-        if (cover >= mincover) {
-          SegCand c;
-          if (derive_cand_c(c, w, m0, (int)(j - i), k, s, cover, mincover, reg_base + r, is_reverse, seqidx)) err = SMG_ERR_ASSERT;
-          cand_tmp[m0] = c;
-          w.cflag[m0] = 1;
+        if (cover >= mincover) {                 // the candidate record itself is derived below, one lane per candidate
+          w.reg_num[m0] = (IT)(j - i);
+          w.cflag[m0] = (uint8_t)cover;          // reads of this form have < 256 bases and cover >= mincover > 0
           if (cover > mx2) { if (cover > mx) { mx2 = mx; mx = cover; } else if (cover != mx) mx2 = cover; }
         }
         i = j;
@@ -286,21 +283,28 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
 #endif
   *max_cover_io = mx; *max2nd_io = mx2;
   *reg_base_io = reg_base + nreg;
-  if (wave_any(err != 0)) return SMG_ERR_ASSERT;
   SMG_SYNC();
   SMG_PH(4)
-  // ordered compaction of the sparse candidates
+  // candidates in segment order: one lane per candidate derives the record (derriveSEGCAND) and writes it once
   uint32_t nc = *ncand_io;
   bool ovf = false;
   SMG_PAR_CHUNKS(base, nsegm) {
     const uint32_t m = base + SMG_LANE;
     const bool f = m < nsegm && w.cflag[m];
     const uint32_t slot = compact_slot(f, nc);
-    if (f) { if (slot < candcap) cand[slot] = cand_tmp[m]; else ovf = true; }
+    if (f) {
+      uint32_t lo = 0, hi = nreg;                // hit region of segment m
+      while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)w.reg_first[mid] <= m) lo = mid; else hi = mid; }
+      const int32_t seqidx = seqbyseq ? (int32_t)(key_grp(w.dat[w.seed_first[w.segm_first[m]]]) & ((1u << KEY_SEQBITS) - 1)) : -1;
+      SegCand c;
+      if (derive_cand_c(c, w, m, (int)(uint32_t)w.reg_num[m], k, s, (uint32_t)w.cflag[m], mincover, reg_base + lo, is_reverse, seqidx)) err = SMG_ERR_ASSERT;
+      if (slot < candcap) cand[slot] = c; else ovf = true;
+    }
   }
   *ncand_io = nc;
   SMG_PH(5)
 #undef SMG_PH
+  if (wave_any(err != 0)) return SMG_ERR_ASSERT;
   if (wave_any(ovf)) return SMG_ERR_CAP;
   return 0;
 }
@@ -436,7 +440,7 @@ SMG_HD inline void dbg_hits(const CandsV2Scratch &x, const uint64_t *dat, uint32
 
 // true when the parallel form applies to this read
 SMG_HD inline bool cands_v2_applicable(const MapPar &p, int k, int s, uint32_t qlen) {
-  return qlen <= 256 && p.min_cover < (uint32_t)(k + s);     // calcMinKtup (rmap.c:240-247) gives min_ktup == 1
+  return qlen <= 255 && p.min_cover < (uint32_t)(k + s);     // calcMinKtup (rmap.c:240-247) gives min_ktup == 1; covers fit a byte
 }
 
 SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t r, CandsV2Scratch &x, unsigned long long *ph) {
