@@ -151,6 +151,7 @@ struct smaltgpu_mapper {
   CandGeom cg;
   uint8_t *cand_scr_dbg = nullptr; uint32_t cand_dbg_reads = 0;
   int *sw_rows = nullptr; uint32_t sw_rowlen = 0, sw_threads = 0;
+  void *strip_bnd = nullptr; uint8_t *strip_win = nullptr; uint32_t strip_grid = 0;   // k_sw_strip: boundary columns + decoded window per workgroup
   uint8_t *align_scr = nullptr; size_t align_bytes = 0; uint32_t align_slots = 0;
   uint32_t wincap = 0, rescap_slot = 0, dstrcap_slot = 0; uint64_t dircap = 0;
   // host mirrors
@@ -213,6 +214,9 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
   DA(b.rcpool, b.rccap);
   b.long_cap = b.rccap / 8 + 1024;
   DA(b.long_list, b.long_cap);
+  b.strip_cap = b.rccap / 8 + 1024;
+  DA(b.strip_list, b.strip_cap);
+  { int G, C; b.tile_qmax = sw_full_geometry(max_read_len, &G, &C) ? 0u : (uint32_t)(G * C); }
   b.rescap = (uint64_t)max_batch_reads * 8 + 4096;
   DA(b.respool, b.rescap);
   b.dstrcap = b.rescap * (uint64_t)(m->qmax / 4 + 48);
@@ -257,6 +261,10 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
   DA(m->sw_rows, (size_t)m->sw_threads * 2 * m->sw_rowlen);
   {
     m->wincap = 4 * m->qmax + 1024;
+    m->strip_grid = 2048;
+    if ((uint64_t)m->strip_grid * m->wincap * 17 > (4ull << 30)) m->strip_grid = (uint32_t)((4ull << 30) / ((uint64_t)m->wincap * 17));
+    if (!rv) rv = dalloc((uint8_t **)&m->strip_bnd, (size_t)m->strip_grid * 2 * m->wincap * 8);
+    DA(m->strip_win, (size_t)m->strip_grid * m->wincap);
     m->dircap = (uint64_t)(m->qmax + 64) * (m->wincap + 8);
     m->rescap_slot = 512; m->dstrcap_slot = 512 * (m->qmax / 4 + 48);
     m->align_bytes = align_scratch_bytes(m->qmax, m->wincap, m->dircap, m->rescap_slot, m->dstrcap_slot);
@@ -278,7 +286,7 @@ extern "C" void smaltgpu_mapper_free(smaltgpu_mapper *m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   void *ps[] = {m->d_bases, m->d_quals, m->d_codes, m->d_codes_rc, m->d_off, m->b.hi, m->b.seeds, m->b.qmask, m->b.ch, m->b.ctl,
-                m->b.stat, m->b.rcpool, m->b.long_list, m->b.respool, m->b.dstrpool, m->d_counters, m->seed_scr, m->cand_scr, m->cand_scr_dbg,
+                m->b.stat, m->b.rcpool, m->b.long_list, m->b.strip_list, m->strip_bnd, m->strip_win, m->b.respool, m->b.dstrpool, m->d_counters, m->seed_scr, m->cand_scr, m->cand_scr_dbg,
                 m->sw_rows, m->align_scr};
   for (void *p : ps) if (p) (void)hipFree(p);
   for (int i = 0; i <= T_NUM; i++) if (m->ev[i]) (void)hipEventDestroy(m->ev[i]);
@@ -344,6 +352,7 @@ static int run_pipeline(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_
   HIPCHK(hipEventRecord(m->ev[T_SW_FULL], s));
   if (!rv) rv = launch_sw_full(s, b, d, p, m->max_len, b.rccap, 8192);
   HIPCHK(hipEventRecord(m->ev[T_SW_SCALAR], s));
+  if (!rv) rv = launch_sw_strip(s, b, d, p, m->strip_bnd, m->strip_win, m->wincap, m->strip_grid);
   if (!rv) rv = launch_sw_scalar(s, b, d, p, m->sw_rows, m->sw_rowlen, m->sw_threads, m->max_len);
   HIPCHK(hipEventRecord(m->ev[T_REPLAY], s));
   if (!rv) rv = launch_replay(s, b, d, p);
@@ -505,7 +514,12 @@ extern "C" int smaltgpu_sw_full_batch(smaltgpu_mapper *m, const uint8_t *qcodes,
     (void)hipMemcpy(dr, rcodes, r_off[ntask], hipMemcpyHostToDevice);
     (void)hipMemcpy(dqo, q_off, ((size_t)ntask + 1) * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(dro, r_off, ((size_t)ntask + 1) * 4, hipMemcpyHostToDevice);
-    int lr = launch_sw_full_raw(m->stream, dq, dqo, dr, dro, ntask, to_par(par), dsc, qmaxlen, packed16);
+    uint32_t rmaxlen = 0;
+    for (uint32_t t = 0; t < ntask; t++) { uint32_t l = r_off[t + 1] - r_off[t]; if (l > rmaxlen) rmaxlen = l; }
+    int lr;
+    if (!packed16 && (qmaxlen > 512 || rmaxlen > (uint32_t)SW_FULL_WMAX))     // beyond the register tiling: the strip kernel (windows up to the mapper's capacity)
+      lr = launch_sw_strip_raw(m->stream, dq, dqo, dr, dro, ntask, to_par(par), dsc, m->strip_bnd, m->strip_win, m->wincap, m->strip_grid);
+    else lr = launch_sw_full_raw(m->stream, dq, dqo, dr, dro, ntask, to_par(par), dsc, qmaxlen, packed16);
     if (lr) rv = fail(SMALTGPU_EARG, lr == -2 ? "scores do not fit the packed 16-bit kernel" : "query longer than the register-tiled kernel supports");
     else if (hipStreamSynchronize(m->stream) != hipSuccess) rv = fail(SMALTGPU_ENODEV, "kernel failed");
     else (void)hipMemcpy(scores, dsc, (size_t)ntask * 4, hipMemcpyDeviceToHost);

@@ -892,9 +892,15 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
       RCand c;
       if (cand_offsets(c, x.cand[x.sort_idx[i]], ix, qlen)) { c.flags |= RCF_ERR; c.rs = c.re = 0; c.qs = c.qe = 0; c.band_l = c.band_r = 0; }
       if (qn) c.flags |= RCF_QN;
-      if (!(c.flags & RCF_ERR) && (uint32_t)(c.re - c.rs + 1) > 248u) {                 // SW_SHORT_WMAX: listed for the large-LDS instance of K2a
-        const unsigned long long li = atomic_add_u64(b.work + WK_LONG_TASKS, 1ull);
-        if (b.long_list && li < b.long_cap) b.long_list[li] = rc_off + i;
+      if (!(c.flags & (RCF_ERR | RCF_BANDED))) {          // K2a task: which instance scores it (smg_kernels.hip)
+        const uint32_t wl_ = (uint32_t)(c.re - c.rs + 1);
+        if (qlen > b.tile_qmax || wl_ > 1016u) {           // SW_FULL_WMAX: strip kernel
+          const unsigned long long li = atomic_add_u64(b.work + WK_STRIP_TASKS, 1ull);
+          if (b.strip_list && li < b.strip_cap) b.strip_list[li] = rc_off + i;
+        } else if (wl_ > 248u) {                            // SW_SHORT_WMAX: large-LDS instance of the packed kernel
+          const unsigned long long li = atomic_add_u64(b.work + WK_LONG_TASKS, 1ull);
+          if (b.long_list && li < b.long_cap) b.long_list[li] = rc_off + i;
+        }
       }
       c.rid = r; c.pad = 0;
       b.rcpool[rc_off + i] = c;

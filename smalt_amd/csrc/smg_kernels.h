@@ -29,6 +29,9 @@ int launch_align(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar
                  uint32_t wincap, uint64_t dircap, uint32_t rescap, uint32_t dstrcap);
 int sw_full_geometry(uint32_t qmax_len, int *G, int *C);
 int launch_sw_full(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t qmax_len, uint32_t ntask_cap, uint32_t grid);
+int launch_sw_strip(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, void *bnd, uint8_t *win, uint32_t wcap, uint32_t grid);
+int launch_sw_strip_raw(hipStream_t s, const uint8_t *q, const uint32_t *qo, const uint8_t *r, const uint32_t *ro, uint32_t n, const MapPar &p,
+                        int32_t *sc, void *bnd, uint8_t *win, uint32_t wcap, uint32_t grid);
 int launch_sw_scalar(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, int *rows, uint32_t rowlen, uint32_t nthreads,
                      uint32_t qmax_len);
 int launch_sw_full_raw(hipStream_t s, const uint8_t *q, const uint32_t *qo, const uint8_t *r, const uint32_t *ro, uint32_t n,

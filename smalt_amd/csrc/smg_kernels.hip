@@ -451,6 +451,162 @@ __global__ void __launch_bounds__(64) k_sw_full16_raw(const uint8_t *qcodes, con
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// K2a for reads or windows beyond the register tiling (long reads): one wave per task.  The read is cut
+// into strips of 64 x SW_STRIP_C columns (lane g owns SW_STRIP_C consecutive columns of the strip) and the
+// window is swept once per strip, lane g one row behind lane g-1 (DPP wave_shr:1 hands over H of the last
+// column and the running F).  H and F of a strip's last column go, row by row, through an LDS ring into a
+// boundary buffer in HBM that feeds lane 0 of the next strip (read back 64 rows at a time, ahead of use).
+// 32-bit lanes, full 8-byte score rows: any code (N) and any score below 2^31.
+// ---------------------------------------------------------------------------------------
+enum : int { SW_STRIP_C = 16 };
+__device__ inline int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true); }
+
+// win: window codes (HBM, wlen bytes), bnd: 2 x wcap (H, F) pairs of this workgroup
+__device__ inline int sw_strip_core(const uint8_t *q, uint32_t qlen, const uint8_t *win, uint32_t wlen, int2 *bnd, uint32_t wcap,
+                                    const uint2 *tab, int2 *ring /* LDS [256] */, int bias, int gi, int ge) {
+  constexpr int C = SW_STRIP_C;
+  const int g = (int)threadIdx.x;
+  int2 *ring_in = ring, *ring_out = ring + 128;
+  int best = 0;
+  const uint32_t nstrip = (qlen + 64 * C - 1) / (64 * C);
+  const int nstep = (int)wlen + 63;
+  for (uint32_t sidx = 0; sidx < nstrip; sidx++) {
+    const int2 *bprev = bnd + (size_t)((sidx + 1) & 1) * wcap;
+    int2 *bnext = bnd + (size_t)(sidx & 1) * wcap;
+    uint32_t sel[C];
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) {
+      const uint32_t j = sidx * 64 * C + (uint32_t)(g * C + cc);
+      sel[cc] = 0x0c0c0c00u | (j < qlen ? (uint32_t)(q[j] & 7) : 5u);
+    }
+    int H[C], E[C];
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) { H[cc] = 0; E[cc] = 0; }
+    int F = 0, prev_hl = 0;
+    __syncthreads();
+    if (sidx > 0) {                                  // first 64 boundary rows of the previous strip
+      const int r0 = g;
+      ring_in[g] = r0 < (int)wlen ? bprev[r0] : make_int2(0, 0);
+    }
+    __syncthreads();
+    for (int step = 0; step < nstep; step++) {
+      const int row = step - g;
+      if (sidx > 0 && (step & 63) == 0) {            // read ahead: boundary rows step+64 .. step+127
+        const int r1 = step + 64 + g;
+        ring_in[((step >> 6) + 1) % 2 * 64 + g] = r1 < (int)wlen ? bprev[r1] : make_int2(0, 0);
+      }
+      const uint32_t rb = (row >= 0 && row < (int)wlen) ? win[row] : 5u;
+      const uint2 tr = tab[rb];
+      int hl = wave_shr1(H[C - 1]);
+      int fin = wave_shr1(F);
+      if (g == 0) {
+        if (sidx > 0) { const int2 v = ring_in[(step >> 6) % 2 * 64 + (step & 63)]; hl = step < (int)wlen ? v.x : 0; fin = step < (int)wlen ? v.y : 0; }
+        else { hl = 0; fin = 0; }
+      }
+      int diag = prev_hl;
+      prev_hl = hl;
+      F = fin;
+#pragma unroll
+      for (int cc = 0; cc < C; cc++) {
+        const int w = (int)__builtin_amdgcn_perm(tr.y, tr.x, sel[cc]);
+        const int h = diag + w - bias;
+        const int hh = max(max(h, E[cc]), F);
+        best = max(best, hh);
+        diag = H[cc];
+        H[cc] = hh;
+        const int tt = hh - gi;
+        E[cc] = max(max(E[cc] - ge, tt), 0);
+        F = max(max(F - ge, tt), 0);
+      }
+      if (sidx + 1 < nstrip) {                       // hand the last column to the next strip
+        if (g == 63 && row >= 0 && row < (int)wlen) ring_out[row & 127] = make_int2(H[C - 1], F);
+        const int rdone = step - 63;                 // row lane 63 has just finished
+        if (rdone >= 0 && ((rdone & 63) == 63 || rdone == (int)wlen - 1)) {
+          __syncthreads();
+          const int base = rdone & ~63, r2 = base + g;
+          if (r2 <= rdone && r2 < (int)wlen) bnext[r2] = ring_out[r2 & 127];
+        }
+      }
+      if (sidx > 0 && (step & 63) == 63) __syncthreads();   // the read-ahead chunk is in place before lane 0 turns to it
+    }
+    __threadfence();
+  }
+  for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
+  return best;
+}
+
+__device__ inline void sw_tab8(uint2 *tab, const MapPar &p, int bias) {
+  if (threadIdx.x < 8) {                     // biased score matrix rows (score.c:138-173; rows 4,6 = N, 7 = A)
+    const int lane = (int)threadIdx.x;
+    const int rb = lane == 7 ? 0 : ((lane == 6 || lane == 4) ? 5 : lane);
+    uint32_t w[2] = {0, 0};
+    for (int qc = 0; qc < 8; qc++) {
+      const int v = (rb == 5 || qc >= 4) ? 0 : ((rb == qc) ? p.match : p.mismatch);
+      w[qc >> 2] |= (uint32_t)((v + bias) & 0xff) << (8 * (qc & 3));
+    }
+    tab[lane] = make_uint2(w[0], w[1]);
+  }
+}
+
+// tasks: the strip list S7 made (ranked candidates whose read or window exceeds the register tiling)
+__global__ void __launch_bounds__(64) k_sw_strip(Batch b, DevIndex ix, MapPar p, int2 *bnd_all, uint8_t *win_all, uint32_t wcap) {
+  const unsigned long long nlist = b.work[WK_STRIP_TASKS];
+  if (nlist == 0) return;
+  __shared__ uint2 tab[8];
+  __shared__ int2 ring[256];
+  const int bias = (p.mismatch < p.mismatch - p.match ? -p.mismatch : -(p.mismatch - p.match));
+  sw_tab8(tab, p, bias);
+  __syncthreads();
+  const bool listed = b.strip_list && nlist <= b.strip_cap;
+  const uint32_t ntask = listed ? (uint32_t)nlist : min(*b.rc_count, b.rccap);
+  int2 *bnd = bnd_all + (size_t)blockIdx.x * 2 * wcap;
+  uint8_t *win = win_all + (size_t)blockIdx.x * wcap;
+  unsigned long long cells = 0, ntasks_done = 0;
+  for (uint32_t tl = blockIdx.x; tl < ntask; tl += gridDim.x) {
+    const uint32_t t = listed ? b.strip_list[tl] : tl;
+    const RCand c = b.rcpool[t];
+    const uint32_t qlen = read_len(b, c.rid), wlen = (uint32_t)(c.re - c.rs + 1);
+    if ((c.flags & (RCF_BANDED | RCF_ERR | RCF_SCORED)) || wlen > wcap) continue;     // wave-uniform
+    const uint64_t gbase = (c.sqidx < 0 ? 0ull : ix.sop[c.sqidx]) + c.rs;
+    const uint8_t *q = ((c.flags & RCF_REVERSE) ? b.codes_rc : b.codes) + b.read_off[c.rid];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < wlen; i += 64) win[i] = (uint8_t)ref_code(ix.packed, gbase + i);
+    __threadfence();
+    __syncthreads();
+    const int best = sw_strip_core(q, qlen, win, wlen, bnd, wcap, tab, ring, bias, -p.gap_init, -p.gap_ext);
+    if (threadIdx.x == 0) {
+      b.rcpool[t].swscor = best;
+      b.rcpool[t].flags = c.flags | RCF_SCORED | (best >= 65535 ? RCF_BANDED : 0u);   // ERRCODE_SWATEXCEED -> K2b
+      cells += (unsigned long long)qlen * wlen;
+      ntasks_done++;
+    }
+  }
+  if (threadIdx.x == 0 && cells) { atomicAdd(b.work + WK_CELLS_FULL, cells); atomicAdd(b.work + WK_TASKS_FULL, ntasks_done); }
+}
+
+// stand-alone form over explicit code arrays (parity tests)
+__global__ void __launch_bounds__(64) k_sw_strip_raw(const uint8_t *qcodes, const uint32_t *q_off, const uint8_t *rcodes, const uint32_t *r_off,
+                                                     uint32_t ntask, MapPar p, int32_t *scores, int2 *bnd_all, uint8_t *win_all, uint32_t wcap) {
+  __shared__ uint2 tab[8];
+  __shared__ int2 ring[256];
+  const int bias = (p.mismatch < p.mismatch - p.match ? -p.mismatch : -(p.mismatch - p.match));
+  sw_tab8(tab, p, bias);
+  __syncthreads();
+  int2 *bnd = bnd_all + (size_t)blockIdx.x * 2 * wcap;
+  uint8_t *win = win_all + (size_t)blockIdx.x * wcap;
+  for (uint32_t t = blockIdx.x; t < ntask; t += gridDim.x) {
+    const uint32_t qlen = q_off[t + 1] - q_off[t], wlen = r_off[t + 1] - r_off[t];
+    if (wlen > wcap) { if (threadIdx.x == 0) scores[t] = -1; continue; }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < wlen; i += 64) { const uint32_t cd = rcodes[r_off[t] + i] & 7; win[i] = (uint8_t)(cd == 7 ? 0 : (cd == 6 || cd == 4) ? 5 : cd); }
+    __threadfence();
+    __syncthreads();
+    const int best = sw_strip_core(qcodes + q_off[t], qlen, win, wlen, bnd, wcap, tab, ring, bias, -p.gap_init, -p.gap_ext);
+    if (threadIdx.x == 0) scores[t] = best;
+  }
+}
+
 // K2a for tasks the register-tiled kernel does not cover (long reads / long windows) and
 // K2b (banded score-only pass, alignment.c:1029) -- one lane per task, rows in HBM scratch.
 __global__ void __launch_bounds__(64) k_sw_scalar(Batch b, DevIndex ix, MapPar p, int *rows, uint32_t rowlen, int full_gc) {
@@ -646,6 +802,21 @@ int launch_sw_full(hipStream_t s, const Batch &b, const DevIndex &ix, const MapP
   else if (G == 8) launch_sw_full_t<8, 20>(s, b, ix, p, ntask_cap, grid);
   else if (C == 16) launch_sw_full_t<16, 16>(s, b, ix, p, ntask_cap, grid);
   else launch_sw_full_t<16, 32>(s, b, ix, p, ntask_cap, grid);
+  SMG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_sw_strip(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, void *bnd, uint8_t *win, uint32_t wcap, uint32_t grid) {
+  if (!b.nreads || !grid) return 0;
+  hipLaunchKernelGGL(k_sw_strip, dim3(grid), dim3(64), 0, s, b, ix, p, (int2 *)bnd, win, wcap);
+  SMG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_sw_strip_raw(hipStream_t s, const uint8_t *q, const uint32_t *qo, const uint8_t *r, const uint32_t *ro, uint32_t n, const MapPar &p,
+                        int32_t *sc, void *bnd, uint8_t *win, uint32_t wcap, uint32_t grid) {
+  if (!n) return 0;
+  hipLaunchKernelGGL(k_sw_strip_raw, dim3(n < grid ? n : grid), dim3(64), 0, s, q, qo, r, ro, n, p, sc, (int2 *)bnd, win, wcap);
   SMG_LAUNCH_CHECK();
   return 0;
 }

@@ -28,6 +28,8 @@ struct Batch {                          // one block of reads resident in HBM
   CandHdr *ch;                          // [nreads]
   RCand *rcpool; uint32_t rccap; uint32_t *rc_count;    // bump-allocated ranked candidates
   uint32_t *long_list; uint32_t long_cap;               // ranked candidates with windows > SW_SHORT_WMAX (count: work[WK_LONG_TASKS])
+  uint32_t *strip_list; uint32_t strip_cap;             // ... whose read or window exceeds the register tiling (work[WK_STRIP_TASKS])
+  uint32_t tile_qmax;                                   // longest read the register-tiled K2a kernels of this mapper take (0: none)
   // O1
   ReadCtl *ctl;                         // [nreads]
   // K3 outputs
@@ -39,7 +41,7 @@ struct Batch {                          // one block of reads resident in HBM
   unsigned long long *work;             // [WK_NWORK] work counters (WK_*), one atomic per workgroup
 };
 enum : int { WK_LOOKUPS = 0, WK_HITS = 1, WK_CELLS_FULL = 2, WK_TASKS_FULL = 3, WK_CELLS_BAND = 4, WK_NCAND = 5, WK_NKEPT = 6,
-              WK_QN_TASKS = 7 /* ranked candidates of reads with non-ACGT codes */, WK_LONG_TASKS = 17 /* windows > SW_SHORT_WMAX */,
+              WK_QN_TASKS = 7 /* ranked candidates of reads with non-ACGT codes */, WK_LONG_TASKS = 17 /* windows > SW_SHORT_WMAX */, WK_STRIP_TASKS = 18 /* beyond the register tiling */,
               WK_PHASE0 = 8 /* .. 23: shader-clock ticks per phase of k_cands (diagnostic) */, WK_NWORK = 24 };
 
 // The score kernels walk the candidate pool linearly.  A read whose ranked candidates do not fit keeps none
@@ -503,9 +505,15 @@ SMG_HD inline uint32_t stage_cands(const Batch &b, const DevIndex &ix, const Map
       RCand c;
       if (cand_offsets(c, x.cand[x.sort_idx[i]], ix, qlen)) { c.flags |= RCF_ERR; c.rs = c.re = 0; c.qs = c.qe = 0; c.band_l = c.band_r = 0; }
       if (qn) c.flags |= RCF_QN;
-      if (!(c.flags & RCF_ERR) && (uint32_t)(c.re - c.rs + 1) > 248u) {                 // SW_SHORT_WMAX: listed for the large-LDS instance of K2a
-        const unsigned long long li = atomic_add_u64(b.work + WK_LONG_TASKS, 1ull);
-        if (b.long_list && li < b.long_cap) b.long_list[li] = rc_off + i;
+      if (!(c.flags & (RCF_ERR | RCF_BANDED))) {          // K2a task: which instance scores it (smg_kernels.hip)
+        const uint32_t wl_ = (uint32_t)(c.re - c.rs + 1);
+        if (qlen > b.tile_qmax || wl_ > 1016u) {           // SW_FULL_WMAX: strip kernel
+          const unsigned long long li = atomic_add_u64(b.work + WK_STRIP_TASKS, 1ull);
+          if (b.strip_list && li < b.strip_cap) b.strip_list[li] = rc_off + i;
+        } else if (wl_ > 248u) {                            // SW_SHORT_WMAX: large-LDS instance of the packed kernel
+          const unsigned long long li = atomic_add_u64(b.work + WK_LONG_TASKS, 1ull);
+          if (b.long_list && li < b.long_cap) b.long_list[li] = rc_off + i;
+        }
       }
       c.rid = r; c.pad = 0;
       b.rcpool[rc_off + i] = c;

@@ -100,7 +100,7 @@ int main(int argc, char **argv) {
   b.rc_count = &rc_count; b.ctl = ctl.data(); b.stat = stat.data(); b.respool = respool.data(); b.rescap = respool.size();
   b.res_count = &res_count; b.dstrpool = dstrpool.data(); b.dstrcap = dstrpool.size(); b.dstr_count = &dstr_count; b.err_flag = &err_flag;
   unsigned long long workctr[WK_NWORK] = {0};
-  b.work = workctr; b.long_list = nullptr; b.long_cap = 0;
+  b.work = workctr; b.long_list = nullptr; b.long_cap = 0; b.strip_list = nullptr; b.strip_cap = 0; b.tile_qmax = 512;
 
   std::vector<uint8_t> sscr(seed_scratch_bytes(qmax, ix.s));
   const uint32_t hcap = 1u << 16, segcap = 1u << 15, candcap = 1u << 16;

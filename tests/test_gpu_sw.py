@@ -69,3 +69,34 @@ def test_sw_full_kernel_matches_oracle(qlo, qhi, oracle_built):
         mp.close()
         gix.close()
         ol.lib().or_index_free(oix)
+
+
+@pytest.mark.parametrize("qlo,qhi,ntask", [(513, 1024, 60), (1025, 2300, 40), (40, 300, 60)])
+def test_sw_strip_kernel_matches_oracle(qlo, qhi, ntask, oracle_built):
+    """K2a beyond the register tiling: strips of 1024 read columns with the boundary column handed from strip to strip
+    (1, 2 and 3 strips); the third case forces short reads with windows > 1016 through the same kernel."""
+    from smalt_amd import api
+    rng = np.random.default_rng(qlo * 31 + qhi)
+    seqs = [bytes(rng.choice(list(b"ACGT"), size=4000).astype(np.uint8))]
+    oix = ol.build_index(seqs, ["s"], 11, 3)
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        pre = os.path.join(tmp, "x")
+        ol.lib().or_index_write(oix, pre.encode())
+        gix = api.Index.load(pre, 0)
+    mp = api.Mapper(gix, 16, 2400)
+    par = gix.default_params()
+    M = (C.c_int8 * 64)()
+    ol.lib().or_score_matrix(M, 1, -2)
+    try:
+        qs, ws = _pairs(rng, ntask, qlo, qhi, True)
+        if qhi <= 512:          # long windows for short reads
+            ws = [w + bytes(rng.integers(0, 4, size=1100, dtype=np.uint8)) for w in ws]
+        got = mp.sw_full_batch(qs, ws, par)
+        for i, (q, w) in enumerate(zip(qs, ws)):
+            exp = ol.lib().or_sw_full(q, len(q), w, len(w), M, -4, -3)
+            assert got[i] == exp, (i, len(q), len(w), got[i], exp)
+    finally:
+        mp.close()
+        gix.close()
+        ol.lib().or_index_free(oix)
