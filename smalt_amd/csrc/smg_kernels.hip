@@ -96,6 +96,7 @@ __global__ void __launch_bounds__(256) k_replay(Batch b, DevIndex ix, MapPar p) 
 }
 
 // K3: one wave per read; hot arrays in LDS, results and oversized direction matrices in the HBM slot
+template <bool WIDE>
 __global__ void __launch_bounds__(64) k_align(Batch b, DevIndex ix, MapPar p, uint8_t *gscratch, size_t gbytes, uint32_t wincap,
                                               uint64_t dircap, uint32_t rescap, uint32_t dstrcap, uint32_t lds_bytes) {
   extern __shared__ __align__(16) uint8_t lds[];
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(64) k_align(Batch b, DevIndex ix, MapPar p, ui
   AlignScratch x = align_scratch_carve_lds(lds_bytes ? lds + LDS_GUARD : nullptr, lds_bytes, base, b.qmax, wincap, dircap, rescap, dstrcap);
   __shared__ uint32_t qslot;
   for (uint32_t r = next_item(b.next_item + 2, &qslot); r < b.nreads; r = next_item(b.next_item + 2, &qslot)) {
-    stage_align(b, ix, p, r, x);
+    stage_align<WIDE>(b, ix, p, r, x);
     __syncthreads();
   }
 }
@@ -760,7 +761,8 @@ int launch_align(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar
   size_t small = align_lds_small_bytes(b.qmax, wincap);
   static const uint32_t lds_kb = getenv("SMALTGPU_ALIGN_LDS_KB") ? (uint32_t)atoi(getenv("SMALTGPU_ALIGN_LDS_KB")) : 8u;   // tuning hook; 8 KB = 20 workgroups per CU
   uint32_t lds_bytes = small + 4096 <= lds_kb * 1024 ? lds_kb * 1024 - LDS_GUARD : 0;      // rows + window + direction bytes
-  hipLaunchKernelGGL(k_align, dim3(grid), dim3(64), lds_bytes ? lds_bytes + LDS_GUARD : 0, s, b, ix, p, scratch, sbytes, wincap, dircap, rescap, dstrcap, lds_bytes);
+  if (b.qmax > 256) hipLaunchKernelGGL(k_align<true>, dim3(grid), dim3(64), lds_bytes ? lds_bytes + LDS_GUARD : 0, s, b, ix, p, scratch, sbytes, wincap, dircap, rescap, dstrcap, lds_bytes);
+  else hipLaunchKernelGGL(k_align<false>, dim3(grid), dim3(64), lds_bytes ? lds_bytes + LDS_GUARD : 0, s, b, ix, p, scratch, sbytes, wincap, dircap, rescap, dstrcap, lds_bytes);
   SMG_LAUNCH_CHECK();
   return 0;
 }

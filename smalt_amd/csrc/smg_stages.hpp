@@ -789,8 +789,74 @@ __device__ inline int band_track_wave(const Band &bp, const uint8_t *q, const ui
   *max_j = best > 0 ? bj : 0;
   return best;
 }
+
+// The same for wider bands.  Columns jmin + c + 64m of lane c that are inside the band at step t differ by 128
+// diagonals, so a lane has at most (r - l) / 128 + 1 live columns; column m keeps its state in register slot m % NS.
+// The left neighbour of (lane c, slot s) is (lane c - 1, slot s), for lane 0 (lane 63, slot s - 1).
+template <int NS>
+__device__ inline int band_track_wave_n(const Band &bp, const uint8_t *q, const uint8_t *win, int match, int mismatch, int gi, int ge,
+                                        uint8_t *dir, int *max_i, int *max_j) {
+  const int lane = (int)threadIdx.x;
+  const int nrows = bp.s_len - bp.s_left, l = bp.l_edge, r = bp.r_edge, bw = bp.band_width;
+  const int jmin = bp.q_left > l ? bp.q_left : l;
+  int jlast = r + nrows - 1; if (jlast > bp.q_len - 1) jlast = bp.q_len - 1;
+  const int tmax = (nrows - 1) + (jlast - jmin);
+  int Hcol[NS], Ecol[NS], Hprev[NS], Fout[NS], lastrow[NS], lastcol[NS], qc[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) { Hcol[s] = Ecol[s] = Hprev[s] = Fout[s] = 0; lastrow[s] = -2; lastcol[s] = -1; qc[s] = 5; }
+  int best = 0, bi = 0, bj = 0;
+  for (int t = 0; t <= tmax; t++) {
+    int nH[NS], nHp[NS], nF[NS], nrow[NS], ncol[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) { nH[s] = wave_ror1(Hcol[s]); nHp[s] = wave_ror1(Hprev[s]); nF[s] = wave_ror1(Fout[s]); nrow[s] = wave_ror1(lastrow[s]); ncol[s] = wave_ror1(lastcol[s]); }
+    const int x0 = t + l - jmin - 2 * lane, x1 = t + r - jmin - 2 * lane;
+    const int mlo = x0 <= 0 ? 0 : (x0 + 127) >> 7;
+    const int mhi = x1 < 0 ? -1 : x1 >> 7;
+    const int mlo_s = mlo % NS;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      const int m = mlo + (s - mlo_s + NS) % NS;
+      const int j = jmin + lane + 64 * m;
+      const int ip = t - (j - jmin);
+      const bool act = m <= mhi && ip >= 0 && ip < nrows && j <= jlast && (j - ip) <= r && (j - ip) >= l;
+      if (act) {
+        if (j != lastcol[s]) { Hcol[s] = 0; Ecol[s] = 0; Hprev[s] = 0; qc[s] = q[j] & 7; }
+        constexpr int SP = 0;   // (placeholder to keep the slot arithmetic below compile-time)
+        (void)SP;
+        const int sp = (s + NS - 1) % NS;
+        const int vH = lane ? nH[s] : nH[sp], vHp = lane ? nHp[s] : nHp[sp], vF = lane ? nF[s] : nF[sp];
+        const int vrow = lane ? nrow[s] : nrow[sp], vcol = lane ? ncol[s] : ncol[sp];
+        int diag = 0, F = 0;
+        if (vcol == j - 1) {
+          if (vrow == ip) { diag = vHp; F = vF; }
+          else if (vrow == ip - 1) diag = vH;
+        }
+        const int rb = win[bp.s_left + ip] & 7;
+        const int w = (rb >= 4 || qc[s] >= 4) ? 0 : (rb == qc[s] ? match : mismatch);
+        const int Hin = diag + w;
+        int Hnew;
+        bool cand;
+        const int hb = Hcol[s];
+        const int d = cell_update(Hnew, Ecol[s], F, Hin, gi, ge, cand);
+        Hprev[s] = hb; Hcol[s] = Hnew; Fout[s] = F; lastrow[s] = ip; lastcol[s] = j;
+        dir[(size_t)ip * (size_t)(bw - 1) + (size_t)(j - l)] = (uint8_t)d;
+        if (cand && (Hin > best || (Hin == best && (ip < bi || (ip == bi && j < bj))))) { best = Hin; bi = ip; bj = j; }
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const int ob = __shfl_xor(best, o), oi = __shfl_xor(bi, o), oj = __shfl_xor(bj, o);
+    if (ob > best || (ob == best && (oi < bi || (oi == bi && oj < bj)))) { best = ob; bi = oi; bj = oj; }
+  }
+  *max_i = best > 0 ? bp.s_left + bi : 0;
+  *max_j = best > 0 ? bj : 0;
+  return best;
+}
 #endif
 
+// WIDE: also instantiate the multi-column wave form for bands of more than 64 columns (long reads); it needs many
+// registers, so mappers for short reads use the lean instance and leave the rare wide band to the sequential form.
+template <bool WIDE = false>
 SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t r, AlignScratch &x) {
   const uint32_t qlen = read_len(b, r);
   const CandHdr ch = b.ch[r];
@@ -871,8 +937,17 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
       int max_i = 0, max_j = 0, max_scor = 0;
       if (!nerr && !skip) {
 #if defined(__HIP_DEVICE_COMPILE__)
+        const int nslot = band.band_width >= 1 ? (band.r_edge - band.l_edge) / 128 + 1 : 0;    // live columns per lane
         if (band.band_width >= 1 && band.band_width <= 64) {
           max_scor = band_track_wave(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j);
+        } else if (WIDE && nslot >= 1 && nslot <= 2) {
+          max_scor = band_track_wave_n<2>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j);
+        } else if (WIDE && nslot >= 1 && nslot <= 4) {
+          max_scor = band_track_wave_n<4>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j);
+        } else if (WIDE && nslot >= 1 && nslot <= 7) {
+          max_scor = band_track_wave_n<7>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j);
+        } else if (WIDE && nslot >= 1 && nslot <= 12) {
+          max_scor = band_track_wave_n<12>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j);
         } else {
           SMG_LANE0 { x.state[8] = band_track_scalar(band, q, win, M, gi, ge, x.Hp, x.Ep, dirm, &max_i, &max_j); x.state[9] = max_i; x.state[10] = max_j; }
           SMG_SYNC();

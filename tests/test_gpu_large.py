@@ -153,3 +153,50 @@ def test_candidate_pool_overflow_is_reported_per_read(oracle_built, tmp_path, mo
     finally:
         mp.close()
         gix.close()
+
+
+def test_long_reads_match_oracle(oracle_built, tmp_path):
+    """BASELINE configs[4] shape in small: 1.5 kbp reads with 3/5/4 % substitutions/insertions/deletions, k=20 s=13
+    (HASH32MIX with nbits_perf): sequential candidate stage, strip K2a kernel, wide-band K3."""
+    from smalt_amd import api, synth
+    ch = synth.make_reference(3, 700_000, seed=51, repeat_frac=0.1, n_fam=3, cons_len=400, divergence=0.05)
+    rng = np.random.default_rng(52)
+    seqs = [synth.codes_to_ascii(c) for c in ch]
+    rb = []
+    for i in range(14):
+        c = int(rng.integers(0, 3)); p = int(rng.integers(0, 700_000 - 1700))
+        src = bytearray(seqs[c][p:p + 1500])
+        out = bytearray()
+        for ch_ in src:
+            u = rng.random()
+            if u < 0.03:
+                out.append(b"ACGT"[int(rng.integers(0, 4))])
+            elif u < 0.08:
+                out.append(ch_); out.append(b"ACGT"[int(rng.integers(0, 4))])
+            elif u < 0.12:
+                continue
+            else:
+                out.append(ch_)
+        r = bytes(out)
+        if i % 2:
+            r = r[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
+        rb.append(r)
+    oix0 = ol.build_index(seqs, ["c%d" % i for i in range(3)], 20, 13)
+    pre = str(tmp_path / "long")
+    assert ol.lib().or_index_write(oix0, pre.encode()) == 0
+    oix = ol.lib().or_index_read(pre.encode())
+    exp = _oracle_map_all(oix, rb, ol.default_params(oix))
+    gix = api.Index.load(pre, 0)
+    mp = api.Mapper(gix, len(rb), max(len(r) for r in rb))
+    try:
+        res, stats = mp.map_batch(rb, [b"5" * len(r) for r in rb], gix.default_params())
+        ms, _ = mp.timers()
+        print("long-read kernel ms:", {k_: round(v, 2) for k_, v in ms.items()})
+    finally:
+        mp.close()
+        gix.close()
+    for i in range(len(rb)):
+        assert stats[i]["err"] == 0
+        assert res[i] == exp[i][0], i
+        for kk, v in exp[i][1].items():
+            assert stats[i][kk] == v, (i, kk)
