@@ -41,7 +41,7 @@ def parse_args():
     ap.add_argument("--chr-mbp", type=float, default=125.0)
     ap.add_argument("--reads", type=int, default=1_000_000)
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--sub-batch", type=int, default=131072)
+    ap.add_argument("--sub-batch", type=int, default=262144)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-buffers", action="store_true", help="also time smaltgpu_map_batch on pageable host buffers (PCIe-inclusive rate, extra field)")
     ap.add_argument("--cpu-sample", type=int, default=150000)

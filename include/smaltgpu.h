@@ -65,6 +65,7 @@ typedef struct smaltgpu_params {
   int32_t target_depth, max_depth;   /* 512, 2048 (smalt.c:60-61) */
   uint32_t rmapflg;                  /* SMALTGPU_FLG_* */
   int32_t match, mismatch, gap_init, gap_ext;  /* +1 -2 -4 -3 */
+  double min_cover_frac;             /* -c below 1.01: > 0 overrides min_cover with (uint32_t)(frac * read length) per read (smalt.c:1113-1122) */
 } smaltgpu_params;
 
 /* One alignment as left by resultSetAddFromAli (results.c:1852) before sorting/MAPQ. */

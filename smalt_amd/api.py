@@ -35,7 +35,7 @@ class Params(C.Structure):
     _fields_ = [("ktuple_maxhit", C.c_int32), ("min_cover", C.c_uint32), ("min_swatscor", C.c_int32),
                 ("min_swatscor_below_max", C.c_int32), ("min_basqval", C.c_int32), ("target_depth", C.c_int32),
                 ("max_depth", C.c_int32), ("rmapflg", C.c_uint32), ("match", C.c_int32), ("mismatch", C.c_int32),
-                ("gap_init", C.c_int32), ("gap_ext", C.c_int32)]
+                ("gap_init", C.c_int32), ("gap_ext", C.c_int32), ("min_cover_frac", C.c_double)]
 
 
 class Result(C.Structure):

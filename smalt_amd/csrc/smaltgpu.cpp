@@ -302,6 +302,7 @@ extern "C" int smaltgpu_set_debug(smaltgpu_mapper *m, int level) {
 
 static MapPar to_par(const smaltgpu_params *p) {
   MapPar q;
+  q.cov_frac = p->min_cover_frac > 0.0 ? p->min_cover_frac : 0.0;
   q.ncut = p->ktuple_maxhit; q.min_cover = p->min_cover; q.min_swatscor = p->min_swatscor; q.below_max = p->min_swatscor_below_max;
   q.min_basq = p->min_basqval; q.target_depth = p->target_depth; q.max_depth = p->max_depth; q.flags = p->rmapflg;
   q.match = p->match; q.mismatch = p->mismatch; q.gap_init = p->gap_init; q.gap_ext = p->gap_ext;

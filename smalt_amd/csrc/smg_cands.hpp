@@ -440,7 +440,7 @@ SMG_HD inline void dbg_hits(const CandsV2Scratch &x, const uint64_t *dat, uint32
 
 // true when the parallel form applies to this read
 SMG_HD inline bool cands_v2_applicable(const MapPar &p, int k, int s, uint32_t qlen) {
-  return qlen <= 255 && p.min_cover < (uint32_t)(k + s);     // calcMinKtup (rmap.c:240-247) gives min_ktup == 1; covers fit a byte
+  return qlen <= 255 && read_min_cover(p, qlen) < (uint32_t)(k + s);     // calcMinKtup (rmap.c:240-247) gives min_ktup == 1; covers fit a byte
 }
 
 SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t r, CandsV2Scratch &x, unsigned long long *ph) {

@@ -62,6 +62,7 @@ struct MapPar {                   // scalar arguments of rmapSingle (rmap.h:127-
   int32_t min_swatscor, below_max, min_basq, target_depth, max_depth;
   uint32_t flags;
   int32_t match, mismatch, gap_init, gap_ext;   // signed scores (-4/-3 for gaps)
+  double cov_frac;                              // > 0: min_cover = (uint32_t)(cov_frac * read length) per read (smalt.c:1113-1122)
 };
 
 struct SeedRec { uint32_t posidx, nhits, qoffs; };                 // hashhit.c:148-162

@@ -57,6 +57,12 @@ SMG_HD inline void rc_pool_fill_inert(const Batch &b, uint32_t rc_off, uint32_t 
   }
 }
 
+// covermin_tuple of this read (smalt.c:1113-1126): a fraction of the read length (-c below 1.01) or an absolute number
+SMG_HD inline uint32_t read_min_cover(const MapPar &p, uint32_t qlen) {
+  if (p.cov_frac > 0.0) { uint32_t c = (uint32_t)(p.cov_frac * qlen); return c > qlen ? qlen : c; }
+  return p.min_cover;
+}
+
 SMG_HD inline uint32_t read_len(const Batch &b, uint32_t r) { return (uint32_t)(b.read_off[r + 1] - b.read_off[r]); }
 
 SMG_HD inline uint32_t atomic_add_u32(uint32_t *p, uint32_t v) {
@@ -299,7 +305,7 @@ SMG_HD inline uint32_t stage_cands(const Batch &b, const DevIndex &ix, const Map
     return 0;
   }
   // calcMinKtup (rmap.c:240-247) and the coverage threshold of mapSingleRead (:1283-1289)
-  uint32_t min_cover = p.min_cover;
+  uint32_t min_cover = read_min_cover(p, qlen);
   const uint32_t min_ktup = (min_cover >= (uint32_t)(k + s)) ? (min_cover - (uint32_t)k) / (uint32_t)s : 1u;
   min_cover = (min_ktup - 1) * (uint32_t)s + (uint32_t)k;
   const int mismatchdiff = p.match - p.mismatch;

@@ -32,6 +32,7 @@ CONFIGS = [
     dict(tag="g_k13s6_nq", nchr=3, chrlen=100000, k=13, s=6, nreads=200, rlen=150, rep=0.15, opts="-q 5", nfrac=0.02, qualmix=True, varlen=True),
     dict(tag="g_k13s6_x", nchr=2, chrlen=100000, k=13, s=6, nreads=120, rlen=150, rep=0.15, opts="-x"),
     dict(tag="g_k13s3_short", nchr=2, chrlen=150000, k=13, s=3, nreads=200, rlen=36, rep=0.0, opts="", varlen=True),
+    dict(tag="g_k13s6_c05", nchr=2, chrlen=100000, k=13, s=6, nreads=150, rlen=150, rep=0.15, opts="-c 0.5", varlen=True),
 ]
 
 

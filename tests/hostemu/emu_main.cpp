@@ -53,7 +53,7 @@ int main(int argc, char **argv) {
   ix.idx = hix.idx.data(); ix.pos = hix.pos.data(); ix.wordidx = hix.wordidx.data(); ix.posidx = hix.posidx.data();
   ix.packed = hix.packed.data(); ix.sop = hix.sop.data(); ix.seqlo = seqlo.data(); ix.nseq = (int32_t)hix.nseq; ix.totlen = hix.totlen;
 
-  MapPar p;
+  MapPar p; p.cov_frac = 0.0;
   p.ncut = ncut; p.min_cover = 0; p.min_swatscor = minscor >= 0 ? minscor : ix.k + ix.s - 1; p.below_max = scordiff;
   p.min_basq = minbasq; p.target_depth = 512; p.max_depth = 2048;
   p.flags = (scordiff ? 0 : FLG_BEST) | (ix.nseq < 512 ? FLG_SEQBYSEQ : 0) | (xflag ? (FLG_NOSHRTINFO | FLG_SENSITIVE) : 0);
@@ -161,6 +161,8 @@ int main(int argc, char **argv) {
     CandScratch cx = cand_scratch_carve(cscr.data() + cbytes * r, qmax, ix.s, hcap, ngrp, segcap, candcap);
     DumpView v;
     v.qlen = (uint32_t)(off[r + 1] - off[r]); v.qmax = qmax; v.k = ix.k;
+    if (mincover < 1.01) { p.min_cover = (uint32_t)(mincover * v.qlen); if (p.min_cover > v.qlen) p.min_cover = v.qlen; }   // as when the read was mapped
+    else p.min_cover = (uint32_t)mincover;
     for (int st = 0; st < 2; st++) { v.hi[st] = hi[2 * r + st]; v.seeds[st] = seeds.data() + (size_t)(2 * r + st) * qmax; v.qmask[st] = qmask.data() + (size_t)(2 * r + st) * qmax; }
     v.ch = ch[r]; v.rc = rcpool.data() + ch[r].rc_off;
     v.ctl = ctl[r]; v.st = stat[r]; v.res = respool.data() + stat[r].res_off; v.dstr = dstrpool.data() + stat[r].dstr_off; v.ngrp = ngrp;

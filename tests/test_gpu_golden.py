@@ -21,6 +21,12 @@ def params_from_opts(ix, opts):
             p.min_basqval = int(o[i + 1]); i += 2
         elif o[i] == "-m":
             p.min_swatscor = int(o[i + 1]); i += 2
+        elif o[i] == "-c":
+            v = float(o[i + 1]); i += 2
+            if v < 1.01:
+                p.min_cover_frac = v          # per read: (uint32_t)(v * read length), smalt.c:1113-1122
+            else:
+                p.min_cover = int(v)
         elif o[i] == "-x":
             p.rmapflg |= api.FLG_NOSHRTINFO | api.FLG_SENSITIVE; i += 1
         else:
