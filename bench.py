@@ -119,9 +119,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        # nccl = RCCL over xGMI; SMALT_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1 path
+        dist.init_process_group(backend=os.environ.get("SMALT_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     k, s = 13, 6
