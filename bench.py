@@ -250,9 +250,9 @@ def main():
             "kernel_ms_per_step": {kk: v / args.steps for kk, v in ms_acc.items()},
             "dominant_kernel": dom,
             "cands_phase_share": [round(x / max(1, sum(work_acc[8:17])), 4) for x in work_acc[8:17]],
-            "cands_phase_ticks": sum(work_acc[8:17]), "cands_gather_split": [round(work_acc[19] / max(1, sum(work_acc[8:17])), 4), round(work_acc[21] / max(1, sum(work_acc[8:17])), 4)],
-            "cands_hbm_strands": {"strands": work_acc[19], "hits": work_acc[20], "cycle_share": round(work_acc[21] / max(1, sum(work_acc[8:17])), 4),
-                                  "over_8192": work_acc[22]},
+            "cands_phase_ticks": sum(work_acc[8:17]),
+            "cands_windows": {"hits_in_windowed_strands": work_acc[20], "window_gather_share": round(work_acc[21] / max(1, sum(work_acc[8:17])), 4),
+                              "table_build_share": round(work_acc[19] / max(1, sum(work_acc[8:17])), 4), "hbm_fallback_strands": work_acc[22]},
             "cands_per_read": work_acc[5] / max(1, world * args.steps * args.reads), "kept_per_read": work_acc[6] / max(1, world * args.steps * args.reads),
             "long_window_tasks_per_read": work_acc[17] / max(1, world * args.steps * args.reads), "ranked_per_read": work_acc[3] / max(1, world * args.steps * args.reads), "scored_in_reference_order_per_read": work_acc[4] / max(1, world * args.steps * args.reads),
             "hits_per_read": work_acc[1] / max(1, world * args.steps * args.reads),

@@ -248,6 +248,10 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
     m->cg.segcap = m->cg.hcap / 2;
     m->cg.candcap = m->cg.hcap;                         // every hit can be a candidate of its own (mincover = k)
     { const char *e = getenv("SMALTGPU_CANDS_WINDOW"); m->cg.window = e ? (uint32_t)atoi(e) : 0; }   // test hook (tests/test_gpu_large.py)
+    { const char *e = getenv("SMALTGPU_CANDS_LDS_HITS"); m->cg.lds_hits = e ? (uint32_t)atoi(e) : (uint32_t)CANDS_LDS_HITS; }   // tuning hook
+    if (m->cg.lds_hits < 256) m->cg.lds_hits = 256;
+    if (m->cg.lds_hits > 2048) m->cg.lds_hits = 2048;
+    m->cg.tab = m->qmax + 8 < (uint32_t)CANDS_TAB ? m->qmax + 8 : (uint32_t)CANDS_TAB;    // a read has fewer seeds than bases
     m->cg.slot_bytes = m->cand_bytes = cand_slot_bytes(m->cg, m->qmax, d.s);
     uint64_t budget = 64ull << 30;     // of 288 GB: more slots than resident workgroups lets the hardware balance uneven reads
     uint64_t slots = budget / m->cand_bytes;

@@ -20,7 +20,7 @@
 
 namespace smg {
 
-enum : uint32_t { CANDS_LDS_HITS = 1152,       // hits of the LDS working set (one strand, or one window of a strand)
+enum : uint32_t { CANDS_LDS_HITS = 640,        // hits of the LDS working set (one strand, or one window of a strand)
                   CANDS_TAB = 264,             // per-list tables: a read of the wave-parallel form has <= 256 seeds
                   CANDS_TAB_BYTES = 5 * CANDS_TAB * 4 };
 enum : int { SMG_WINDOW_FALLBACK = 1000 };      // internal: a hit region does not fit a window
@@ -376,7 +376,8 @@ SMG_HD inline uint32_t wave_cover_deficit(const HitInfoHdr &hdr, const SeedRec *
 
 struct CandsV2Scratch {
   uint8_t *lds; size_t lds_bytes;        // per-workgroup LDS block (the host build passes plain memory)
-  uint32_t window;                       // test hook: hits per window (0: CANDS_LDS_HITS)
+  uint32_t window;                       // test hook: hits per window (0: lds_hits)
+  uint32_t lds_hits, tab;                // geometry of the LDS block: hits of the working set, entries of the per-list tables
   uint8_t *hbm;                          // HBM slot: strand work for large strands + cand_tmp + candidates
   uint32_t hcap_strand;                  // capacity of the HBM strand work (hits per strand)
   SegCand *cand_tmp; SegCand *cand; uint32_t candcap;
@@ -397,7 +398,7 @@ SMG_HD inline size_t cands_v2_hbm_bytes(uint32_t qmax, int s, uint32_t hcap_stra
 SMG_HD inline CandsV2Scratch cands_v2_carve(uint8_t *lds, size_t lds_bytes, uint8_t *hbm, uint32_t qmax, int s, uint32_t hcap_strand,
                                             uint32_t ngrp, uint32_t candcap, bool debug) {
   CandsV2Scratch x;
-  x.lds = lds; x.lds_bytes = lds_bytes; x.window = 0; x.hcap_strand = hcap_strand; x.candcap = candcap; x.ngrp = ngrp;
+  x.lds = lds; x.lds_bytes = lds_bytes; x.window = 0; x.lds_hits = CANDS_LDS_HITS; x.tab = CANDS_TAB; x.hcap_strand = hcap_strand; x.candcap = candcap; x.ngrp = ngrp;
   uint8_t *b = hbm;
   x.hbm = b; b += (strand_work_bytes<uint32_t>(hcap_strand) + 63) & ~(size_t)63;
   x.cand_tmp = (SegCand *)b; b += (size_t)hcap_strand * sizeof(SegCand);
@@ -536,14 +537,14 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     //          a window ends at a hit-region boundary, so every later stage sees complete regions
     //  mode 2: HBM working set (allocation-boundary protocol active, or a region larger than a window)
     const bool simple = all_in || !seqbyseq;
-    const size_t wl_bytes = (strand_work_bytes<uint16_t>(CANDS_LDS_HITS) + 15) & ~(size_t)15;
-    const bool lds_ok = x.lds && wl_bytes + CANDS_TAB_BYTES <= x.lds_bytes;
-    uint32_t W = CANDS_LDS_HITS;
+    const size_t wl_bytes = (strand_work_bytes<uint16_t>(x.lds_hits) + 15) & ~(size_t)15;
+    const bool lds_ok = x.lds && wl_bytes + (size_t)5 * x.tab * 4 <= x.lds_bytes && n_use < x.tab;
+    uint32_t W = x.lds_hits;
     if (x.window && x.window < W) W = x.window;
-    StrandWork<uint16_t> wl = strand_work_carve<uint16_t>(x.lds, CANDS_LDS_HITS);
+    StrandWork<uint16_t> wl = strand_work_carve<uint16_t>(x.lds, x.lds_hits);
     StrandWork<uint32_t> wg = strand_work_carve<uint32_t>(x.hbm, x.hcap_strand);
     uint32_t *gt = lds_ok ? (uint32_t *)(x.lds + wl_bytes) : x.sort_keys;        // per-list tables (sort arrays are dead here)
-    uint32_t *g_pfx = gt, *g_poff = gt + CANDS_TAB, *g_qo = gt + 2 * CANDS_TAB, *g_len = gt + 3 * CANDS_TAB;
+    uint32_t *g_pfx = gt, *g_poff = gt + x.tab, *g_qo = gt + 2 * x.tab, *g_len = gt + 3 * x.tab;
     uint32_t nlist = 0, total = 0;
     if (simple) {
       // Seeds that contribute become "lists" (position lists of the index, ascending); hit h of the strand
@@ -584,7 +585,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     uint64_t *dbg_w = x.dbg_words ? x.dbg_words + (size_t)st * x.hcap_strand : nullptr;
 
     if (mode == 1) {
-      uint32_t *g_cur = gt + 4 * CANDS_TAB;            // per-list cursor
+      uint32_t *g_cur = gt + 4 * x.tab;                // per-list cursor
       SMG_PAR_CHUNKS(base, nlist) { const uint32_t l = base + SMG_LANE; if (l < nlist) g_cur[l] = 0; }
       SMG_SYNC();
       uint32_t carry = 0, remaining = total, reg_base = 0, gproc = 0, last_grp = ~0u;
@@ -709,7 +710,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
 
     if (mode != 1) {
       const bool in_lds = mode == 0;
-      const uint32_t gcap = in_lds ? CANDS_LDS_HITS : x.hcap_strand;
+      const uint32_t gcap = in_lds ? x.lds_hits : x.hcap_strand;
       uint64_t *dat = in_lds ? (uint64_t *)wl.dat : wg.dat;
       if (simple) {
         if (total > gcap) { err = SMG_ERR_CAP; break; }

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(64) k_cands(Batch b, DevIndex ix, MapPar p, ui
     uint8_t *base = gscratch + g.slot_bytes * (g.debug ? r : blockIdx.x);
     if (cands_v2_applicable(p, ix.k, ix.s, read_len(b, r))) {
       CandsV2Scratch x = cands_v2_carve(lds + LDS_GUARD, lds_bytes, base, b.qmax, ix.s, g.hcap_strand, g.ngrp, g.candcap, g.debug != 0);
-      x.window = g.window;
+      x.window = g.window; x.lds_hits = g.lds_hits; x.tab = g.tab;
       nhit += stage_cands_v2(b, ix, p, r, x, ph);
     } else {
       CandScratch x = cand_scratch_carve(base, b.qmax, ix.s, g.hcap, g.ngrp, g.segcap, g.candcap);
@@ -741,7 +741,7 @@ int launch_seed(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar 
 int launch_cands(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint8_t *scratch, uint32_t nslots, const CandGeom &g) {
   if (!b.nreads) return 0;
   uint32_t grid = b.nreads < nslots ? b.nreads : nslots;
-  const uint32_t lds_bytes = (uint32_t)(((strand_work_bytes<uint16_t>(CANDS_LDS_HITS) + 15) & ~(size_t)15) + CANDS_TAB_BYTES);
+  const uint32_t lds_bytes = (uint32_t)(((strand_work_bytes<uint16_t>(g.lds_hits) + 15) & ~(size_t)15) + (size_t)5 * g.tab * 4);
   hipLaunchKernelGGL(k_cands, dim3(grid), dim3(64), lds_bytes + LDS_GUARD, s, b, ix, p, scratch, g, lds_bytes);
   SMG_LAUNCH_CHECK();
   return 0;
