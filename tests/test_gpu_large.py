@@ -200,3 +200,36 @@ def test_long_reads_match_oracle(oracle_built, tmp_path):
         assert res[i] == exp[i][0], i
         for kk, v in exp[i][1].items():
             assert stats[i][kk] == v, (i, kk)
+
+
+def test_edge_batches(oracle_built, tmp_path):
+    """Empty batch, reads shorter than k, a read of exactly the mapper's maximum length, an over-long read, all-N reads."""
+    from smalt_amd import api, synth
+    ch = synth.make_reference(2, 150_000, seed=61, repeat_frac=0.05, n_fam=1, cons_len=200)
+    seqs = [synth.codes_to_ascii(c) for c in ch]
+    oix0 = ol.build_index(seqs, ["c0", "c1"], 13, 6)
+    pre = str(tmp_path / "edge")
+    assert ol.lib().or_index_write(oix0, pre.encode()) == 0
+    oix = ol.lib().or_index_read(pre.encode())
+    gix = api.Index.load(pre, 0)
+    mp = api.Mapper(gix, 8, 120)
+    par = gix.default_params()
+    try:
+        res, stats = mp.map_batch([], None, par)
+        assert res == [] and stats == []
+        rb = [b"ACGTA", b"N" * 40, seqs[0][1000:1120], seqs[1][500:512], b"A"]
+        res, stats = mp.map_batch(rb, None, par)
+        exp = _oracle_map_all(oix, rb, ol.default_params(oix))
+        for i in range(len(rb)):
+            assert stats[i]["err"] == 0
+            assert res[i] == exp[i][0], i
+        assert res[0] == [] and res[1] == [] and len(res[2]) >= 1
+        with pytest.raises(api.SmaltGpuError):
+            mp.map_batch([seqs[0][:121]], None, par)               # longer than the mapper was created for
+        with pytest.raises(api.SmaltGpuError):
+            mp.map_batch([b"ACGT"] * 9, None, par)                 # more reads than the mapper was created for
+        res, stats = mp.map_batch([seqs[0][2000:2100]], None, par)  # still usable afterwards
+        assert len(res[0]) >= 1
+    finally:
+        mp.close()
+        gix.close()
