@@ -154,7 +154,7 @@ SMG_HD inline int derive_cand_c(SegCand &c, const StrandWork<IT> &w, uint32_t m0
 // Returns 0 or an SMG_ERR_* code (wave-uniform).
 template <class IT>
 SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, bool seqbyseq, uint32_t qlen, int k, int s,
-                               uint32_t mincover, SegCand *cand_tmp, SegCand *cand, uint32_t candcap, uint32_t *ncand_io,
+                               uint32_t mincover, uint8_t *cover8, SegCand *cand, uint32_t candcap, uint32_t *ncand_io,
                                uint32_t *max_cover_io, uint32_t *max2nd_io, unsigned long long *ph,
                                bool hold_tail, uint32_t *nproc_out, uint32_t *reg_base_io) {
   *nproc_out = n;
@@ -298,7 +298,7 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
       const int32_t seqidx = seqbyseq ? (int32_t)(key_grp(w.dat[w.seed_first[w.segm_first[m]]]) & ((1u << KEY_SEQBITS) - 1)) : -1;
       SegCand c;
       if (derive_cand_c(c, w, m, (int)(uint32_t)w.reg_num[m], k, s, (uint32_t)w.cflag[m], mincover, reg_base + lo, is_reverse, seqidx)) err = SMG_ERR_ASSERT;
-      if (slot < candcap) cand[slot] = c; else ovf = true;
+      if (slot < candcap) { cand[slot] = c; cover8[slot] = w.cflag[m]; } else ovf = true;     // covers again as a byte array: the S6 filter reads only these
     }
   }
   *ncand_io = nc;
@@ -380,7 +380,8 @@ struct CandsV2Scratch {
   uint32_t lds_hits, tab;                // geometry of the LDS block: hits of the working set, entries of the per-list tables
   uint8_t *hbm;                          // HBM slot: strand work for large strands + cand_tmp + candidates
   uint32_t hcap_strand;                  // capacity of the HBM strand work (hits per strand)
-  SegCand *cand_tmp; SegCand *cand; uint32_t candcap;
+  SegCand *cand_tmp;                     // HBM: used as the byte array of candidate covers (capacity >= candcap)
+  SegCand *cand; uint32_t candcap;
   uint32_t *sort_keys, *sort_idx;
   FillDecision *dec; uint32_t ngrp;
   uint32_t *qbr, *frame_cnt, *frame_rank; uint32_t stride; uint8_t *qbuf;
@@ -678,7 +679,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
         ph[13] += phase_clock() - tb0;
         SMG_PH(1)
         uint32_t nproc = n;
-        rv = strand_cands(wl, n, st != 0, seqbyseq, qlen, k, s, min_cover, x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph,
+        rv = strand_cands(wl, n, st != 0, seqbyseq, qlen, k, s, min_cover, (uint8_t *)x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph,
                           remaining > 0, &nproc, &reg_base);
         t0 = phase_clock();
         if (rv) break;
@@ -767,8 +768,8 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
       SMG_PH(1)
       int rv;
       uint32_t nproc = nkeys, reg_base = 0, last_grp = ~0u;
-      if (in_lds) rv = strand_cands(wl, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph, false, &nproc, &reg_base);
-      else rv = strand_cands(wg, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph, false, &nproc, &reg_base);
+      if (in_lds) rv = strand_cands(wl, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, (uint8_t *)x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph, false, &nproc, &reg_base);
+      else rv = strand_cands(wg, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, (uint8_t *)x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph, false, &nproc, &reg_base);
       t0 = phase_clock();
       if (!in_lds) { ph[14]++; ph[15] += t0 - ts; }
       if (rv) { err = rv; break; }
@@ -817,7 +818,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     // candidates that pass the cover threshold, in candidate order (:1700-1730); four independent loads per lane
     for (uint32_t base = 0; base < ncand; base += 4 * SMG_NLANES) {
       uint32_t cov[4];
-      for (int u = 0; u < 4; u++) { const uint32_t i = base + (uint32_t)u * SMG_NLANES + SMG_LANE; cov[u] = i < ncand ? x.cand[i].cover : 0; }
+      for (int u = 0; u < 4; u++) { const uint32_t i = base + (uint32_t)u * SMG_NLANES + SMG_LANE; cov[u] = i < ncand ? ((const uint8_t *)x.cand_tmp)[i] : 0; }
       for (int u = 0; u < 4; u++) {
         const uint32_t i = base + (uint32_t)u * SMG_NLANES + SMG_LANE;
         const bool keep = i < ncand && !(cov[u] + adj < min_cov_thr);
