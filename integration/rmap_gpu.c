@@ -1,0 +1,113 @@
+/* rmap_gpu.c -- the reference-side binding of libsmaltgpu: replaces the reference's
+ * rmapSingle() (src/rmap.c:1648) by a version that runs the seed-and-extend path on the GPU through the C ABI of
+ * include/smaltgpu.h and hands the raw alignments back to the reference's own, unmodified post-processing
+ * (results.c: assignSequenceIndex, sortAndPrune, mapping quality, filters) and reporting code.
+ *
+ * This is OUR source.  It is compiled only by oracle/Makefile (target ref_gpu), which takes the text of the
+ * reference's rmap.c from where it lies at build time (nothing is copied into this repository) so that every
+ * other symbol of that file -- rmapCreate, rmapDelete, rmapGetData, rmapPair, the profile helpers -- stays the
+ * reference's own code.  Used by tests/test_gpu_dropin.py: `smalt map` built this way must print what the
+ * reference prints.
+ *
+ * Environment: SMALTGPU_INDEX_PREFIX = the index prefix given to `smalt map` (the library reads the same
+ * .smi/.sma files; a production binding would hand over the HashTable/SeqSet arrays instead).
+ * One read per call: smalt.c consumes the results of a read before it maps the next one (smalt.c:1172-1185),
+ * so without the additive block hook of INTEGRATION.md section 2 the batch size is 1 -- correct, not fast.
+ */
+#define rmapSingle rmapSingle_reference_cpu          /* the CPU implementation stays linkable under this name */
+#include "rmap.c"
+#undef rmapSingle
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include "smaltgpu.h"
+
+/* results_inject.c (our TU around the reference's results.c) */
+extern int resultSetInjectRaw(ResultSet *rsp, unsigned n, const smaltgpu_result *res, const unsigned char *dstr,
+                              int swatscor_max, int swatscor_2ndmax);
+
+enum { GPU_MAXMAPPERS = 256 };
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static smaltgpu_index *g_ix = NULL;
+static struct { const RMap *rmp; smaltgpu_mapper *mp; uint32_t maxlen; char *bases; char *quals; } g_map[GPU_MAXMAPPERS];
+static int g_nmap = 0;
+
+static int gpuMapperFor(const RMap *rmp, uint32_t rlen)
+{
+  int i, slot = -1;
+  pthread_mutex_lock(&g_lock);
+  if (!g_ix) {
+    const char *prefix = getenv("SMALTGPU_INDEX_PREFIX");
+    if (!prefix || smaltgpu_index_load(&g_ix, prefix, 0)) { pthread_mutex_unlock(&g_lock); return -1; }
+  }
+  for (i = 0; i < g_nmap; i++) if (g_map[i].rmp == rmp) { slot = i; break; }
+  if (slot < 0 && g_nmap < GPU_MAXMAPPERS) { slot = g_nmap++; memset(&g_map[slot], 0, sizeof(g_map[slot])); g_map[slot].rmp = rmp; }
+  pthread_mutex_unlock(&g_lock);
+  if (slot < 0) return -1;
+  if (!g_map[slot].mp || g_map[slot].maxlen < rlen) {
+    uint32_t cap = 256;
+    while (cap < rlen) cap *= 2;
+    if (g_map[slot].mp) smaltgpu_mapper_free(g_map[slot].mp);
+    g_map[slot].mp = NULL;
+    free(g_map[slot].bases); free(g_map[slot].quals);
+    g_map[slot].bases = malloc(cap + 1); g_map[slot].quals = malloc(cap + 1);
+    if (!g_map[slot].bases || !g_map[slot].quals || smaltgpu_mapper_create(&g_map[slot].mp, g_ix, 1, cap)) return -1;
+    g_map[slot].maxlen = cap;
+  }
+  return slot;
+}
+
+int rmapSingle(ErrMsg *errmsgp, RMap *rmp, SeqFastq *readp, int ktuple_maxhit, uint32_t min_cover, int min_swatscor,
+               int min_swatscor_below_max, UCHAR min_basqval, short target_depth, short max_depth, RMAPFLG_t rmapflg,
+               const ScoreMatrix *scormtxp, const ResultFilter *rsfp, const HashTable *htp, const SeqSet *ssp,
+               const SeqCodec *codecp)
+{
+  int errcode, slot;
+  uint32_t rlen, qlen = 0, i;
+  char cod, qcod;
+  const char *seqp, *qualp;
+  short mismatchscor, gapinitscor, gapextscor, matchscor;
+  smaltgpu_params par;
+  smaltgpu_batch_out out;
+  uint64_t off[2];
+  static const char ALPHA[8] = {'A', 'C', 'G', 'T', 'N', 'N', 'N', 'N'};     /* codes 4..7 are non-standard: all encode as N on the way in */
+
+  if (rmapflg & (RMAPFLG_SPLIT | RMAPFLG_CMPLXW))     /* not on the GPU path: the reference's own implementation */
+    return rmapSingle_reference_cpu(errmsgp, rmp, readp, ktuple_maxhit, min_cover, min_swatscor, min_swatscor_below_max,
+                                    min_basqval, target_depth, max_depth, rmapflg, scormtxp, rsfp, htp, ssp, codecp);
+  rmapBlank(rmp);
+  if ((errcode = makeRMAPPROFfromRead(rmp->prp, readp, scormtxp, codecp)))
+    ERRMSGNO(errmsgp, errcode);
+  seqp = seqFastqGetConstSequence(readp, &rlen, &cod);
+  if (rlen >= hashTableGetKtupLen(htp, NULL)) {
+    if ((slot = gpuMapperFor(rmp, rlen)) < 0) ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+    for (i = 0; i < rlen; i++)
+      g_map[slot].bases[i] = (cod == SEQCOD_ASCII) ? seqp[i] : ALPHA[seqp[i] & SEQCOD_ALPHA_MASK];
+    qualp = seqFastqGetConstQualityFactors(readp, &qlen, &qcod);
+    if (qualp && qlen == rlen) memcpy(g_map[slot].quals, qualp, rlen);
+    matchscor = scoreProfileGetAvgPenalties(&mismatchscor, &gapinitscor, &gapextscor, rmp->prp->scorprofp);
+    smaltgpu_params_default(&par, g_ix);
+    par.ktuple_maxhit = ktuple_maxhit; par.min_cover = min_cover; par.min_swatscor = min_swatscor;
+    par.min_swatscor_below_max = min_swatscor_below_max; par.min_basqval = min_basqval;
+    par.target_depth = target_depth; par.max_depth = max_depth; par.rmapflg = rmapflg;
+    par.match = matchscor; par.mismatch = mismatchscor; par.gap_init = gapinitscor; par.gap_ext = gapextscor;
+    par.min_cover_frac = 0.0;
+    off[0] = 0; off[1] = rlen;
+    if (smaltgpu_map_batch(g_map[slot].mp, (const uint8_t *)g_map[slot].bases,
+                           (qualp && qlen == rlen) ? (const uint8_t *)g_map[slot].quals : NULL, off, 1, &par, &out))
+      ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+    if (out.stat[0].errcode) ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+    if ((errcode = resultSetInjectRaw(rmp->rsrp, (unsigned)(out.res_off[1] - out.res_off[0]), out.res + out.res_off[0], out.diffstr,
+                                      out.stat[0].swatscor_max, out.stat[0].swatscor_2ndmax)))
+      ERRMSGNO(errmsgp, errcode);
+    resultSetAlignmentStats(rmp->rsrp, out.stat[0].n_ali_done, out.stat[0].n_ali_tot, max_depth,
+                            out.stat[0].n_hits_used, out.stat[0].n_hits_tot);                 /* rmap.c:1337 */
+    if ((errcode = resultSetSortAndAssignSequence(rmp->rsrp, rmp->bfp->sqbfp, 0, readp, rmp->prp->scorprofp,
+                                                  rmp->prp->scorprofRCp, ssp, codecp)))        /* rmap.c:1418 */
+      ERRMSGNO(errmsgp, errcode);
+    if ((errcode = resultSetFilterResults(rmp->rsrp, rsfp, readp)))                            /* rmap.c:1734 */
+      ERRMSGNO(errmsgp, errcode);
+  }
+  return ERRCODE_SUCCESS;
+}

@@ -1,0 +1,88 @@
+"""The drop-in claim, end to end: `oracle/_ref/smalt_gpu` is the reference's own `smalt` program with ONE function
+replaced -- rmapSingle (src/rmap.c:1648) bound to libsmaltgpu through the C ABI (integration/rmap_gpu.c); FASTQ input,
+result post-processing (sorting, pruning, mapping qualities), filters and output formatting are the reference's
+unmodified code.  `smalt_gpu map` must print byte-for-byte what `smalt map` (the unmodified reference, same build
+recipe) prints.  Both binaries are built in the development container from the reference sources where they lie
+(oracle/Makefile: ref, ref_gpu); only the binaries travel."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALT = os.path.join(ROOT, "oracle", "_ref", "smalt")
+SMALT_GPU = os.path.join(ROOT, "oracle", "_ref", "smalt_gpu")
+
+
+def _data(tmp, nchr, chrlen, nreads, rlen, seed, with_n=False):
+    from smalt_amd import synth
+    ch = synth.make_reference(nchr, chrlen, seed=seed, repeat_frac=0.1, n_fam=3, cons_len=300)
+    fa, fq = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.fq")
+    synth.write_fasta(fa, ch)
+    reads, _ = synth.make_reads(ch, nreads, rlen, seed=seed + 1, sub_rate=0.02, indel_read_frac=0.2)
+    rng = np.random.default_rng(seed + 2)
+    with open(fq, "wb") as f:
+        for i, r in enumerate(reads):
+            b = bytearray(synth.codes_to_ascii(r))
+            if with_n and i % 7 == 0:
+                b[int(rng.integers(0, len(b)))] = ord("N")
+            if i % 11 == 0:
+                b = b[:int(rng.integers(10, len(b)))]            # ragged lengths, some shorter than k
+            q = bytes(33 + int(x) for x in rng.integers(5, 41, size=len(b)))
+            f.write(b"@r%d\n" % i + bytes(b) + b"\n+\n" + q + b"\n")
+    return fa, fq
+
+
+@pytest.mark.skipif(not (os.path.exists(SMALT) and os.path.exists(SMALT_GPU)), reason="reference binaries not built (make -C oracle ref ref_gpu)")
+@pytest.mark.parametrize("k,s,nchr,chrlen,rlen,opts", [
+    (13, 6, 1, 1_000_000, 100, ["-f", "cigar"]),                  # BASELINE configs[0] shape
+    (13, 6, 3, 300_000, 150, ["-f", "sam", "-q", "10"]),          # multi-sequence, SAM with mapping qualities, -q
+    (11, 3, 2, 200_000, 120, ["-f", "cigar", "-d", "-1"]),        # all alignments (no best-only)
+    (13, 6, 2, 250_000, 150, ["-f", "cigar", "-x", "-c", "0.4"]),  # exhaustive search, fractional cover threshold
+])
+def test_smalt_map_prints_the_same(k, s, nchr, chrlen, rlen, opts, tmp_path):
+    tmp = str(tmp_path)
+    fa, fq = _data(tmp, nchr, chrlen, 1200, rlen, seed=k * 100 + s + nchr, with_n=True)
+    pre = os.path.join(tmp, "idx")
+    subprocess.run([SMALT, "index", "-k", str(k), "-s", str(s), pre, fa], check=True, capture_output=True)
+    out_ref, out_gpu = os.path.join(tmp, "ref.out"), os.path.join(tmp, "gpu.out")
+    subprocess.run([SMALT, "map"] + opts + ["-o", out_ref, pre, fq], check=True, capture_output=True)
+    env = dict(os.environ, SMALTGPU_INDEX_PREFIX=pre)
+    r = subprocess.run([SMALT_GPU, "map"] + opts + ["-o", out_gpu, pre, fq], capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    a = [ln for ln in open(out_ref).read().split("\n") if not ln.startswith("@PG")]
+    b = [ln for ln in open(out_gpu).read().split("\n") if not ln.startswith("@PG")]
+    assert len(a) == len(b)
+    diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
+    assert not diff, diff[:3]
+    assert sum(1 for ln in a if ln and not ln.startswith("@")) >= 1000
+
+
+@pytest.mark.skipif(not (os.path.exists(SMALT) and os.path.exists(SMALT_GPU)), reason="reference binaries not built (make -C oracle ref ref_gpu)")
+def test_binding_goes_through_the_library_and_threads(tmp_path):
+    """Without the index prefix the bound binary cannot map (so the equality above is not the CPU path in disguise), and
+    with worker threads (-n 3: one RMap = one mapper = one HIP stream per thread, -O keeps input order) it still prints
+    the reference's lines for reads with a unique best alignment (ties are drawn with a thread-shared drand48)."""
+    tmp = str(tmp_path)
+    fa, fq = _data(tmp, 2, 300_000, 900, 100, seed=77)
+    pre = os.path.join(tmp, "idx")
+    subprocess.run([SMALT, "index", "-k", "13", "-s", "6", pre, fa], check=True, capture_output=True)
+    env = dict(os.environ)
+    env.pop("SMALTGPU_INDEX_PREFIX", None)
+    r = subprocess.run([SMALT_GPU, "map", "-f", "cigar", "-o", os.path.join(tmp, "x.out"), pre, fq], capture_output=True, env=env)
+    assert r.returncode != 0
+    out_ref, out_gpu = os.path.join(tmp, "ref.out"), os.path.join(tmp, "gpu.out")
+    subprocess.run([SMALT, "map", "-f", "cigar", "-o", out_ref, pre, fq], check=True, capture_output=True)
+    env["SMALTGPU_INDEX_PREFIX"] = pre
+    r = subprocess.run([SMALT_GPU, "map", "-n", "3", "-O", "-f", "cigar", "-o", out_gpu, pre, fq], capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    a, b = open(out_ref).read().split("\n"), open(out_gpu).read().split("\n")
+    assert len(a) == len(b)
+    same = sum(1 for x, y in zip(a, b) if x == y)
+    assert same >= 0.97 * len(a), (same, len(a))
+    for x, y in zip(a, b):
+        if x != y:                       # only the reads whose best alignment is not unique may differ (class R / mapq 0-3)
+            assert x.split()[0].split(":")[1] in ("R", "S") or int(x.split()[0].split(":")[2]) <= 3, (x, y)
