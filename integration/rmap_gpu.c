@@ -30,10 +30,19 @@ extern int resultSetInjectRaw(ResultSet *rsp, unsigned n, const smaltgpu_result 
 enum { GPU_MAXMAPPERS = 256 };
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 static smaltgpu_index *g_ix = NULL;
-static struct { const RMap *rmp; smaltgpu_mapper *mp; uint32_t maxlen; char *bases; char *quals; } g_map[GPU_MAXMAPPERS];
+static struct {
+  const RMap *rmp; smaltgpu_mapper *mp; uint32_t maxlen, maxreads;
+  char *bases, *quals; uint64_t *off; size_t basecap;
+  smaltgpu_batch_out out; int nbatch;          /* results of the last rmapGpuBatch */
+} g_map[GPU_MAXMAPPERS];
 static int g_nmap = 0;
 
-static int gpuMapperFor(const RMap *rmp, uint32_t rlen)
+static int gpuMapperFor(const RMap *rmp, uint32_t rlen);
+static int gpuMapperForBatch(const RMap *rmp, uint32_t rlen, uint32_t nreads, size_t nbases);
+
+static int gpuMapperFor(const RMap *rmp, uint32_t rlen) { return gpuMapperForBatch(rmp, rlen, 1, rlen); }
+
+static int gpuMapperForBatch(const RMap *rmp, uint32_t rlen, uint32_t nreads, size_t nbases)
 {
   int i, slot = -1;
   pthread_mutex_lock(&g_lock);
@@ -45,15 +54,22 @@ static int gpuMapperFor(const RMap *rmp, uint32_t rlen)
   if (slot < 0 && g_nmap < GPU_MAXMAPPERS) { slot = g_nmap++; memset(&g_map[slot], 0, sizeof(g_map[slot])); g_map[slot].rmp = rmp; }
   pthread_mutex_unlock(&g_lock);
   if (slot < 0) return -1;
-  if (!g_map[slot].mp || g_map[slot].maxlen < rlen) {
-    uint32_t cap = 256;
+  if (!g_map[slot].mp || g_map[slot].maxlen < rlen || g_map[slot].maxreads < nreads) {
+    uint32_t cap = g_map[slot].maxlen > 256 ? g_map[slot].maxlen : 256, rcap = g_map[slot].maxreads > 1 ? g_map[slot].maxreads : 1;
     while (cap < rlen) cap *= 2;
+    while (rcap < nreads) rcap *= 2;
     if (g_map[slot].mp) smaltgpu_mapper_free(g_map[slot].mp);
     g_map[slot].mp = NULL;
+    if (smaltgpu_mapper_create(&g_map[slot].mp, g_ix, rcap, cap)) return -1;
+    g_map[slot].maxlen = cap; g_map[slot].maxreads = rcap;
+    free(g_map[slot].off);
+    if (!(g_map[slot].off = malloc(((size_t)rcap + 1) * sizeof(uint64_t)))) return -1;
+  }
+  if (g_map[slot].basecap < nbases + 1) {
     free(g_map[slot].bases); free(g_map[slot].quals);
-    g_map[slot].bases = malloc(cap + 1); g_map[slot].quals = malloc(cap + 1);
-    if (!g_map[slot].bases || !g_map[slot].quals || smaltgpu_mapper_create(&g_map[slot].mp, g_ix, 1, cap)) return -1;
-    g_map[slot].maxlen = cap;
+    g_map[slot].basecap = 2 * nbases + 1024;
+    g_map[slot].bases = malloc(g_map[slot].basecap); g_map[slot].quals = malloc(g_map[slot].basecap);
+    if (!g_map[slot].bases || !g_map[slot].quals) return -1;
   }
   return slot;
 }
@@ -109,5 +125,73 @@ int rmapSingle(ErrMsg *errmsgp, RMap *rmp, SeqFastq *readp, int ktuple_maxhit, u
     if ((errcode = resultSetFilterResults(rmp->rsrp, rsfp, readp)))                            /* rmap.c:1734 */
       ERRMSGNO(errmsgp, errcode);
   }
+  return ERRCODE_SUCCESS;
+}
+
+
+/* ---- batched form: used by integration/smalt_batch.c, which replaces the per-read loop of
+ *      processArgBlock (smalt.c:1221) by   rmapGpuBatch(block)  +  rmapGpuFinish(read i) per read. ---- */
+static const char GPU_ALPHA[8] = {'A', 'C', 'G', 'T', 'N', 'N', 'N', 'N'};
+
+/* phase 1 + 2: all reads of a block (encoded, SEQCOD_MANGLED) through the GPU path; results stay with the mapper */
+int rmapGpuBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, int n, int ktuple_maxhit, double tupcovmin,
+                 int min_swatscor, int min_swatscor_below_max, UCHAR min_basqval, short target_depth, short max_depth,
+                 RMAPFLG_t rmapflg, const ScoreMatrix *scormtxp, const SeqCodec *codecp)
+{
+  int i, slot, errcode, has_qual = 1;
+  uint32_t maxlen = 1, rlen, qlen, j;
+  size_t tot = 0;
+  char cod, qcod;
+  short mismatchscor, gapinitscor, gapextscor, matchscor;
+  smaltgpu_params par;
+  for (i = 0; i < n; i++) { (void)seqFastqGetConstSequence(reads[i], &rlen, &cod); tot += rlen; if (rlen > maxlen) maxlen = rlen; }
+  if ((slot = gpuMapperForBatch(rmp, maxlen, (uint32_t)n, tot)) < 0) ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+  for (i = 0, tot = 0; i < n; i++) {
+    const char *seqp = seqFastqGetConstSequence(reads[i], &rlen, &cod);
+    const char *qualp = seqFastqGetConstQualityFactors(reads[i], &qlen, &qcod);
+    g_map[slot].off[i] = tot;
+    for (j = 0; j < rlen; j++) g_map[slot].bases[tot + j] = (cod == SEQCOD_ASCII) ? seqp[j] : GPU_ALPHA[seqp[j] & SEQCOD_ALPHA_MASK];
+    if (qualp && qlen == rlen) memcpy(g_map[slot].quals + tot, qualp, rlen); else has_qual = 0;
+    tot += rlen;
+  }
+  g_map[slot].off[n] = tot;
+  /* penalties as the reference derives them for a read (rmap.c:1259): the profile of the first read */
+  if ((errcode = makeRMAPPROFfromRead(rmp->prp, reads[0], scormtxp, codecp))) ERRMSGNO(errmsgp, errcode);
+  matchscor = scoreProfileGetAvgPenalties(&mismatchscor, &gapinitscor, &gapextscor, rmp->prp->scorprofp);
+  smaltgpu_params_default(&par, g_ix);
+  par.ktuple_maxhit = ktuple_maxhit; par.min_swatscor = min_swatscor; par.min_swatscor_below_max = min_swatscor_below_max;
+  par.min_basqval = min_basqval; par.target_depth = target_depth; par.max_depth = max_depth; par.rmapflg = rmapflg;
+  par.match = matchscor; par.mismatch = mismatchscor; par.gap_init = gapinitscor; par.gap_ext = gapextscor;
+  if (tupcovmin < 1.01) { par.min_cover = 0; par.min_cover_frac = tupcovmin; }      /* smalt.c:1113-1126 */
+  else { par.min_cover = (uint32_t)tupcovmin; par.min_cover_frac = 0.0; }
+  g_map[slot].nbatch = 0;
+  if (smaltgpu_map_batch(g_map[slot].mp, (const uint8_t *)g_map[slot].bases, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
+                         g_map[slot].off, (uint32_t)n, &par, &g_map[slot].out))
+    ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+  g_map[slot].nbatch = n;
+  return ERRCODE_SUCCESS;
+}
+
+/* phase 3: the ResultSet of read i of the last batch, then the reference's own post-processing */
+int rmapGpuFinish(ErrMsg *errmsgp, RMap *rmp, int i, SeqFastq *readp, short max_depth, const ScoreMatrix *scormtxp,
+                  const ResultFilter *rsfp, const HashTable *htp, const SeqSet *ssp, const SeqCodec *codecp)
+{
+  int errcode, slot;
+  uint32_t rlen;
+  const smaltgpu_batch_out *o;
+  if ((slot = gpuMapperFor(rmp, 1)) < 0 || i < 0 || i >= g_map[slot].nbatch) ERRMSGNO(errmsgp, ERRCODE_ASSERT);
+  o = &g_map[slot].out;
+  rmapBlank(rmp);
+  if ((errcode = makeRMAPPROFfromRead(rmp->prp, readp, scormtxp, codecp))) ERRMSGNO(errmsgp, errcode);
+  (void)seqFastqGetConstSequence(readp, &rlen, NULL);
+  if (rlen < hashTableGetKtupLen(htp, NULL)) return ERRCODE_SUCCESS;                      /* ERRCODE_SHORTSEQ is swallowed (rmap.c:1736) */
+  if (o->stat[i].errcode) ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+  if ((errcode = resultSetInjectRaw(rmp->rsrp, (unsigned)(o->res_off[i + 1] - o->res_off[i]), o->res + o->res_off[i], o->diffstr,
+                                    o->stat[i].swatscor_max, o->stat[i].swatscor_2ndmax)))
+    ERRMSGNO(errmsgp, errcode);
+  resultSetAlignmentStats(rmp->rsrp, o->stat[i].n_ali_done, o->stat[i].n_ali_tot, max_depth, o->stat[i].n_hits_used, o->stat[i].n_hits_tot);
+  if ((errcode = resultSetSortAndAssignSequence(rmp->rsrp, rmp->bfp->sqbfp, 0, readp, rmp->prp->scorprofp, rmp->prp->scorprofRCp, ssp, codecp)))
+    ERRMSGNO(errmsgp, errcode);
+  if ((errcode = resultSetFilterResults(rmp->rsrp, rsfp, readp))) ERRMSGNO(errmsgp, errcode);
   return ERRCODE_SUCCESS;
 }

@@ -42,6 +42,8 @@ def _data(tmp, nchr, chrlen, nreads, rlen, seed, with_n=False):
     (13, 6, 3, 300_000, 150, ["-f", "sam", "-q", "10"]),          # multi-sequence, SAM with mapping qualities, -q
     (11, 3, 2, 200_000, 120, ["-f", "cigar", "-d", "-1"]),        # all alignments (no best-only)
     (13, 6, 2, 250_000, 150, ["-f", "cigar", "-x", "-c", "0.4"]),  # exhaustive search, fractional cover threshold
+    (13, 6, 3, 300_000, 150, ["-f", "sam", "-n", "3", "-O", "-r", "-1"]),   # worker threads: blocks of 96 reads per GPU batch; -r -1: no random draws
+    (13, 6, 2, 250_000, 100, ["-f", "cigar", "-n", "8", "-O", "-r", "-1", "-x", "-c", "30"]),   # blocks of 256 reads, exhaustive, absolute cover threshold
 ])
 def test_smalt_map_prints_the_same(k, s, nchr, chrlen, rlen, opts, tmp_path):
     tmp = str(tmp_path)
@@ -51,14 +53,16 @@ def test_smalt_map_prints_the_same(k, s, nchr, chrlen, rlen, opts, tmp_path):
     out_ref, out_gpu = os.path.join(tmp, "ref.out"), os.path.join(tmp, "gpu.out")
     subprocess.run([SMALT, "map"] + opts + ["-o", out_ref, pre, fq], check=True, capture_output=True)
     env = dict(os.environ, SMALTGPU_INDEX_PREFIX=pre)
-    r = subprocess.run([SMALT_GPU, "map"] + opts + ["-o", out_gpu, pre, fq], capture_output=True, env=env)
-    assert r.returncode == 0, r.stderr.decode()[-2000:]
     a = [ln for ln in open(out_ref).read().split("\n") if not ln.startswith("@PG")]
-    b = [ln for ln in open(out_gpu).read().split("\n") if not ln.startswith("@PG")]
-    assert len(a) == len(b)
-    diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
-    assert not diff, diff[:3]
     assert sum(1 for ln in a if ln and not ln.startswith("@")) >= 1000
+    # batched binding (the worker maps a block of reads per GPU batch) and per-read binding (rmapSingle, one read per call)
+    for extra in ({}, {"SMALTGPU_PER_READ": "1"}):
+        r = subprocess.run([SMALT_GPU, "map"] + opts + ["-o", out_gpu, pre, fq], capture_output=True, env=dict(env, **extra))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        b = [ln for ln in open(out_gpu).read().split("\n") if not ln.startswith("@PG")]
+        assert len(a) == len(b)
+        diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
+        assert not diff, (extra, diff[:3])
 
 
 @pytest.mark.skipif(not (os.path.exists(SMALT) and os.path.exists(SMALT_GPU)), reason="reference binaries not built (make -C oracle ref ref_gpu)")
