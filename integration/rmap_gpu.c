@@ -55,8 +55,9 @@ static int gpuMapperForBatch(const RMap *rmp, uint32_t rlen, uint32_t nreads, si
   pthread_mutex_unlock(&g_lock);
   if (slot < 0) return -1;
   if (!g_map[slot].mp || g_map[slot].maxlen < rlen || g_map[slot].maxreads < nreads) {
-    uint32_t cap = g_map[slot].maxlen > 256 ? g_map[slot].maxlen : 256, rcap = g_map[slot].maxreads > 1 ? g_map[slot].maxreads : 1;
-    while (cap < rlen) cap *= 2;
+    uint32_t cap = g_map[slot].maxlen > 64 ? g_map[slot].maxlen : 64, rcap = g_map[slot].maxreads > 1 ? g_map[slot].maxreads : 1;
+    if (cap < rlen) cap = (rlen + 31u) & ~31u;                /* scratch is sized by the longest read */
+    setenv("SMALTGPU_SLOT_BUDGET_GB", "6", 0);            /* one mapper per worker thread shares the device */
     while (rcap < nreads) rcap *= 2;
     if (g_map[slot].mp) smaltgpu_mapper_free(g_map[slot].mp);
     g_map[slot].mp = NULL;
@@ -145,7 +146,7 @@ int rmapGpuBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, int n, int 
   short mismatchscor, gapinitscor, gapextscor, matchscor;
   smaltgpu_params par;
   for (i = 0; i < n; i++) { (void)seqFastqGetConstSequence(reads[i], &rlen, &cod); tot += rlen; if (rlen > maxlen) maxlen = rlen; }
-  if ((slot = gpuMapperForBatch(rmp, maxlen, (uint32_t)n, tot)) < 0) ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+  if ((slot = gpuMapperForBatch(rmp, maxlen, (uint32_t)n, tot)) < 0) { fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error()); ERRMSGNO(errmsgp, ERRCODE_FAILURE); }
   for (i = 0, tot = 0; i < n; i++) {
     const char *seqp = seqFastqGetConstSequence(reads[i], &rlen, &cod);
     const char *qualp = seqFastqGetConstQualityFactors(reads[i], &qlen, &qcod);
@@ -166,8 +167,10 @@ int rmapGpuBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, int n, int 
   else { par.min_cover = (uint32_t)tupcovmin; par.min_cover_frac = 0.0; }
   g_map[slot].nbatch = 0;
   if (smaltgpu_map_batch(g_map[slot].mp, (const uint8_t *)g_map[slot].bases, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
-                         g_map[slot].off, (uint32_t)n, &par, &g_map[slot].out))
+                         g_map[slot].off, (uint32_t)n, &par, &g_map[slot].out)) {
+    fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error());
     ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+  }
   g_map[slot].nbatch = n;
   return ERRCODE_SUCCESS;
 }

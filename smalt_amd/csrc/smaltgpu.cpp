@@ -254,6 +254,7 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
     m->cg.tab = m->qmax + 8 < (uint32_t)CANDS_TAB ? m->qmax + 8 : (uint32_t)CANDS_TAB;    // a read has fewer seeds than bases
     m->cg.slot_bytes = m->cand_bytes = cand_slot_bytes(m->cg, m->qmax, d.s);
     uint64_t budget = 64ull << 30;     // of 288 GB: more slots than resident workgroups lets the hardware balance uneven reads
+    if (const char *e = getenv("SMALTGPU_SLOT_BUDGET_GB")) { const long g = atol(e); if (g > 0) budget = (uint64_t)g << 30; }   // many mappers on one device
     uint64_t slots = budget / m->cand_bytes;
     if (slots > 2048) slots = 2048;                     // LDS admits 4 workgroups per CU: 1024 run at a time
     if (slots < 64) slots = 64;

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""End-to-end tool comparison (not the bench.py contract): the reference's `smalt map -n T` against the same program with
+its read-mapping worker bound to libsmaltgpu (`oracle/_ref/smalt_gpu`, integration/*.c) on BASELINE configs[1] inputs
+written to disk: 3 Gbp reference index (.sma/.smi, written from the GPU-built image), FASTQ of N reads.  Everything
+around the hot path -- FASTQ parsing (one reader thread), post-processing and mapping qualities (worker threads), CIGAR
+output (one writer) -- is the reference's own host code in both programs.  Wall times are whole-program; the index
+load is removed by the difference of two read counts (as bench.py's cpu_baseline does).  Prints one JSON line."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=400000)
+    ap.add_argument("--cpu-reads", type=int, default=100000)
+    ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--gpu-threads", type=int, default=0, help="worker threads of the bound program (0: same as --threads)")
+    ap.add_argument("--nchr", type=int, default=24)
+    ap.add_argument("--chr-mbp", type=float, default=125.0)
+    a = ap.parse_args()
+    import torch
+    from smalt_amd import gpuindex, indexfile
+    dev = torch.device("cuda", 0)
+    k, s, rlen = 13, 6, 150
+    chrlen = int(a.chr_mbp * 1e6)
+    sop = np.arange(a.nchr + 1, dtype=np.int64) * chrlen
+    names = ["chr%d" % (i + 1) for i in range(a.nchr)]
+    ref = gpuindex.make_reference_gpu(a.nchr, chrlen, 20261004, dev)
+    packed = gpuindex.pack_reference(ref)
+    idx, pos = gpuindex.build_perfect_index(ref, sop, k, s)
+    reads, _ = gpuindex.make_reads_gpu(ref, sop, a.reads, rlen, 777)
+    rd = reads.cpu().numpy().reshape(a.reads, rlen)
+    smalt, smalt_gpu = os.path.join(ROOT, "oracle", "_ref", "smalt"), os.path.join(ROOT, "oracle", "_ref", "smalt_gpu")
+    gthreads = a.gpu_threads or a.threads
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        prefix = os.path.join(tmp, "hs")
+        tot = int(sop[-1])
+        indexfile.write_sma(prefix, names, sop, packed.cpu().numpy())
+        indexfile.write_smi_perfect(prefix, k, s, idx.cpu().numpy(), pos.cpu().numpy(), (tot + s - 1) // s - 1)
+        del ref, packed, idx, pos
+        torch.cuda.empty_cache()
+
+        def write_fq(path, n):
+            q = b"I" * rlen
+            with open(path, "wb") as f:
+                for i in range(n):
+                    f.write(b"@r%d\n" % i + rd[i].tobytes() + b"\n+\n" + q + b"\n")
+
+        def run(binary, nthr, fq, out, env=None):
+            t = time.time()
+            r = subprocess.run([binary, "map", "-n", str(nthr), "-O", "-r", "-1", "-f", "cigar", "-o", out, prefix, fq], capture_output=True, env=env)
+            if r.returncode:
+                raise SystemExit("%s failed: %s" % (binary, r.stderr.decode()[-1500:]))
+            return time.time() - t
+        small, cpu_fq, gpu_fq = os.path.join(tmp, "s.fq"), os.path.join(tmp, "c.fq"), os.path.join(tmp, "g.fq")
+        nsmall = 2000
+        write_fq(small, nsmall)
+        write_fq(cpu_fq, a.cpu_reads)
+        write_fq(gpu_fq, a.reads)
+        env = dict(os.environ, SMALTGPU_INDEX_PREFIX=prefix)
+        t_c0 = run(smalt, a.threads, small, os.path.join(tmp, "c0.cig"))
+        t_c1 = run(smalt, a.threads, cpu_fq, os.path.join(tmp, "c1.cig"))
+        t_g0 = run(smalt_gpu, gthreads, small, os.path.join(tmp, "g0.cig"), env)
+        t_g1 = run(smalt_gpu, gthreads, gpu_fq, os.path.join(tmp, "g1.cig"), env)
+        # same lines for the reads both programs mapped (the CPU run covers a prefix of the GPU run's reads)
+        c = open(os.path.join(tmp, "c1.cig")).read().split("\n")
+        g = open(os.path.join(tmp, "g1.cig")).read().split("\n")
+        ncmp = len([x for x in c if x])
+        identical = c[:ncmp] == g[:ncmp]
+        cpu_rate = (a.cpu_reads - nsmall) / max(t_c1 - t_c0, 1e-6)
+        gpu_rate = (a.reads - nsmall) / max(t_g1 - t_g0, 1e-6)
+        print(json.dumps({"what": "whole program `smalt map`, reads/s with the index load removed", "threads_cpu": a.threads, "threads_gpu_bound": gthreads,
+                          "cpu_reads_per_s": cpu_rate, "gpu_bound_reads_per_s": gpu_rate, "speedup": gpu_rate / cpu_rate,
+                          "outputs_identical_on_common_reads": identical, "lines_compared": ncmp,
+                          "wall_s": {"cpu_small": t_c0, "cpu": t_c1, "gpu_small": t_g0, "gpu": t_g1}, "reads": {"cpu": a.cpu_reads, "gpu": a.reads}}))
+
+
+if __name__ == "__main__":
+    main()
