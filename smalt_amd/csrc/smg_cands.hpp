@@ -150,7 +150,7 @@ SMG_HD inline int derive_cand_c(SegCand &c, const StrandWork<IT> &w, uint32_t m0
 }
 
 // One strand: hits in w.dat[0..n) (unsorted keys on entry) -> candidates appended to cand[*ncand..].
-// cand_tmp: HBM array of capacity >= n used for the sparse (per first-segment) candidates.
+// cover8: byte array (capacity >= candcap) that receives the cover of every candidate.
 // Returns 0 or an SMG_ERR_* code (wave-uniform).
 template <class IT>
 SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, bool seqbyseq, uint32_t qlen, int k, int s,
@@ -378,20 +378,18 @@ struct CandsV2Scratch {
   uint8_t *lds; size_t lds_bytes;        // per-workgroup LDS block (the host build passes plain memory)
   uint32_t window;                       // test hook: hits per window (0: lds_hits)
   uint32_t lds_hits, tab;                // geometry of the LDS block: hits of the working set, entries of the per-list tables
-  uint8_t *hbm;                          // HBM slot: strand work for large strands + cand_tmp + candidates
+  uint8_t *hbm;                          // HBM slot: strand work for large strands, candidates, sort arrays
   uint32_t hcap_strand;                  // capacity of the HBM strand work (hits per strand)
-  SegCand *cand_tmp;                     // HBM: used as the byte array of candidate covers (capacity >= candcap)
+  uint8_t *cover8;                       // [candcap] cover of every candidate (what the S6 filter reads)
   SegCand *cand; uint32_t candcap;
   uint32_t *sort_keys, *sort_idx;
   FillDecision *dec; uint32_t ngrp;
-  uint32_t *qbr, *frame_cnt, *frame_rank; uint32_t stride; uint8_t *qbuf;
   uint64_t *dbg_words; uint32_t *dbg_first, *dbg_cnt;   // debug: packed hit words grouped as the dump expects (or null)
 };
 
 SMG_HD inline size_t cands_v2_hbm_bytes(uint32_t qmax, int s, uint32_t hcap_strand, uint32_t ngrp, uint32_t candcap, bool debug) {
-  const uint32_t stride = qmax / (uint32_t)s + 2;
-  size_t n = strand_work_bytes<uint32_t>(hcap_strand) + (size_t)hcap_strand * sizeof(SegCand) + (size_t)candcap * (sizeof(SegCand) + 8) +
-             (size_t)ngrp * 2 * sizeof(FillDecision) + (size_t)qmax * 5 + (size_t)s * 4 + (size_t)s * stride * 4 + 256;
+  (void)qmax; (void)s;
+  size_t n = strand_work_bytes<uint32_t>(hcap_strand) + (size_t)candcap * (sizeof(SegCand) + 8 + 1) + (size_t)ngrp * 2 * sizeof(FillDecision) + 512;
   if (debug) n += (size_t)hcap_strand * 2 * 8 + (size_t)ngrp * 2 * 8;
   return (n + 255) & ~(size_t)255;
 }
@@ -402,16 +400,11 @@ SMG_HD inline CandsV2Scratch cands_v2_carve(uint8_t *lds, size_t lds_bytes, uint
   x.lds = lds; x.lds_bytes = lds_bytes; x.window = 0; x.lds_hits = CANDS_LDS_HITS; x.tab = CANDS_TAB; x.hcap_strand = hcap_strand; x.candcap = candcap; x.ngrp = ngrp;
   uint8_t *b = hbm;
   x.hbm = b; b += (strand_work_bytes<uint32_t>(hcap_strand) + 63) & ~(size_t)63;
-  x.cand_tmp = (SegCand *)b; b += (size_t)hcap_strand * sizeof(SegCand);
   x.cand = (SegCand *)b; b += (size_t)candcap * sizeof(SegCand);
   x.sort_keys = (uint32_t *)b; b += (size_t)candcap * 4;
   x.sort_idx = (uint32_t *)b; b += (size_t)candcap * 4;
   x.dec = (FillDecision *)b; b += (size_t)ngrp * 2 * sizeof(FillDecision);
-  x.qbr = (uint32_t *)b; b += (size_t)qmax * 4;
-  x.stride = qmax / (uint32_t)s + 2;
-  x.frame_cnt = (uint32_t *)b; b += (size_t)s * 4;
-  x.frame_rank = (uint32_t *)b; b += (size_t)s * x.stride * 4;
-  x.qbuf = b; b += qmax;
+  x.cover8 = b; b += candcap;
   b = (uint8_t *)(((uintptr_t)b + 15) & ~(uintptr_t)15);
   if (debug) {
     x.dbg_words = (uint64_t *)b; b += (size_t)hcap_strand * 2 * 8;
@@ -679,7 +672,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
         ph[13] += phase_clock() - tb0;
         SMG_PH(1)
         uint32_t nproc = n;
-        rv = strand_cands(wl, n, st != 0, seqbyseq, qlen, k, s, min_cover, (uint8_t *)x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph,
+        rv = strand_cands(wl, n, st != 0, seqbyseq, qlen, k, s, min_cover, x.cover8, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph,
                           remaining > 0, &nproc, &reg_base);
         t0 = phase_clock();
         if (rv) break;
@@ -768,8 +761,8 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
       SMG_PH(1)
       int rv;
       uint32_t nproc = nkeys, reg_base = 0, last_grp = ~0u;
-      if (in_lds) rv = strand_cands(wl, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, (uint8_t *)x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph, false, &nproc, &reg_base);
-      else rv = strand_cands(wg, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, (uint8_t *)x.cand_tmp, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph, false, &nproc, &reg_base);
+      if (in_lds) rv = strand_cands(wl, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, x.cover8, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph, false, &nproc, &reg_base);
+      else rv = strand_cands(wg, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, x.cover8, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph, false, &nproc, &reg_base);
       t0 = phase_clock();
       if (!in_lds) { ph[14]++; ph[15] += t0 - ts; }
       if (rv) { err = rv; break; }
@@ -818,7 +811,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     // candidates that pass the cover threshold, in candidate order (:1700-1730); four independent loads per lane
     for (uint32_t base = 0; base < ncand; base += 4 * SMG_NLANES) {
       uint32_t cov[4];
-      for (int u = 0; u < 4; u++) { const uint32_t i = base + (uint32_t)u * SMG_NLANES + SMG_LANE; cov[u] = i < ncand ? ((const uint8_t *)x.cand_tmp)[i] : 0; }
+      for (int u = 0; u < 4; u++) { const uint32_t i = base + (uint32_t)u * SMG_NLANES + SMG_LANE; cov[u] = i < ncand ? x.cover8[i] : 0; }
       for (int u = 0; u < 4; u++) {
         const uint32_t i = base + (uint32_t)u * SMG_NLANES + SMG_LANE;
         const bool keep = i < ncand && !(cov[u] + adj < min_cov_thr);

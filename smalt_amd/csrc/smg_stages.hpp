@@ -827,8 +827,6 @@ __device__ inline int band_track_wave_n(const Band &bp, const uint8_t *q, const 
       const bool act = m <= mhi && ip >= 0 && ip < nrows && j <= jlast && (j - ip) <= r && (j - ip) >= l;
       if (act) {
         if (j != lastcol[s]) { Hcol[s] = 0; Ecol[s] = 0; Hprev[s] = 0; qc[s] = q[j] & 7; }
-        constexpr int SP = 0;   // (placeholder to keep the slot arithmetic below compile-time)
-        (void)SP;
         const int sp = (s + NS - 1) % NS;
         const int vH = lane ? nH[s] : nH[sp], vHp = lane ? nHp[s] : nHp[sp], vF = lane ? nF[s] : nF[sp];
         const int vrow = lane ? nrow[s] : nrow[sp], vcol = lane ? ncol[s] : ncol[sp];
