@@ -29,7 +29,10 @@ extern int resultSetInjectRaw(ResultSet *rsp, unsigned n, const smaltgpu_result 
 
 enum { GPU_MAXMAPPERS = 256 };
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
-static smaltgpu_index *g_ix = NULL;
+enum { GPU_MAXDEV = 16 };
+static smaltgpu_index *g_ixdev[GPU_MAXDEV];      /* one index image per device, shared by the mappers on it */
+static int g_ndev = 0;
+#define g_ix (g_ixdev[0])
 static struct {
   const RMap *rmp; smaltgpu_mapper *mp; uint32_t maxlen, maxreads;
   char *bases, *quals; uint64_t *off; size_t basecap;
@@ -46,12 +49,19 @@ static int gpuMapperForBatch(const RMap *rmp, uint32_t rlen, uint32_t nreads, si
 {
   int i, slot = -1;
   pthread_mutex_lock(&g_lock);
-  if (!g_ix) {
-    const char *prefix = getenv("SMALTGPU_INDEX_PREFIX");
-    if (!prefix || smaltgpu_index_load(&g_ix, prefix, 0)) { pthread_mutex_unlock(&g_lock); return -1; }
+  if (!g_ndev) {                    /* worker threads are dealt round-robin to the devices (SMALTGPU_NDEV limits them) */
+    const char *e = getenv("SMALTGPU_NDEV");
+    g_ndev = smaltgpu_device_count();
+    if (e && atoi(e) > 0 && atoi(e) < g_ndev) g_ndev = atoi(e);
+    if (g_ndev > GPU_MAXDEV) g_ndev = GPU_MAXDEV;
+    if (g_ndev < 1) { g_ndev = 0; pthread_mutex_unlock(&g_lock); return -1; }
   }
   for (i = 0; i < g_nmap; i++) if (g_map[i].rmp == rmp) { slot = i; break; }
   if (slot < 0 && g_nmap < GPU_MAXMAPPERS) { slot = g_nmap++; memset(&g_map[slot], 0, sizeof(g_map[slot])); g_map[slot].rmp = rmp; }
+  if (slot >= 0 && !g_ixdev[slot % g_ndev]) {
+    const char *prefix = getenv("SMALTGPU_INDEX_PREFIX");
+    if (!prefix || smaltgpu_index_load(&g_ixdev[slot % g_ndev], prefix, slot % g_ndev)) { pthread_mutex_unlock(&g_lock); return -1; }
+  }
   pthread_mutex_unlock(&g_lock);
   if (slot < 0) return -1;
   if (!g_map[slot].mp || g_map[slot].maxlen < rlen || g_map[slot].maxreads < nreads) {
@@ -61,7 +71,7 @@ static int gpuMapperForBatch(const RMap *rmp, uint32_t rlen, uint32_t nreads, si
     while (rcap < nreads) rcap *= 2;
     if (g_map[slot].mp) smaltgpu_mapper_free(g_map[slot].mp);
     g_map[slot].mp = NULL;
-    if (smaltgpu_mapper_create(&g_map[slot].mp, g_ix, rcap, cap)) return -1;
+    if (smaltgpu_mapper_create(&g_map[slot].mp, g_ixdev[slot % g_ndev], rcap, cap)) return -1;
     g_map[slot].maxlen = cap; g_map[slot].maxreads = rcap;
     free(g_map[slot].off);
     if (!(g_map[slot].off = malloc(((size_t)rcap + 1) * sizeof(uint64_t)))) return -1;
