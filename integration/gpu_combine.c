@@ -1,0 +1,161 @@
+/* gpu_combine.c -- OUR host glue of the batched binding (integration/rmap_gpu.c): worker threads of `smalt map -n T`
+ * each hand over a block of nthreads x 32 reads at a time; one GPU batch per block is too small to fill the device
+ * (60 k reads/s at 512 reads per batch against 400 k+ at 32 k).  The threads therefore meet here: whoever arrives while
+ * no batch is being assembled becomes the leader, waits a moment for the others, maps everything that is pending as ONE
+ * batch on one shared mapper (smaltgpu_map_batch), and hands every thread its slice of the results.  Plain C on top
+ * of the C ABI; nothing of the reference is needed here. */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "smaltgpu.h"
+#include "gpu_combine.h"
+
+enum { COMB_MAXDEV = 16, COMB_MAXREQ = 512, COMB_MAXREADS = 65536 };
+
+typedef struct {
+  const char *bases, *quals; const uint64_t *off; uint32_t n;
+  const smaltgpu_params *par;
+  GpuCombOut *out;
+  int done, rv;
+} CombReq;
+
+static struct CombDev {
+  pthread_mutex_t mu; pthread_cond_t cv; int init;
+  CombReq *pending[COMB_MAXREQ]; int npending; int leader;
+  smaltgpu_mapper *mp; uint32_t cap_reads, cap_len;
+  char *bases, *quals; uint64_t *off; size_t basecap;
+} g_dev[COMB_MAXDEV];
+static pthread_mutex_t g_init = PTHREAD_MUTEX_INITIALIZER;
+
+static int grow(void **p, size_t *cap, size_t need, size_t elem)
+{
+  if (*cap >= need) return 0;
+  size_t c = *cap ? *cap : 64;
+  while (c < need) c *= 2;
+  void *q = realloc(*p, c * elem);
+  if (!q) return -1;
+  *p = q; *cap = c;
+  return 0;
+}
+
+/* one combined batch: reqs[0..nreq) on device d */
+static void run_batch(struct CombDev *d, const smaltgpu_index *ix, CombReq **reqs, int nreq)
+{
+  uint32_t ntot = 0, maxlen = 1, r0;
+  size_t nb = 0;
+  int i, has_qual = 1, rv = 0;
+  smaltgpu_batch_out o;
+  for (i = 0; i < nreq; i++) {
+    uint32_t j;
+    ntot += reqs[i]->n; nb += (size_t)reqs[i]->off[reqs[i]->n];
+    if (!reqs[i]->quals) has_qual = 0;
+    for (j = 0; j < reqs[i]->n; j++) { const uint32_t l = (uint32_t)(reqs[i]->off[j + 1] - reqs[i]->off[j]); if (l > maxlen) maxlen = l; }
+  }
+  if (!d->mp || d->cap_reads < ntot || d->cap_len < maxlen) {
+    uint32_t cr = d->cap_reads > 16384 ? d->cap_reads : 16384, cl = d->cap_len > 64 ? d->cap_len : 64;
+    while (cr < ntot) cr *= 2;
+    if (cl < maxlen) cl = (maxlen + 31u) & ~31u;
+    if (d->mp) smaltgpu_mapper_free(d->mp);
+    d->mp = NULL;
+    free(d->off);
+    d->off = malloc(((size_t)cr + 1) * sizeof(uint64_t));
+    if (!d->off || smaltgpu_mapper_create(&d->mp, ix, cr, cl)) rv = SMALTGPU_ENOMEM;
+    else { d->cap_reads = cr; d->cap_len = cl; }
+  }
+  if (!rv && d->basecap < nb + 1) {
+    free(d->bases); free(d->quals);
+    d->basecap = 2 * nb + 4096;
+    d->bases = malloc(d->basecap); d->quals = malloc(d->basecap);
+    if (!d->bases || !d->quals) rv = SMALTGPU_ENOMEM;
+  }
+  if (!rv) {
+    size_t pos = 0;
+    uint32_t k = 0;
+    for (i = 0; i < nreq; i++) {
+      uint32_t j;
+      const size_t len = (size_t)reqs[i]->off[reqs[i]->n];
+      memcpy(d->bases + pos, reqs[i]->bases, len);
+      if (has_qual) memcpy(d->quals + pos, reqs[i]->quals, len);
+      for (j = 0; j < reqs[i]->n; j++) d->off[k++] = pos + reqs[i]->off[j];
+      pos += len;
+    }
+    d->off[k] = pos;
+    rv = smaltgpu_map_batch(d->mp, (const uint8_t *)d->bases, has_qual ? (const uint8_t *)d->quals : NULL, d->off, ntot, reqs[0]->par, &o);
+  }
+  for (i = 0, r0 = 0; i < nreq; i++) {                    /* every request gets its own copy of its slice */
+    CombReq *q = reqs[i];
+    GpuCombOut *w = q->out;
+    q->rv = rv;
+    if (!rv) {
+      const uint64_t a = o.res_off[r0], b = o.res_off[r0 + q->n];
+      uint64_t j;
+      size_t nd = 0;
+      uint32_t t;
+      for (j = a; j < b; j++) nd += o.res[j].strlen;
+      if (grow((void **)&w->res_off, &w->cap_off, (size_t)q->n + 1, sizeof(uint64_t)) || grow((void **)&w->stat, &w->cap_stat, q->n, sizeof(smaltgpu_readstat)) ||
+          grow((void **)&w->res, &w->cap_res, (size_t)(b - a) + 1, sizeof(smaltgpu_result)) || grow((void **)&w->dstr, &w->cap_dstr, nd + 1, 1)) q->rv = SMALTGPU_ENOMEM;
+      else {
+        for (t = 0; t <= q->n; t++) w->res_off[t] = o.res_off[r0 + t] - a;
+        memcpy(w->stat, o.stat + r0, (size_t)q->n * sizeof(smaltgpu_readstat));
+        for (j = a, nd = 0; j < b; j++) {
+          w->res[j - a] = o.res[j];
+          memcpy(w->dstr + nd, o.diffstr + o.res[j].stroffs, o.res[j].strlen);
+          w->res[j - a].stroffs = (uint32_t)nd;
+          nd += o.res[j].strlen;
+        }
+        w->n = q->n;
+      }
+    }
+    r0 += q->n;
+  }
+}
+
+int gpuCombineSubmit(int dev, const smaltgpu_index *ix, const char *bases, const char *quals, const uint64_t *off, uint32_t n,
+                     const smaltgpu_params *par, GpuCombOut *out)
+{
+  struct CombDev *d;
+  CombReq req;
+  if (dev < 0 || dev >= COMB_MAXDEV || !n) return SMALTGPU_EARG;
+  d = &g_dev[dev];
+  pthread_mutex_lock(&g_init);
+  if (!d->init) { pthread_mutex_init(&d->mu, NULL); pthread_cond_init(&d->cv, NULL); d->init = 1; }
+  pthread_mutex_unlock(&g_init);
+  req.bases = bases; req.quals = quals; req.off = off; req.n = n; req.par = par; req.out = out; req.done = 0; req.rv = 0;
+  pthread_mutex_lock(&d->mu);
+  while (d->npending >= COMB_MAXREQ) pthread_cond_wait(&d->cv, &d->mu);
+  d->pending[d->npending++] = &req;
+  pthread_cond_broadcast(&d->cv);
+  while (!req.done) {
+    if (!d->leader) {
+      CombReq *take[COMB_MAXREQ];
+      int ntake = 0, i, rounds;
+      uint32_t reads = 0;
+      d->leader = 1;
+      for (rounds = 0; rounds < 8; rounds++) {              /* let the other workers arrive: up to 8 x 250 us while requests keep coming */
+        struct timespec ts;
+        const int before = d->npending;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        ts.tv_nsec += 250000;
+        if (ts.tv_nsec >= 1000000000L) { ts.tv_sec++; ts.tv_nsec -= 1000000000L; }
+        (void)pthread_cond_timedwait(&d->cv, &d->mu, &ts);
+        if (d->npending == before) break;
+      }
+      for (i = 0; i < d->npending; i++) {
+        if (ntake && reads + d->pending[i]->n > COMB_MAXREADS) break;
+        reads += d->pending[i]->n; take[ntake++] = d->pending[i];
+      }
+      memmove(d->pending, d->pending + ntake, (size_t)(d->npending - ntake) * sizeof(d->pending[0]));
+      d->npending -= ntake;
+      pthread_mutex_unlock(&d->mu);
+      run_batch(d, ix, take, ntake);
+      pthread_mutex_lock(&d->mu);
+      for (i = 0; i < ntake; i++) take[i]->done = 1;
+      d->leader = 0;
+      pthread_cond_broadcast(&d->cv);
+    } else pthread_cond_wait(&d->cv, &d->mu);
+  }
+  pthread_mutex_unlock(&d->mu);
+  return req.rv;
+}

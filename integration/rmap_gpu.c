@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "smaltgpu.h"
+#include "gpu_combine.h"
 
 /* results_inject.c (our TU around the reference's results.c) */
 extern int resultSetInjectRaw(ResultSet *rsp, unsigned n, const smaltgpu_result *res, const unsigned char *dstr,
@@ -37,15 +38,16 @@ static struct {
   const RMap *rmp; smaltgpu_mapper *mp; uint32_t maxlen, maxreads;
   char *bases, *quals; uint64_t *off; size_t basecap;
   smaltgpu_batch_out out; int nbatch;          /* results of the last rmapGpuBatch */
+  GpuCombOut comb; int use_comb;               /* ... when they came from a combined batch (gpu_combine.c) */
 } g_map[GPU_MAXMAPPERS];
 static int g_nmap = 0;
 
 static int gpuMapperFor(const RMap *rmp, uint32_t rlen);
-static int gpuMapperForBatch(const RMap *rmp, uint32_t rlen, uint32_t nreads, size_t nbases);
+static int gpuMapperForBatch(const RMap *rmp, uint32_t rlen, uint32_t nreads, size_t nbases, int need_mapper);
 
-static int gpuMapperFor(const RMap *rmp, uint32_t rlen) { return gpuMapperForBatch(rmp, rlen, 1, rlen); }
+static int gpuMapperFor(const RMap *rmp, uint32_t rlen) { return gpuMapperForBatch(rmp, rlen, 1, rlen, 1); }
 
-static int gpuMapperForBatch(const RMap *rmp, uint32_t rlen, uint32_t nreads, size_t nbases)
+static int gpuMapperForBatch(const RMap *rmp, uint32_t rlen, uint32_t nreads, size_t nbases, int need_mapper)
 {
   int i, slot = -1;
   pthread_mutex_lock(&g_lock);
@@ -64,7 +66,16 @@ static int gpuMapperForBatch(const RMap *rmp, uint32_t rlen, uint32_t nreads, si
   }
   pthread_mutex_unlock(&g_lock);
   if (slot < 0) return -1;
-  if (!g_map[slot].mp || g_map[slot].maxlen < rlen || g_map[slot].maxreads < nreads) {
+  if (!need_mapper) {                          /* combined batches: only the host staging buffers of this worker */
+    if (g_map[slot].maxreads < nreads) {
+      uint32_t rcap = g_map[slot].maxreads > 1 ? g_map[slot].maxreads : 1;
+      while (rcap < nreads) rcap *= 2;
+      if (g_map[slot].mp) { smaltgpu_mapper_free(g_map[slot].mp); g_map[slot].mp = NULL; g_map[slot].maxlen = 0; }
+      free(g_map[slot].off);
+      if (!(g_map[slot].off = malloc(((size_t)rcap + 1) * sizeof(uint64_t)))) return -1;
+      g_map[slot].maxreads = rcap;
+    }
+  } else if (!g_map[slot].mp || g_map[slot].maxlen < rlen || g_map[slot].maxreads < nreads) {
     uint32_t cap = g_map[slot].maxlen > 64 ? g_map[slot].maxlen : 64, rcap = g_map[slot].maxreads > 1 ? g_map[slot].maxreads : 1;
     if (cap < rlen) cap = (rlen + 31u) & ~31u;                /* scratch is sized by the longest read */
     setenv("SMALTGPU_SLOT_BUDGET_GB", "6", 0);            /* one mapper per worker thread shares the device */
@@ -156,7 +167,8 @@ int rmapGpuBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, int n, int 
   short mismatchscor, gapinitscor, gapextscor, matchscor;
   smaltgpu_params par;
   for (i = 0; i < n; i++) { (void)seqFastqGetConstSequence(reads[i], &rlen, &cod); tot += rlen; if (rlen > maxlen) maxlen = rlen; }
-  if ((slot = gpuMapperForBatch(rmp, maxlen, (uint32_t)n, tot)) < 0) { fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error()); ERRMSGNO(errmsgp, ERRCODE_FAILURE); }
+  const int combine = !getenv("SMALTGPU_NO_COMBINE");       /* default: blocks of all worker threads form one GPU batch */
+  if ((slot = gpuMapperForBatch(rmp, maxlen, (uint32_t)n, tot, !combine)) < 0) { fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error()); ERRMSGNO(errmsgp, ERRCODE_FAILURE); }
   for (i = 0, tot = 0; i < n; i++) {
     const char *seqp = seqFastqGetConstSequence(reads[i], &rlen, &cod);
     const char *qualp = seqFastqGetConstQualityFactors(reads[i], &qlen, &qcod);
@@ -176,7 +188,16 @@ int rmapGpuBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, int n, int 
   if (tupcovmin < 1.01) { par.min_cover = 0; par.min_cover_frac = tupcovmin; }      /* smalt.c:1113-1126 */
   else { par.min_cover = (uint32_t)tupcovmin; par.min_cover_frac = 0.0; }
   g_map[slot].nbatch = 0;
-  if (smaltgpu_map_batch(g_map[slot].mp, (const uint8_t *)g_map[slot].bases, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
+  g_map[slot].use_comb = combine;
+  if (combine) {
+    if (gpuCombineSubmit(slot % g_ndev, g_ixdev[slot % g_ndev], g_map[slot].bases, has_qual ? g_map[slot].quals : NULL, g_map[slot].off,
+                         (uint32_t)n, &par, &g_map[slot].comb)) {
+      fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error());
+      ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+    }
+    g_map[slot].out.nreads = (uint32_t)n; g_map[slot].out.res_off = g_map[slot].comb.res_off; g_map[slot].out.res = g_map[slot].comb.res;
+    g_map[slot].out.diffstr = g_map[slot].comb.dstr; g_map[slot].out.stat = g_map[slot].comb.stat;
+  } else if (smaltgpu_map_batch(g_map[slot].mp, (const uint8_t *)g_map[slot].bases, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
                          g_map[slot].off, (uint32_t)n, &par, &g_map[slot].out)) {
     fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error());
     ERRMSGNO(errmsgp, ERRCODE_FAILURE);
@@ -192,7 +213,7 @@ int rmapGpuFinish(ErrMsg *errmsgp, RMap *rmp, int i, SeqFastq *readp, short max_
   int errcode, slot;
   uint32_t rlen;
   const smaltgpu_batch_out *o;
-  if ((slot = gpuMapperFor(rmp, 1)) < 0 || i < 0 || i >= g_map[slot].nbatch) ERRMSGNO(errmsgp, ERRCODE_ASSERT);
+  if ((slot = gpuMapperForBatch(rmp, 1, 1, 1, 0)) < 0 || i < 0 || i >= g_map[slot].nbatch) ERRMSGNO(errmsgp, ERRCODE_ASSERT);
   o = &g_map[slot].out;
   rmapBlank(rmp);
   if ((errcode = makeRMAPPROFfromRead(rmp->prp, readp, scormtxp, codecp))) ERRMSGNO(errmsgp, errcode);
