@@ -142,8 +142,9 @@ int gpuCombineSubmit(int dev, const smaltgpu_index *ix, const char *bases, const
         (void)pthread_cond_timedwait(&d->cv, &d->mu, &ts);
         if (d->npending == before) break;
       }
+      const uint32_t maxreads = getenv("SMALTGPU_COMBINE_READS") ? (uint32_t)atoi(getenv("SMALTGPU_COMBINE_READS")) : (uint32_t)COMB_MAXREADS;
       for (i = 0; i < d->npending; i++) {
-        if (ntake && reads + d->pending[i]->n > COMB_MAXREADS) break;
+        if (ntake && reads + d->pending[i]->n > maxreads) break;
         reads += d->pending[i]->n; take[ntake++] = d->pending[i];
       }
       memmove(d->pending, d->pending + ntake, (size_t)(d->npending - ntake) * sizeof(d->pending[0]));

@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--reads", type=int, default=400000)
+    ap.add_argument("--reads", type=int, default=1000000)
     ap.add_argument("--cpu-reads", type=int, default=100000)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--gpu-threads", type=int, default=0, help="worker threads of the bound program (0: same as --threads)")
@@ -68,9 +68,9 @@ def main():
         write_fq(cpu_fq, a.cpu_reads)
         write_fq(gpu_fq, a.reads)
         env = dict(os.environ, SMALTGPU_INDEX_PREFIX=prefix)
-        t_c0 = run(smalt, a.threads, small, os.path.join(tmp, "c0.cig"))
+        t_c0 = min(run(smalt, a.threads, small, os.path.join(tmp, "c0.cig")) for _ in range(2))
         t_c1 = run(smalt, a.threads, cpu_fq, os.path.join(tmp, "c1.cig"))
-        t_g0 = run(smalt_gpu, gthreads, small, os.path.join(tmp, "g0.cig"), env)
+        t_g0 = min(run(smalt_gpu, gthreads, small, os.path.join(tmp, "g0.cig"), env) for _ in range(3))     # start-up (index load, device init) varies: best of three
         t_g1 = run(smalt_gpu, gthreads, gpu_fq, os.path.join(tmp, "g1.cig"), env)
         # same lines for the reads both programs mapped (the CPU run covers a prefix of the GPU run's reads)
         c = open(os.path.join(tmp, "c1.cig")).read().split("\n")
