@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument("--reads", type=int, default=1_000_000)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--sub-batch", type=int, default=262144)
+    ap.add_argument("--streams", type=int, default=1, help="mappers (HIP streams) that take the sub-batches in turn: kernels of consecutive sub-batches overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-buffers", action="store_true", help="also time smaltgpu_map_batch on pageable host buffers (PCIe-inclusive rate, extra field)")
     ap.add_argument("--cpu-sample", type=int, default=150000)
@@ -167,7 +168,8 @@ def main():
     par = gix.default_params()
     sub = min(args.sub_batch, args.reads)
     os.environ.setdefault("SMALTGPU_CANDS_PER_READ", "768")
-    mapper = api.Mapper(gix, sub, args.read_len)
+    mappers = [api.Mapper(gix, sub, args.read_len) for _ in range(max(1, args.streams))]
+    mapper = mappers[0]
     offs = torch.arange(sub + 1, dtype=torch.int64, device=dev) * args.read_len
     torch.cuda.synchronize()
 
@@ -175,19 +177,29 @@ def main():
 
     def one_step(collect):
         mapped = total_res = 0
-        for b0 in range(0, args.reads, sub):
-            n = min(sub, args.reads - b0)
-            mapper.map_batch_device(reads_ascii.data_ptr() + b0 * args.read_len, 0, offs.data_ptr(), n, n * args.read_len, par)
-            out = mapper.fetch_results()
+        pending = []                      # (mapper, n) whose kernels are enqueued and whose results have not been fetched
+
+        def fetch(mp, n):
+            nonlocal mapped, total_res
+            out = mp.fetch_results()
             st = np.ctypeslib.as_array(C.cast(out.stat, C.POINTER(C.c_uint32)), shape=(n, 8))
             mapped += int((st[:, 7] > 0).sum())
             total_res += int(out.res_off[n])
             if collect:
-                ms, wk = mapper.timers()
+                ms, wk = mp.timers()
                 for kk, v in ms.items():
                     ms_acc[kk] = ms_acc.get(kk, 0.0) + v
                 for i in range(24):
                     work_acc[i] += wk[i]
+        for bi, b0 in enumerate(range(0, args.reads, sub)):
+            n = min(sub, args.reads - b0)
+            mp = mappers[bi % len(mappers)]
+            if len(pending) == len(mappers):          # this mapper still holds the results of its previous sub-batch
+                fetch(*pending.pop(0))
+            mp.map_batch_device(reads_ascii.data_ptr() + b0 * args.read_len, 0, offs.data_ptr(), n, n * args.read_len, par)
+            pending.append((mp, n))
+        while pending:
+            fetch(*pending.pop(0))
         return mapped, total_res
 
     import ctypes as C
@@ -244,7 +256,7 @@ def main():
                        % (args.reads, args.read_len, nchr, args.chr_mbp, k, s),
                        "reads_per_gpu_per_step": args.reads, "sub_batch": sub, "mapped_fraction": mapped_all / (world * args.steps * args.reads),
                        "reads_per_s_total": world * args.steps * args.reads / dt, "setup_s": setup_s, "index_broadcast_ms": bcast_ms,
-                       "parallelism": "read-shard x%d" % world},
+                       "parallelism": "read-shard x%d" % world, "streams": len(mappers)},
             "roofline": roof_sw if dom in ("sw_full",) else roof_seed,
             "roofline_sw": roof_sw, "roofline_seed": roof_seed,
             "kernel_ms_per_step": {kk: v / args.steps for kk, v in ms_acc.items()},
@@ -271,7 +283,8 @@ def main():
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 line["cpu_baseline"] = dict(value=None, unit="mapped reads/s", cores=0, kind="reference", sample="failed: %r" % (e,))
         print(json.dumps(line))
-    mapper.close()
+    for mp_ in mappers:
+        mp_.close()
     gix.close()
     if world > 1:
         dist.destroy_process_group()

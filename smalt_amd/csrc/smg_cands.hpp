@@ -74,24 +74,6 @@ SMG_HD inline bool seed_break(uint64_t a, uint64_t b, int k, int s) {
   return key_diag(a) != key_diag(b) || qb > qa + (uint32_t)k || ((qb - qa) % (uint32_t)s) != 0;
 }
 
-// 256-bit read-coverage mask in registers
-struct QMask256 { uint32_t w[8]; };
-SMG_HD inline void qm_clear(QMask256 &m) { for (int i = 0; i < 8; i++) m.w[i] = 0; }
-// add [q, q+len) ; returns the number of newly covered bases
-SMG_HD inline uint32_t qm_add(QMask256 &m, uint32_t q, uint32_t len) {
-  uint32_t added = 0;
-  const uint32_t e = q + len;
-  for (int i = 0; i < 8; i++) {
-    const uint32_t lo = (uint32_t)i * 32, hi = lo + 32;
-    if (e <= lo || q >= hi) continue;
-    const uint32_t a = q > lo ? q - lo : 0, b = e < hi ? e - lo : 32;
-    const uint32_t bits = (b >= 32 ? 0xFFFFFFFFu : ((1u << b) - 1)) & ~((1u << a) - 1);
-    added += (uint32_t)__builtin_popcount(bits & ~m.w[i]);
-    m.w[i] |= bits;
-  }
-  return added;
-}
-
 // calcSegmentBoundaries (segment.c:635-668) from the compact arrays
 template <class IT>
 SMG_HD inline void segm_bounds(const StrandWork<IT> &w, uint32_t m, int k, int s, bool is_reverse, uint32_t *qs, uint32_t *qe,

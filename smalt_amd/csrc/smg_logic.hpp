@@ -671,4 +671,23 @@ SMG_HD inline int diffstr_reverse(uint8_t *out, const uint8_t *in, int n) {
   return u;
 }
 
+// 256-bit read-coverage mask in registers
+struct QMask256 { uint32_t w[8]; };
+SMG_HD inline void qm_clear(QMask256 &m) { for (int i = 0; i < 8; i++) m.w[i] = 0; }
+// add [q, q+len) ; returns the number of newly covered bases
+SMG_HD inline uint32_t qm_add(QMask256 &m, uint32_t q, uint32_t len) {
+  uint32_t added = 0;
+  const uint32_t e = q + len;
+  for (int i = 0; i < 8; i++) {
+    const uint32_t lo = (uint32_t)i * 32, hi = lo + 32;
+    if (e <= lo || q >= hi) continue;
+    const uint32_t a = q > lo ? q - lo : 0, b = e < hi ? e - lo : 32;
+    const uint32_t bits = (b >= 32 ? 0xFFFFFFFFu : ((1u << b) - 1)) & ~((1u << a) - 1);
+    added += (uint32_t)__builtin_popcount(bits & ~m.w[i]);
+    m.w[i] |= bits;
+  }
+  return added;
+}
+
+
 }  // namespace smg

@@ -11,6 +11,7 @@
 #include "smg_common.h"
 #include "smg_exec.h"
 #include "smg_logic.hpp"
+#include "smg_wsort.hpp"
 
 namespace smg {
 
@@ -100,11 +101,14 @@ struct SeedScratch {          // per wave; capacity qmax each unless noted
   uint32_t *frame_rank;       // [s * stride]
   uint8_t *qbuf;              // [qmax]
   uint32_t stride;
+  uint32_t *kv;               // [qmax] packed (nhits << 12 | seed) for the wave form of the rarity sort
+  uint32_t *wk;               // [SEED_WSORT_WORDS] its work words; also the prefix sums of the seed budget
 };
+enum : int { SEED_IDXBITS = 12, SEED_LISTCAP = 32, SEED_LSTK = 12, SEED_WSORT_WORDS = 256 + 2 * SEED_LISTCAP + 64 * SEED_LSTK };
 
 SMG_HD inline size_t seed_scratch_bytes(uint32_t qmax, int s) {
   uint32_t stride = qmax / (uint32_t)s + 2;
-  return (size_t)qmax * (4 + 8 + 4 + 4 + 4 + 4 + 4 + 1) + (size_t)s * 4 + (size_t)s * stride * 4 + 64;
+  return (size_t)qmax * (4 + 8 + 4 + 4 + 4 + 4 + 4 + 1 + 4) + (size_t)SEED_WSORT_WORDS * 4 + (size_t)s * 4 + (size_t)s * stride * 4 + 64;
 }
 
 SMG_HD inline SeedScratch seed_scratch_carve(uint8_t *base, uint32_t qmax, int s) {
@@ -119,6 +123,8 @@ SMG_HD inline SeedScratch seed_scratch_carve(uint8_t *base, uint32_t qmax, int s
   x.stride = qmax / (uint32_t)s + 2;
   x.frame_cnt = (uint32_t *)base; base += (size_t)s * 4;
   x.frame_rank = (uint32_t *)base; base += (size_t)s * x.stride * 4;
+  x.kv = (uint32_t *)base; base += (size_t)qmax * 4;
+  x.wk = (uint32_t *)base; base += (size_t)SEED_WSORT_WORDS * 4;
   x.qbuf = base;
   return x;
 }
@@ -197,7 +203,75 @@ SMG_HD inline uint32_t stage_seed(const Batch &b, const DevIndex &ix, const MapP
   }
   SMG_SYNC();
 
-  // (3) rarity ranking + budget: sequential (sort.c:233 tie order; hashhit.c:769)
+  // (3) rarity ranking + seed budget (sort.c:233 tie order; getHitInfoMaxRank, hashhit.c:769-891).
+  // Wave form for reads of up to 256 bases whose seeds and hit counts fit the packed sort element: the unstable
+  // quicksort is emulated exactly (smg_wsort.hpp); the budget is a prefix sum over the sorted hit counts; the
+  // per-frame coverage loops run one lane per sampling frame with the read coverage as a 256-bit register mask.
+  uint32_t maxkey = 0;
+  SMG_PAR_CHUNKS(base, nseeds) { const uint32_t i = base + SMG_LANE; if (i < nseeds && x.key[i] > maxkey) maxkey = x.key[i]; }
+  maxkey = wave_max_u32(maxkey);
+  const bool wave_form = !noshort && nseeds > 1 && qlen <= 256 && nseeds < (1u << SEED_IDXBITS) && maxkey < (1u << (32 - SEED_IDXBITS));
+  if (wave_form) {
+    SMG_PAR_CHUNKS(base, nseeds) { const uint32_t i = base + SMG_LANE; if (i < nseeds) x.kv[i] = (x.key[i] << SEED_IDXBITS) | i; }
+    SMG_SYNC();
+    wave_sort_kv<SEED_IDXBITS, SEED_LISTCAP, SEED_LSTK>(x.kv, (int)nseeds, (int)nseeds, x.wk);
+    SMG_SYNC();
+    uint32_t run = 0;                                   // inclusive prefix sums of the sorted hit counts -> x.wk
+    SMG_PAR_CHUNKS(base, nseeds) {
+      const uint32_t i = base + SMG_LANE;
+      uint32_t v = 0;
+      if (i < nseeds) { v = x.kv[i] >> SEED_IDXBITS; x.key[i] = v; x.sidx[i] = x.kv[i] & ((1u << SEED_IDXBITS) - 1u); x.qbr[i] = x.sqoffs[x.sidx[i]]; }
+      uint32_t incl = v;
+#if defined(__HIP_DEVICE_COMPILE__)
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)incl, o); if ((int)SMG_LANE >= o) incl += u; }
+#endif
+      if (i < nseeds) x.wk[i] = run + incl;
+#if defined(__HIP_DEVICE_COMPILE__)
+      run += (uint32_t)__shfl((int)incl, 63);
+#else
+      run += incl;
+#endif
+    }
+    SMG_SYNC();
+    uint32_t mincover = (uint32_t)(HITINFO_MINCOVER_KMER * k + s);
+    uint32_t maxcover = qlen * HITINFO_MAXCOVER_PERCENT / 100;
+    if (maxcover < (uint32_t)(k + s)) maxcover = (uint32_t)(k + s);
+    else if (maxcover > qlen - (uint32_t)s) maxcover = qlen - (uint32_t)s;
+    if (mincover > maxcover) { mincover = 0; maxcover = qlen; }
+    // n = first rank whose inclusive prefix exceeds HASH_MAXNHITS (hashhit.c:822-827), n_seeds if none
+    uint32_t nbud = nseeds;
+    SMG_PAR_CHUNKS(base, nseeds) { const uint32_t i = base + SMG_LANE; if (i < nseeds && x.wk[i] > (uint32_t)HASH_MAXNHITS && i < nbud) nbud = i; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t u = (uint32_t)__shfl_xor((int)nbud, o); if (u < nbud) nbud = u; }
+#endif
+    uint32_t nmax = nbud;
+    SMG_PAR_CHUNKS(base, (uint32_t)s) {                // one lane per sampling frame (:860-882)
+      const uint32_t f = base + SMG_LANE;
+      if (f < (uint32_t)s) {
+        QMask256 mk;
+        qm_clear(mk);
+        uint32_t cover = 0;
+        int last = -1;
+        for (uint32_t rk = 0; rk < nseeds; rk++) {
+          const uint32_t q0 = x.qbr[rk];
+          if (q0 % (uint32_t)s != f) continue;
+          if (!(cover <= maxcover && (cover < mincover || rk <= nbud))) break;
+          cover += qm_add(mk, q0, (uint32_t)k - 1);      // k-1 bases (hashhit.c:873)
+          last = (int)rk;
+        }
+        if (last >= 0 && (uint32_t)last > nmax) nmax = (uint32_t)last;
+      }
+    }
+    nmax = wave_max_u32(nmax);
+    uint32_t seed_rank = nmax;
+    if (nmax < (uint32_t)HITINFO_MINSEEDNUM) seed_rank = ((uint32_t)HITINFO_MINSEEDNUM < nseeds) ? (uint32_t)HITINFO_MINSEEDNUM : nseeds;
+    SMG_LANE0 {
+      const uint32_t ns = seed_rank > 0 ? seed_rank : nseeds;          // hashhit.c:1200-1219
+      hdr.nhit_rank = ns ? x.wk[ns - 1] : 0;
+      hdr.nhit_tot = x.wk[nseeds - 1];
+      hdr.n_seeds = nseeds; hdr.seed_rank = seed_rank; hdr.status = (st ? HI_REVERSE : 0) | HI_SORTED | HI_RANK; hdr.qlen = qlen;
+    }
+  } else
   SMG_LANE0 {
     uint32_t status = st ? HI_REVERSE : 0, seed_rank = 0;
     if (!noshort) {

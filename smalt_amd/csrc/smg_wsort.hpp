@@ -20,9 +20,10 @@ namespace smg {
 enum : int { WSORT_IDXBITS = 22, WSORT_SMALL = 32, WSORT_LISTCAP = 256, WSORT_LSTK = 16,
              WSORT_WORDS = 128 + 128 + 2 * WSORT_LISTCAP + 64 * WSORT_LSTK,   // LDS words of the wave sort
              WSORT_NBINS = 320 };
-#define SMG_KVKEY(v) ((v) >> WSORT_IDXBITS)
+#define SMG_KVKEY(v) ((v) >> IB)       // IB: index bits of the packed element (template parameter of the routines below)
 
 // the reference's routine on the sub-range [lo, hi] of a packed array; stk: >= 2*log2(hi-lo+1)+2 ints
+template <int IB = WSORT_IDXBITS>
 SMG_HD inline void qsort_kv_range(uint32_t *a, int lo, int hi, int *stk) {
   int i, j, mid, sp = 0;
   uint32_t pv, t;
@@ -61,6 +62,7 @@ SMG_HD inline void qsort_kv_range(uint32_t *a, int lo, int hi, int *stk) {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // One partition step of [lo, hi] (hi - lo >= 7) by the wave; returns the reference's final i and j.
+template <int IB = WSORT_IDXBITS>
 __device__ inline void wave_partition_kv(uint32_t *a, int lo, int hi, uint32_t *pairs, int &out_i, int &out_j) {
   const int lane = (int)threadIdx.x;
   const uint64_t lt = (1ull << lane) - 1ull;
@@ -123,12 +125,14 @@ __device__ inline void wave_partition_kv(uint32_t *a, int lo, int hi, uint32_t *
 #endif
 
 // Sort a[0..n) like the reference does, at least up to position nneed.  wk: WSORT_WORDS words (LDS).
+// wk: 256 + 2 * LISTCAP + 64 * LSTK words (WSORT_WORDS with the defaults); LSTK >= 2 * log2(WSORT_SMALL) + 2
+template <int IB = WSORT_IDXBITS, int LISTCAP = WSORT_LISTCAP, int LSTK = WSORT_LSTK>
 SMG_HD inline void wave_sort_kv(uint32_t *a, int n, int nneed, uint32_t *wk) {
   if (n < 2) return;
 #if defined(__HIP_DEVICE_COMPILE__)
   const int lane = (int)threadIdx.x;
   uint32_t *pairs = wk;
-  int *bstk = (int *)(wk + 128), *slist = (int *)(wk + 256), *lstk = (int *)(wk + 256 + 2 * WSORT_LISTCAP) + lane * WSORT_LSTK;
+  int *bstk = (int *)(wk + 128), *slist = (int *)(wk + 256), *lstk = (int *)(wk + 256 + 2 * LISTCAP) + lane * LSTK;
   int nb = 0, ns = 0;
   int lo = 0, hi = n - 1;
   bool have = true;
@@ -143,16 +147,16 @@ SMG_HD inline void wave_sort_kv(uint32_t *a, int n, int nneed, uint32_t *wk) {
     if (lo >= nneed || hi <= lo) continue;
     if (hi - lo + 1 <= WSORT_SMALL) {
       slist[2 * ns] = lo; slist[2 * ns + 1] = hi; ns++;   // every lane writes the same words
-      if (ns == WSORT_LISTCAP) {
+      if (ns == LISTCAP) {
         __syncthreads();
-        for (int t = lane; t < ns; t += 64) qsort_kv_range(a, slist[2 * t], slist[2 * t + 1], lstk);
+        for (int t = lane; t < ns; t += 64) qsort_kv_range<IB>(a, slist[2 * t], slist[2 * t + 1], lstk);
         __syncthreads();
         ns = 0;
       }
       continue;
     }
     int i, j;
-    wave_partition_kv(a, lo, hi, pairs, i, j);
+    wave_partition_kv<IB>(a, lo, hi, pairs, i, j);
     // [lo, j-1] and [i, hi]: keep the smaller one, park the larger (bounded stack)
     int plo, phi;
     if (hi - i + 1 >= j - lo) { plo = i; phi = hi; hi = j - 1; }
@@ -161,12 +165,12 @@ SMG_HD inline void wave_sort_kv(uint32_t *a, int n, int nneed, uint32_t *wk) {
     have = true;
   }
   __syncthreads();
-  for (int t = lane; t < ns; t += 64) qsort_kv_range(a, slist[2 * t], slist[2 * t + 1], lstk);
+  for (int t = lane; t < ns; t += 64) qsort_kv_range<IB>(a, slist[2 * t], slist[2 * t + 1], lstk);
   __syncthreads();
 #else
   (void)nneed; (void)wk;
   int stk[128];
-  qsort_kv_range(a, 0, n - 1, stk);
+  qsort_kv_range<IB>(a, 0, n - 1, stk);
 #endif
 }
 
