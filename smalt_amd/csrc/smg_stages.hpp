@@ -957,7 +957,21 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
   }
   SMG_SYNC();
   const uint32_t ncand = (ctl.go && qlen >= (uint32_t)ix.k) ? (uint32_t)ctl.n_scored : 0u;
-  for (uint32_t ci = 0; ci < ncand; ci++) {
+  // Candidates are visited in rank order, but only those whose first-pass score reaches the threshold are aligned
+  // (rmap.c:826-828), typically one to three of a few hundred, and the threshold only rises while the read is
+  // processed (rmap.c:881-885).  64 scores are tested at once against the initial threshold; the survivors are
+  // taken in order and tested again against the current one.
+  for (uint32_t cbase = 0; cbase < ncand && !x.state[S_ERR]; cbase += SMG_NLANES) {
+   const uint32_t cmy = cbase + SMG_LANE;
+   const bool cpass = cmy < ncand && rc[cmy].swscor >= ctl.min_swatscor;
+#if defined(__HIP_DEVICE_COMPILE__)
+   unsigned long long cmask = __ballot(cpass);
+#else
+   unsigned long long cmask = cpass ? 1ull : 0ull;
+#endif
+   while (cmask) {
+    const uint32_t ci = cbase + (uint32_t)__builtin_ctzll(cmask);
+    cmask &= cmask - 1ull;
     const RCand c = rc[ci];
     if (x.state[S_ERR]) break;
     if (c.swscor < x.state[S_MINSW]) continue;            // rmap.c:826-828 (all ranked candidates are scored)
@@ -1113,6 +1127,7 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
       }
     }
     SMG_SYNC();
+  }
   }
   // ---- publish: exact-size slices of the result and string pools ----
   SMG_LANE0 {
