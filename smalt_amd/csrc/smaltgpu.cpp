@@ -267,9 +267,9 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
   {
     m->wincap = 4 * m->qmax + 1024;
     m->strip_grid = 2048;
-    if ((uint64_t)m->strip_grid * m->wincap * 17 > (4ull << 30)) m->strip_grid = (uint32_t)((4ull << 30) / ((uint64_t)m->wincap * 17));
+    if ((uint64_t)m->strip_grid * m->wincap * 18 > (4ull << 30)) m->strip_grid = (uint32_t)((4ull << 30) / ((uint64_t)m->wincap * 18));
     if (!rv) rv = dalloc((uint8_t **)&m->strip_bnd, (size_t)m->strip_grid * 2 * m->wincap * 8);
-    DA(m->strip_win, (size_t)m->strip_grid * m->wincap);
+    DA(m->strip_win, (size_t)m->strip_grid * m->wincap * 2);      // code pairs of the packed strip kernel
     m->dircap = (uint64_t)(m->qmax + 64) * (m->wincap + 8);
     m->rescap_slot = 512; m->dstrcap_slot = 512 * (m->qmax / 4 + 48);
     m->align_bytes = align_scratch_bytes(m->qmax, m->wincap, m->dircap, m->rescap_slot, m->dstrcap_slot);

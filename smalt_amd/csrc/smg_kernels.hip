@@ -550,6 +550,150 @@ __device__ inline void sw_tab8(uint2 *tab, const MapPar &p, int bias) {
   }
 }
 
+// The same in packed 16-bit halves: two tasks per wave (as k_sw_full16; reads without non-ACGT codes, scores < 65535).
+// win2: per-row code pairs (low byte task A, high byte task B); bnd: 2 x wcap packed (H pair, F pair).
+__device__ inline uint32_t sw_strip16_core(const uint8_t *qa, uint32_t qlen_a, const uint8_t *qb, uint32_t qlen_b, const uint16_t *win2, uint32_t wmax,
+                                           uint2 *bnd, uint32_t wcap, const uint32_t *rowtab, uint2 *ring /* LDS [256] */, const Sw16Par &sp) {
+  constexpr int C = SW_STRIP_C;
+  const int g = (int)threadIdx.x;
+  uint2 *ring_in = ring, *ring_out = ring + 128;
+  us2 best = us2{0, 0};
+  const uint32_t qmaxlen = qlen_a > qlen_b ? qlen_a : qlen_b;
+  const uint32_t nstrip = (qmaxlen + 64 * C - 1) / (64 * C);
+  const int nstep = (int)wmax + 63;
+  for (uint32_t sidx = 0; sidx < nstrip; sidx++) {
+    const uint2 *bprev = bnd + (size_t)((sidx + 1) & 1) * wcap;
+    uint2 *bnext = bnd + (size_t)(sidx & 1) * wcap;
+    uint32_t sel[C];
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) {
+      const uint32_t j = sidx * 64 * C + (uint32_t)(g * C + cc);
+      const uint32_t sa = j < qlen_a ? (uint32_t)(qa[j] & 3) : 0x0cu, sb = j < qlen_b ? 4u + (uint32_t)(qb[j] & 3) : 0x0cu;
+      sel[cc] = 0x0c000c00u | sa | (sb << 16);
+    }
+    us2 H[C], E[C];
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) { H[cc] = us2{0, 0}; E[cc] = us2{0, 0}; }
+    us2 F = us2{0, 0}, prev_hl = us2{0, 0};
+    __syncthreads();
+    if (sidx > 0) ring_in[g] = g < (int)wmax ? bprev[g] : make_uint2(0, 0);
+    __syncthreads();
+    for (int step = 0; step < nstep; step++) {
+      const int row = step - g;
+      if (sidx > 0 && (step & 63) == 0) {
+        const int r1 = step + 64 + g;
+        ring_in[((step >> 6) + 1) % 2 * 64 + g] = r1 < (int)wmax ? bprev[r1] : make_uint2(0, 0);
+      }
+      const uint32_t rp = (row >= 0 && row < (int)wmax) ? win2[row] : 0x0505u;
+      const uint32_t rowA = rowtab[rp & 0xffu], rowB = rowtab[rp >> 8];
+      uint32_t hl = (uint32_t)wave_shr1((int)as_u32(H[C - 1]));
+      uint32_t fin = (uint32_t)wave_shr1((int)as_u32(F));
+      if (g == 0) {
+        if (sidx > 0) { const uint2 v = ring_in[(step >> 6) % 2 * 64 + (step & 63)]; hl = step < (int)wmax ? v.x : 0u; fin = step < (int)wmax ? v.y : 0u; }
+        else { hl = 0; fin = 0; }
+      }
+      us2 carry = prev_hl;
+      prev_hl = as_us2(hl);
+      F = as_us2(fin);
+#pragma unroll
+      for (int c0 = 0; c0 < C; c0 += 4) {
+        us2 t3[4];
+        const us2 last_old = H[c0 + 3];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const us2 w = as_us2(__builtin_amdgcn_perm(rowB, rowA, sel[c0 + u]));
+          const us2 dg = u == 0 ? carry : H[c0 + u - 1];
+          t3[u] = pk_max(pk_subs(dg + w, sp.bias), E[c0 + u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const us2 hh = pk_max(t3[u], F);
+          best = pk_max(best, hh);
+          H[c0 + u] = hh;
+          const us2 tt = pk_subs(hh, sp.gi);
+          E[c0 + u] = pk_max(pk_subs(E[c0 + u], sp.ge), tt);
+          F = pk_max(pk_subs(F, sp.ge), tt);
+        }
+        carry = last_old;
+      }
+      if (sidx + 1 < nstrip) {
+        if (g == 63 && row >= 0 && row < (int)wmax) ring_out[row & 127] = make_uint2(as_u32(H[C - 1]), as_u32(F));
+        const int rdone = step - 63;
+        if (rdone >= 0 && ((rdone & 63) == 63 || rdone == (int)wmax - 1)) {
+          __syncthreads();
+          const int r2 = (rdone & ~63) + g;
+          if (r2 <= rdone && r2 < (int)wmax) bnext[r2] = ring_out[r2 & 127];
+        }
+      }
+      if (sidx > 0 && (step & 63) == 63) __syncthreads();
+    }
+    __threadfence();
+  }
+  uint32_t bb = as_u32(best);
+  for (int o = 32; o > 0; o >>= 1) bb = as_u32(pk_max(as_us2(bb), as_us2((uint32_t)__shfl_xor((int)bb, o))));
+  return bb;
+}
+
+// packed strip kernel over the strip list: two consecutive list entries per wave; reads with non-ACGT codes are left
+// to k_sw_strip (32-bit lanes), which runs afterwards on whatever is still unscored
+__global__ void __launch_bounds__(64) k_sw_strip16(Batch b, DevIndex ix, MapPar p, uint2 *bnd_all, uint16_t *win_all, uint32_t wcap) {
+  const unsigned long long nlist = b.work[WK_STRIP_TASKS];
+  if (nlist == 0 || !b.strip_list || nlist > b.strip_cap) return;
+  __shared__ uint32_t rowtab[8];
+  __shared__ uint2 ring[256];
+  const Sw16Par sp = sw16_par(p);
+  sw16_rowtab(rowtab, sp);
+  __syncthreads();
+  const uint32_t npair = ((uint32_t)nlist + 1) / 2;
+  uint2 *bnd = bnd_all + (size_t)blockIdx.x * 2 * wcap;
+  uint16_t *win = win_all + (size_t)blockIdx.x * wcap;
+  unsigned long long cells = 0, ntasks_done = 0;
+  for (uint32_t tp = blockIdx.x; tp < npair; tp += gridDim.x) {
+    RCand c[2];
+    bool live[2] = {false, false};
+    uint32_t qlen[2] = {0, 0}, wlen[2] = {0, 0}, tix[2] = {0, 0};
+    uint64_t gbase[2] = {0, 0};
+    const uint8_t *q[2] = {b.codes, b.codes};
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const uint32_t tl = 2 * tp + (uint32_t)u;
+      if (tl < (uint32_t)nlist) {
+        tix[u] = b.strip_list[tl];
+        c[u] = b.rcpool[tix[u]];
+        qlen[u] = read_len(b, c[u].rid);
+        wlen[u] = (uint32_t)(c[u].re - c[u].rs + 1);
+        live[u] = !(c[u].flags & (RCF_BANDED | RCF_ERR | RCF_QN | RCF_SCORED)) && wlen[u] <= wcap;
+        gbase[u] = (c[u].sqidx < 0 ? 0ull : ix.sop[c[u].sqidx]) + c[u].rs;
+        q[u] = ((c[u].flags & RCF_REVERSE) ? b.codes_rc : b.codes) + b.read_off[c[u].rid];
+      }
+      if (!live[u]) { qlen[u] = 0; wlen[u] = 0; }
+    }
+    const uint32_t wmax = wlen[0] > wlen[1] ? wlen[0] : wlen[1];
+    if (wmax == 0) continue;                                   // wave-uniform
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < wmax; i += 64) {
+      const uint32_t a = i < wlen[0] ? ref_code(ix.packed, gbase[0] + i) : 5u, bb = i < wlen[1] ? ref_code(ix.packed, gbase[1] + i) : 5u;
+      win[i] = (uint16_t)(a | (bb << 8));
+    }
+    __threadfence();
+    __syncthreads();
+    const uint32_t bb = sw_strip16_core(q[0], qlen[0], q[1], qlen[1], win, wmax, bnd, wcap, rowtab, ring, sp);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if (live[u]) {
+          const int best = (int)((bb >> (16 * u)) & 0xffffu);
+          b.rcpool[tix[u]].swscor = best;
+          b.rcpool[tix[u]].flags = c[u].flags | RCF_SCORED | (best >= 65535 ? RCF_BANDED : 0u);   // ERRCODE_SWATEXCEED -> K2b
+          cells += (unsigned long long)qlen[u] * wlen[u];
+          ntasks_done++;
+        }
+      }
+    }
+  }
+  if (threadIdx.x == 0 && cells) { atomicAdd(b.work + WK_CELLS_FULL, cells); atomicAdd(b.work + WK_TASKS_FULL, ntasks_done); }
+}
+
 // tasks: the strip list S7 made (ranked candidates whose read or window exceeds the register tiling)
 __global__ void __launch_bounds__(64) k_sw_strip(Batch b, DevIndex ix, MapPar p, int2 *bnd_all, uint8_t *win_all, uint32_t wcap) {
   const unsigned long long nlist = b.work[WK_STRIP_TASKS];
@@ -810,6 +954,8 @@ int launch_sw_full(hipStream_t s, const Batch &b, const DevIndex &ix, const MapP
 
 int launch_sw_strip(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, void *bnd, uint8_t *win, uint32_t wcap, uint32_t grid) {
   if (!b.nreads || !grid) return 0;
+  if (sw16_ok(p) && (uint64_t)b.qmax * (uint64_t)p.match < 60000ull)          // 16-bit halves hold every score of these reads
+    hipLaunchKernelGGL(k_sw_strip16, dim3(grid), dim3(64), 0, s, b, ix, p, (uint2 *)bnd, (uint16_t *)win, wcap);
   hipLaunchKernelGGL(k_sw_strip, dim3(grid), dim3(64), 0, s, b, ix, p, (int2 *)bnd, win, wcap);
   SMG_LAUNCH_CHECK();
   return 0;
