@@ -44,6 +44,8 @@ def _data(tmp, nchr, chrlen, nreads, rlen, seed, with_n=False):
     (13, 6, 2, 250_000, 150, ["-f", "cigar", "-x", "-c", "0.4"]),  # exhaustive search, fractional cover threshold
     (13, 6, 3, 300_000, 150, ["-f", "sam", "-n", "3", "-O", "-r", "-1"]),   # worker threads: blocks of 96 reads per GPU batch; -r -1: no random draws
     (13, 6, 2, 250_000, 100, ["-f", "cigar", "-n", "8", "-O", "-r", "-1", "-x", "-c", "30"]),   # blocks of 256 reads, exhaustive, absolute cover threshold
+    (13, 6, 700, 1_500, 100, ["-f", "sam", "-n", "2", "-O", "-r", "-1"]),   # >= 512 reference sequences: concatenated mode (hashCollectHitsUsingCutoff, assignSequenceIndex)
+    (11, 4, 600, 2_000, 120, ["-f", "cigar", "-d", "-1"]),                   # concatenated mode, all alignments
 ])
 def test_smalt_map_prints_the_same(k, s, nchr, chrlen, rlen, opts, tmp_path):
     tmp = str(tmp_path)
