@@ -12,7 +12,9 @@
 #include "smaltgpu.h"
 #include "gpu_combine.h"
 
-enum { COMB_MAXDEV = 16, COMB_MAXREQ = 512, COMB_MAXREADS = 65536 };
+enum { COMB_MAXDEV = 16, COMB_MAXREQ = 512,
+       COMB_MAXREADS = 8192 };   /* reads per combined batch: with more worker blocks than this pending, the rest forms the next batch
+                                  * and is mapped while the first cohort's threads post-process (SMALTGPU_COMBINE_READS overrides) */
 
 typedef struct {
   const char *bases, *quals; const uint64_t *off; uint32_t n;
@@ -59,6 +61,7 @@ static void run_batch(struct CombDev *d, const smaltgpu_index *ix, CombReq **req
     if (cl < maxlen) cl = (maxlen + 31u) & ~31u;
     if (d->mp) smaltgpu_mapper_free(d->mp);
     d->mp = NULL;
+    setenv("SMALTGPU_CANDS_PER_READ", "1024", 0);        /* ranked candidates per read of the shared pool (default sizing is for large batches) */
     free(d->off);
     d->off = malloc(((size_t)cr + 1) * sizeof(uint64_t));
     if (!d->off || smaltgpu_mapper_create(&d->mp, ix, cr, cl)) rv = SMALTGPU_ENOMEM;
