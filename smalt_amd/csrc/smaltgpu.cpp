@@ -203,11 +203,11 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
   DA(b.ch, max_batch_reads); DA(b.ctl, max_batch_reads); DA(b.stat, max_batch_reads);
   {
     const char *e = getenv("SMALTGPU_CANDS_PER_READ");
-    uint64_t per = e ? strtoull(e, nullptr, 10) : 256;
+    uint64_t per = e ? strtoull(e, nullptr, 10) : 640;      // ranked candidates per read: the depth cut leaves 270 on average at 3 Gbp, at most 2048
     if (per < 8) per = 8;
     if (per > 2048) per = 2048;
     uint64_t cap = (uint64_t)max_batch_reads * per;
-    if (max_batch_reads <= 4096) cap = (uint64_t)max_batch_reads * 2048;
+    if (max_batch_reads <= 4096 && !e) cap = (uint64_t)max_batch_reads * 2048;
     if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
     b.rccap = (uint32_t)cap;
   }
