@@ -134,11 +134,31 @@ SMG_HD inline int derive_cand_c(SegCand &c, const StrandWork<IT> &w, uint32_t m0
 // One strand: hits in w.dat[0..n) (unsorted keys on entry) -> candidates appended to cand[*ncand..].
 // cover8: byte array (capacity >= candcap) that receives the cover of every candidate.
 // Returns 0 or an SMG_ERR_* code (wave-uniform).
-template <class IT>
+//
+// LONG (reads of 256 bases and more): covers do not fit a byte and the coverage mask of a region does not fit
+// registers.  Regions of one segment (nearly all of them) need no mask; the others are taken one after the other by
+// the whole wave, segment by segment as the reference does, the seeds of a segment spread over the lanes and the
+// mask (one bit per read base) in memory.  lw: covers per first segment, list of multi-segment regions, mask words.
+struct LongWork { uint32_t *ccov, *mlist, *mask; };
+
+// bits [q, q + len) of a mask in memory; returns how many were clear (addCandsFast's cover_new, segment.c:1185-1200)
+SMG_HD inline uint32_t mask_add_mem(uint32_t *mask, uint32_t q, uint32_t len) {
+  uint32_t added = 0;
+  const uint32_t e = q + len;
+  for (uint32_t w = q >> 5; (w << 5) < e; w++) {
+    const uint32_t lo = w << 5, a = q > lo ? q - lo : 0, z = e - lo;
+    const uint32_t bits = (z >= 32 ? 0xFFFFFFFFu : ((1u << z) - 1u)) & ~((1u << a) - 1u);
+    const uint32_t old = atomic_or_u32(&mask[w], bits);
+    added += (uint32_t)__builtin_popcount(bits & ~old);
+  }
+  return added;
+}
+
+template <bool LONG, class IT>
 SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, bool seqbyseq, uint32_t qlen, int k, int s,
                                uint32_t mincover, uint8_t *cover8, SegCand *cand, uint32_t candcap, uint32_t *ncand_io,
                                uint32_t *max_cover_io, uint32_t *max2nd_io, unsigned long long *ph,
-                               bool hold_tail, uint32_t *nproc_out, uint32_t *reg_base_io) {
+                               bool hold_tail, uint32_t *nproc_out, uint32_t *reg_base_io, const LongWork &lw) {
   *nproc_out = n;
   if (!n) return 0;
   unsigned long long t0 = phase_clock(), t1;
@@ -224,11 +244,14 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
   // S5: one lane per hit region (addCandsFast, segment.c:1169-1217)
   uint32_t mx = *max_cover_io, mx2 = *max2nd_io;
   int err = 0;
+  uint32_t nmulti = 0;
   SMG_PAR_CHUNKS(base, nreg) {
     const uint32_t r = base + SMG_LANE;
+    bool multi = false;
     if (r < nreg) {
       const uint32_t first = w.reg_first[r], num = (r + 1 < nreg ? (uint32_t)w.reg_first[r + 1] : nsegm) - first;
-      for (uint32_t i = 0; i < num;) {
+      if (LONG && num > 1) multi = true;
+      else for (uint32_t i = 0; i < num;) {
         const uint32_t m0 = first + i;
         uint32_t cover = w.segm_cover[m0], j = i + 1;
         if (j < num) {
@@ -245,12 +268,48 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
         }
         if (cover >= mincover) {                 // the candidate record itself is derived below, one lane per candidate
           w.reg_num[m0] = (IT)(j - i);
-          w.cflag[m0] = (uint8_t)cover;          // reads of this form have < 256 bases and cover >= mincover > 0
+          if (LONG) { w.cflag[m0] = 1; lw.ccov[m0] = cover; }
+          else w.cflag[m0] = (uint8_t)cover;     // reads of this form have < 256 bases and cover >= mincover > 0
           if (cover > mx2) { if (cover > mx) { mx2 = mx; mx = cover; } else if (cover != mx) mx2 = cover; }
         }
         i = j;
       }
     }
+    if (LONG) { const uint32_t slot = compact_slot(multi, nmulti); if (multi) lw.mlist[slot] = r; }
+  }
+  if (LONG && nmulti) {
+    SMG_SYNC();
+    const uint32_t nw = (qlen + 31) >> 5;
+    for (uint32_t t = 0; t < nmulti; t++) {      // wave-uniform from here
+      const uint32_t r = lw.mlist[t];
+      const uint32_t first = w.reg_first[r], num = (r + 1 < nreg ? (uint32_t)w.reg_first[r + 1] : nsegm) - first;
+      for (uint32_t i = 0; i < num;) {
+        const uint32_t m0 = first + i;
+        uint32_t cover = w.segm_cover[m0], j = i + 1;
+        if (j < num) {
+          SMG_SYNC();
+          SMG_PAR_CHUNKS(base, nw) { const uint32_t x = base + SMG_LANE; if (x < nw) lw.mask[x] = 0; }
+          SMG_SYNC();
+          { const uint32_t ns0 = w.segm_nseed[m0], sf = w.segm_first[m0];
+            SMG_PAR_CHUNKS(base, ns0) { const uint32_t x = base + SMG_LANE; if (x < ns0) (void)mask_add_mem(lw.mask, key_q(w.dat[w.seed_first[sf + x]]), w.seed_len[sf + x]); } }
+          for (; j < num; j++) {
+            const uint32_t m = first + j, nsm = w.segm_nseed[m], sf = w.segm_first[m];
+            uint32_t cover_new = 0;
+            SMG_SYNC();
+            SMG_PAR_CHUNKS(base, nsm) { const uint32_t x = base + SMG_LANE; if (x < nsm) cover_new += mask_add_mem(lw.mask, key_q(w.dat[w.seed_first[sf + x]]), w.seed_len[sf + x]); }
+            cover_new = wave_sum_u32(cover_new);
+            if ((cover_new << 1) < (uint32_t)w.segm_cover[m] && cover >= mincover) break;
+            cover += cover_new;
+          }
+        }
+        if (cover >= mincover) {
+          SMG_LANE0 { w.reg_num[m0] = (IT)(j - i); w.cflag[m0] = 1; lw.ccov[m0] = cover; }
+          if (cover > mx2) { if (cover > mx) { mx2 = mx; mx = cover; } else if (cover != mx) mx2 = cover; }
+        }
+        i = j;
+      }
+    }
+    SMG_SYNC();
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   // (largest, second largest distinct) over the lanes
@@ -279,8 +338,9 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
       while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)w.reg_first[mid] <= m) lo = mid; else hi = mid; }
       const int32_t seqidx = seqbyseq ? (int32_t)(key_grp(w.dat[w.seed_first[w.segm_first[m]]]) & ((1u << KEY_SEQBITS) - 1)) : -1;
       SegCand c;
-      if (derive_cand_c(c, w, m, (int)(uint32_t)w.reg_num[m], k, s, (uint32_t)w.cflag[m], mincover, reg_base + lo, is_reverse, seqidx)) err = SMG_ERR_ASSERT;
-      if (slot < candcap) { cand[slot] = c; cover8[slot] = w.cflag[m]; } else ovf = true;     // covers again as a byte array: the S6 filter reads only these
+      const uint32_t ccover = LONG ? lw.ccov[m] : (uint32_t)w.cflag[m];
+      if (derive_cand_c(c, w, m, (int)(uint32_t)w.reg_num[m], k, s, ccover, mincover, reg_base + lo, is_reverse, seqidx)) err = SMG_ERR_ASSERT;
+      if (slot < candcap) { cand[slot] = c; if (!LONG) cover8[slot] = w.cflag[m]; } else ovf = true;     // covers again as a byte array: the S6 filter reads only these
     }
   }
   *ncand_io = nc;
@@ -293,11 +353,12 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
 
 // hashCalcHitInfoCoverDeficit (hashhit.c:1096-1169) by the wave.  With a seed-rank cut the per-frame
 // coverage is a union of k-base intervals (order-free): lanes OR the intervals of the seeds below the
-// rank into one 256-bit mask per sampling frame.  wk: >= 9 * s words of scratch.
-SMG_HD inline uint32_t wave_cover_deficit(const HitInfoHdr &hdr, const SeedRec *seeds, const uint8_t *qmask, uint32_t qlen, int k, int s, uint32_t *wk) {
-  uint32_t *mask = wk, *val = wk + 8 * (uint32_t)s;        // mask[s][8]; val[s]: frame has seeds / per-frame result
+// rank into one mask of nw words per sampling frame.  wk: >= (nw + 1) * s words of scratch.
+SMG_HD inline uint32_t wave_cover_deficit(const HitInfoHdr &hdr, const SeedRec *seeds, const uint8_t *qmask, uint32_t qlen, int k, int s, uint32_t *wk,
+                                          uint32_t nw = 8) {
+  uint32_t *mask = wk, *val = wk + nw * (uint32_t)s;       // mask[s][nw] (nw * 32 >= qlen); val[s]: frame has seeds / per-frame result
   SMG_SYNC();
-  SMG_PAR_CHUNKS(base, 9u * (uint32_t)s) { const uint32_t i = base + SMG_LANE; if (i < 9u * (uint32_t)s) wk[i] = 0; }
+  SMG_PAR_CHUNKS(base, (nw + 1) * (uint32_t)s) { const uint32_t i = base + SMG_LANE; if (i < (nw + 1) * (uint32_t)s) wk[i] = 0; }
   SMG_SYNC();
   uint32_t deficit = 0;
   if (hdr.status & HI_RANK) {
@@ -305,12 +366,12 @@ SMG_HD inline uint32_t wave_cover_deficit(const HitInfoHdr &hdr, const SeedRec *
       const uint32_t i = base + SMG_LANE;
       if (i < hdr.n_seeds) {
         const uint32_t q0 = seeds[i].qoffs, f = q0 % (uint32_t)s;
-        atomic_or_u32(&val[f], 1u);
+        (void)atomic_or_u32(&val[f], 1u);
         if (i < hdr.seed_rank) {
           for (uint32_t w = q0 >> 5; w <= (q0 + (uint32_t)k - 1) >> 5; w++) {
             const uint32_t lo = w << 5, a = q0 > lo ? q0 - lo : 0, e = q0 + (uint32_t)k - lo;
             const uint32_t bits = (e >= 32 ? 0xFFFFFFFFu : ((1u << e) - 1u)) & ~((1u << a) - 1u);
-            atomic_or_u32(&mask[f * 8 + (w & 7)], bits);
+            if (w < nw) (void)atomic_or_u32(&mask[f * nw + w], bits);
           }
         }
       }
@@ -321,7 +382,7 @@ SMG_HD inline uint32_t wave_cover_deficit(const HitInfoHdr &hdr, const SeedRec *
       const uint32_t f = base + SMG_LANE;
       if (f < (uint32_t)s && val[f]) {
         uint32_t cover = 0;
-        for (int w = 0; w < 8; w++) cover += (uint32_t)__builtin_popcount(mask[f * 8 + (uint32_t)w]);
+        for (uint32_t w = 0; w < nw; w++) cover += (uint32_t)__builtin_popcount(mask[f * nw + w]);
         if (cover < d) d = cover;
         if (cover > maxcover) maxcover = cover;
       }
@@ -367,11 +428,13 @@ struct CandsV2Scratch {
   uint32_t *sort_keys, *sort_idx;
   FillDecision *dec; uint32_t ngrp;
   uint64_t *dbg_words; uint32_t *dbg_first, *dbg_cnt;   // debug: packed hit words grouped as the dump expects (or null)
+  LongWork lw;                           // reads of 256 bases and more
 };
 
 SMG_HD inline size_t cands_v2_hbm_bytes(uint32_t qmax, int s, uint32_t hcap_strand, uint32_t ngrp, uint32_t candcap, bool debug) {
-  (void)qmax; (void)s;
+  (void)s;
   size_t n = strand_work_bytes<uint32_t>(hcap_strand) + (size_t)candcap * (sizeof(SegCand) + 8 + 1) + (size_t)ngrp * 2 * sizeof(FillDecision) + 512;
+  if (qmax > 255) n += (size_t)hcap_strand * 8 + (size_t)(qmax / 32 + 2) * 4 + 64;
   if (debug) n += (size_t)hcap_strand * 2 * 8 + (size_t)ngrp * 2 * 8;
   return (n + 255) & ~(size_t)255;
 }
@@ -393,6 +456,14 @@ SMG_HD inline CandsV2Scratch cands_v2_carve(uint8_t *lds, size_t lds_bytes, uint
     x.dbg_first = (uint32_t *)b; b += (size_t)ngrp * 2 * 4;
     x.dbg_cnt = (uint32_t *)b;
   } else { x.dbg_words = nullptr; x.dbg_first = x.dbg_cnt = nullptr; }
+  x.lw.ccov = x.lw.mlist = x.lw.mask = nullptr;
+  if (qmax > 255) {
+    b = (uint8_t *)(((uintptr_t)b + 15) & ~(uintptr_t)15);
+    if (debug) b += (size_t)ngrp * 2 * 4;
+    x.lw.ccov = (uint32_t *)b; b += (size_t)hcap_strand * 4;
+    x.lw.mlist = (uint32_t *)b; b += (size_t)hcap_strand * 4;
+    x.lw.mask = (uint32_t *)b;
+  }
   return x;
 }
 
@@ -417,9 +488,11 @@ SMG_HD inline void dbg_hits(const CandsV2Scratch &x, const uint64_t *dat, uint32
 
 // true when the parallel form applies to this read
 SMG_HD inline bool cands_v2_applicable(const MapPar &p, int k, int s, uint32_t qlen) {
-  return qlen <= 255 && read_min_cover(p, qlen) < (uint32_t)(k + s);     // calcMinKtup (rmap.c:240-247) gives min_ktup == 1; covers fit a byte
+  return qlen < (1u << KEY_QBITS) && read_min_cover(p, qlen) < (uint32_t)(k + s);     // calcMinKtup (rmap.c:240-247) gives min_ktup == 1
 }
 
+// LONG: reads of 256 bases and more (wide covers, coverage masks in memory, 64-bit ranking words)
+template <bool LONG>
 SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t r, CandsV2Scratch &x, unsigned long long *ph) {
   unsigned long long t0 = phase_clock(), t1;
 #define SMG_PH(i) { t1 = phase_clock(); ph[i] += t1 - t0; t0 = t1; }
@@ -515,12 +588,14 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     const bool simple = all_in || !seqbyseq;
     const size_t wl_bytes = (strand_work_bytes<uint16_t>(x.lds_hits) + 15) & ~(size_t)15;
     const bool lds_ok = x.lds && wl_bytes + (size_t)5 * x.tab * 4 <= x.lds_bytes && n_use < x.tab;
+    const uint32_t tabn = lds_ok ? x.tab : ((n_use + 8) & ~3u);      // tables in the sort arrays (2 * candcap words) otherwise
+    if (!lds_ok && (uint64_t)5 * tabn > (uint64_t)2 * x.candcap) { err = SMG_ERR_CAP; break; }
     uint32_t W = x.lds_hits;
     if (x.window && x.window < W) W = x.window;
     StrandWork<uint16_t> wl = strand_work_carve<uint16_t>(x.lds, x.lds_hits);
     StrandWork<uint32_t> wg = strand_work_carve<uint32_t>(x.hbm, x.hcap_strand);
     uint32_t *gt = lds_ok ? (uint32_t *)(x.lds + wl_bytes) : x.sort_keys;        // per-list tables (sort arrays are dead here)
-    uint32_t *g_pfx = gt, *g_poff = gt + x.tab, *g_qo = gt + 2 * x.tab, *g_len = gt + 3 * x.tab;
+    uint32_t *g_pfx = gt, *g_poff = gt + tabn, *g_qo = gt + 2 * tabn, *g_len = gt + 3 * tabn;
     uint32_t nlist = 0, total = 0;
     if (simple) {
       // Seeds that contribute become "lists" (position lists of the index, ascending); hit h of the strand
@@ -561,7 +636,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     uint64_t *dbg_w = x.dbg_words ? x.dbg_words + (size_t)st * x.hcap_strand : nullptr;
 
     if (mode == 1) {
-      uint32_t *g_cur = gt + 4 * x.tab;                // per-list cursor
+      uint32_t *g_cur = gt + 4 * tabn;                 // per-list cursor
       SMG_PAR_CHUNKS(base, nlist) { const uint32_t l = base + SMG_LANE; if (l < nlist) g_cur[l] = 0; }
       SMG_SYNC();
       uint32_t carry = 0, remaining = total, reg_base = 0, gproc = 0, last_grp = ~0u;
@@ -654,8 +729,8 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
         ph[13] += phase_clock() - tb0;
         SMG_PH(1)
         uint32_t nproc = n;
-        rv = strand_cands(wl, n, st != 0, seqbyseq, qlen, k, s, min_cover, x.cover8, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph,
-                          remaining > 0, &nproc, &reg_base);
+        rv = strand_cands<LONG>(wl, n, st != 0, seqbyseq, qlen, k, s, min_cover, x.cover8, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph,
+                          remaining > 0, &nproc, &reg_base, x.lw);
         t0 = phase_clock();
         if (rv) break;
         if (dbg_w) dbg_hits(x, (const uint64_t *)wl.dat, nproc, gproc, st, ngrp, seqbyseq, dbg_w, last_grp);
@@ -743,8 +818,8 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
       SMG_PH(1)
       int rv;
       uint32_t nproc = nkeys, reg_base = 0, last_grp = ~0u;
-      if (in_lds) rv = strand_cands(wl, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, x.cover8, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph, false, &nproc, &reg_base);
-      else rv = strand_cands(wg, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, x.cover8, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph, false, &nproc, &reg_base);
+      if (in_lds) rv = strand_cands<LONG>(wl, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, x.cover8, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph, false, &nproc, &reg_base, x.lw);
+      else rv = strand_cands<LONG>(wg, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, x.cover8, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph, false, &nproc, &reg_base, x.lw);
       t0 = phase_clock();
       if (!in_lds) { ph[14]++; ph[15] += t0 - ts; }
       if (rv) { err = rv; break; }
@@ -770,11 +845,22 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     }
   }
   uint32_t *hist = wk + WSORT_WORDS;
+  uint64_t *kv64 = nullptr;
+  uint32_t nbins = WSORT_NBINS;
+  const uint32_t nwq = LONG ? (qlen + 31) >> 5 : 8u;
+  if (LONG) {                               // the HBM strand work is dead too: cover-deficit masks, then key histogram | ranking words
+    nbins = max_cover + 2;
+    hist = (uint32_t *)x.hbm;
+    size_t hb = (size_t)(nwq + 1) * (uint32_t)s;
+    if (hb < nbins) hb = nbins;
+    kv64 = (uint64_t *)(x.hbm + ((hb * 4 + 15) & ~(size_t)15));
+    if ((size_t)((uint8_t *)kv64 - x.hbm) + (size_t)ncand * 8 > strand_work_bytes<uint32_t>(x.hcap_strand)) err = err ? err : SMG_ERR_CAP;
+  }
   SMG_SYNC();
   uint32_t cdf[2] = {0, 0};
   for (uint32_t st = 0; st < 2; st++) {
     const uint32_t rs = 2 * r + st;
-    cdf[st] = wave_cover_deficit(b.hi[rs], b.seeds + (size_t)rs * b.qmax, b.qmask + (size_t)rs * b.qmax, qlen, k, s, wk);
+    cdf[st] = wave_cover_deficit(b.hi[rs], b.seeds + (size_t)rs * b.qmax, b.qmask + (size_t)rs * b.qmax, qlen, k, s, LONG ? hist : wk, nwq);
   }
   SMG_LANE0 { ch.cover_deficit[0] = cdf[0]; ch.cover_deficit[1] = cdf[1]; }
   uint32_t target_depth = (uint32_t)p.target_depth, max_depth = (uint32_t)p.max_depth;
@@ -785,23 +871,24 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   if (min_cov_thr > max2nd) { cdfx = min_cov_thr - max2nd; min_cov_thr = max2nd; }
   const uint32_t adj = (cdf[0] > cdfx) ? cdf[0] - cdfx : 0;       // deficit of strand [0] for both strands (:1676)
   uint32_t nmin = 0;
-  if (!err && (ncand > (1u << WSORT_IDXBITS) || max_cover >= (uint32_t)WSORT_NBINS)) err = SMG_ERR_CAP;
+  if (!LONG && !err && (ncand > (1u << WSORT_IDXBITS) || max_cover >= (uint32_t)WSORT_NBINS)) err = SMG_ERR_CAP;
   if (!err) {
     if (ncand > lds_sort_cap) kv = x.sort_keys;
-    SMG_PAR_CHUNKS(base, (uint32_t)WSORT_NBINS) { const uint32_t i = base + SMG_LANE; if (i < (uint32_t)WSORT_NBINS) hist[i] = 0; }
+    SMG_PAR_CHUNKS(base, nbins) { const uint32_t i = base + SMG_LANE; if (i < nbins) hist[i] = 0; }
     SMG_SYNC();
     // candidates that pass the cover threshold, in candidate order (:1700-1730); four independent loads per lane
     for (uint32_t base = 0; base < ncand; base += 4 * SMG_NLANES) {
       uint32_t cov[4];
-      for (int u = 0; u < 4; u++) { const uint32_t i = base + (uint32_t)u * SMG_NLANES + SMG_LANE; cov[u] = i < ncand ? x.cover8[i] : 0; }
+      for (int u = 0; u < 4; u++) { const uint32_t i = base + (uint32_t)u * SMG_NLANES + SMG_LANE; cov[u] = i < ncand ? (LONG ? x.cand[i].cover : (uint32_t)x.cover8[i]) : 0; }
       for (int u = 0; u < 4; u++) {
         const uint32_t i = base + (uint32_t)u * SMG_NLANES + SMG_LANE;
         const bool keep = i < ncand && !(cov[u] + adj < min_cov_thr);
         const uint32_t slot = compact_slot(keep, nmin);
         if (keep) {
           const uint32_t key = max_cover - cov[u];
-          kv[slot] = (key << WSORT_IDXBITS) | i;
-          atomic_add_u32(&hist[key < (uint32_t)WSORT_NBINS ? key : (uint32_t)WSORT_NBINS - 1], 1u);
+          if (LONG) kv64[slot] = ((uint64_t)key << 32) | i;
+          else kv[slot] = (key << WSORT_IDXBITS) | i;
+          atomic_add_u32(&hist[key < nbins ? key : nbins - 1], 1u);
         }
       }
     }
@@ -812,9 +899,24 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   // the key histogram, and only ranks below it have to be brought into the reference's order.
   uint32_t nrank = 0;
   if (!err) {
-    SMG_LANE0 { uint32_t c = 0; for (int v = 0; v < WSORT_NBINS; v++) { c += hist[v]; hist[v] = c; } }   // hist[v] = #keys <= v
+    if (LONG) {                                                                   // hist[v] = #keys <= v
+      uint32_t run = 0;
+      SMG_PAR_CHUNKS(base, nbins) {
+        const uint32_t i = base + SMG_LANE;
+        uint32_t incl = i < nbins ? hist[i] : 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if ((int)SMG_LANE >= o) incl += v; }
+#endif
+        if (i < nbins) hist[i] = run + incl;
+#if defined(__HIP_DEVICE_COMPILE__)
+        run += (uint32_t)__shfl((int)incl, 63);
+#else
+        run += incl;
+#endif
+      }
+    } else SMG_LANE0 { uint32_t c = 0; for (int v = 0; v < WSORT_NBINS; v++) { c += hist[v]; hist[v] = c; } }
     SMG_SYNC();
-#define SMG_CLT(v) ((v) == 0 ? 0u : hist[((v) > (uint32_t)WSORT_NBINS ? (uint32_t)WSORT_NBINS : (v)) - 1])
+#define SMG_CLT(v) ((v) == 0 ? 0u : hist[((v) > nbins ? nbins : (v)) - 1])
     uint32_t j = nmin;
     if (j > target_depth) {
       const uint32_t maxj = (j < max_depth) ? j : max_depth;
@@ -825,7 +927,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
         if (c2 > j) j = c2;
       } else {
         const uint32_t rank = j / 2;
-        uint32_t lo = 0, hi = WSORT_NBINS - 1;                         // key of rank j/2
+        uint32_t lo = 0, hi = nbins - 1;                               // key of rank j/2
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (hist[mid] > rank) hi = mid; else lo = mid + 1; }
         uint32_t cov = lo;
         if (cov < (uint32_t)s) cov = (uint32_t)s;
@@ -837,7 +939,8 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
 #undef SMG_CLT
     nrank = j;
     SMG_SYNC();
-    wave_sort_kv(kv, (int)nmin, (int)nrank, wk);    // sort.c:233 tie order
+    if (LONG) wave_sort_kv<32, WSORT_LISTCAP, WSORT_LSTK, uint64_t>(kv64, (int)nmin, (int)nrank, wk);
+    else wave_sort_kv(kv, (int)nmin, (int)nrank, wk);    // sort.c:233 tie order
   }
   SMG_LANE0 {
     ch.ncand = ncand; ch.n_sort = nrank; ch.n_mincover = nmin; ch.max_cover = max_cover; ch.max2nd_cover = max2nd;
@@ -849,9 +952,13 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   SMG_SYNC();
   {                                         // ranked part to the slot (S7 below, diagnostics)
     const uint32_t ns = ch.n_sort;
-    SMG_PAR_CHUNKS(base, ns) { const uint32_t i = base + SMG_LANE; if (i < ns) { const uint32_t v = kv[i]; x.sort_idx[i] = v & ((1u << WSORT_IDXBITS) - 1u); } }
-    SMG_SYNC();
-    SMG_PAR_CHUNKS(base, ns) { const uint32_t i = base + SMG_LANE; if (i < ns) x.sort_keys[i] = kv[i] >> WSORT_IDXBITS; }
+    if (LONG) {
+      SMG_PAR_CHUNKS(base, ns) { const uint32_t i = base + SMG_LANE; if (i < ns) { const uint64_t v = kv64[i]; x.sort_idx[i] = (uint32_t)v; x.sort_keys[i] = (uint32_t)(v >> 32); } }
+    } else {
+      SMG_PAR_CHUNKS(base, ns) { const uint32_t i = base + SMG_LANE; if (i < ns) { const uint32_t v = kv[i]; x.sort_idx[i] = v & ((1u << WSORT_IDXBITS) - 1u); } }
+      SMG_SYNC();
+      SMG_PAR_CHUNKS(base, ns) { const uint32_t i = base + SMG_LANE; if (i < ns) x.sort_keys[i] = kv[i] >> WSORT_IDXBITS; }
+    }
   }
   SMG_SYNC();
   SMG_PH(7)

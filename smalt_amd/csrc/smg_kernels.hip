@@ -71,7 +71,8 @@ __global__ void __launch_bounds__(64) k_cands(Batch b, DevIndex ix, MapPar p, ui
     if (cands_v2_applicable(p, ix.k, ix.s, read_len(b, r))) {
       CandsV2Scratch x = cands_v2_carve(lds + LDS_GUARD, lds_bytes, base, b.qmax, ix.s, g.hcap_strand, g.ngrp, g.candcap, g.debug != 0);
       x.window = g.window; x.lds_hits = g.lds_hits; x.tab = g.tab;
-      nhit += stage_cands_v2(b, ix, p, r, x, ph);
+      if (read_len(b, r) > 255) nhit += stage_cands_v2<true>(b, ix, p, r, x, ph);
+      else nhit += stage_cands_v2<false>(b, ix, p, r, x, ph);
     } else {
       CandScratch x = cand_scratch_carve(base, b.qmax, ix.s, g.hcap, g.ngrp, g.segcap, g.candcap);
       nhit += stage_cands(b, ix, p, r, x);

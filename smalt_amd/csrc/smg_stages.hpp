@@ -73,11 +73,11 @@ SMG_HD inline uint32_t atomic_add_u32(uint32_t *p, uint32_t v) {
   uint32_t o = *p; *p += v; return o;
 #endif
 }
-SMG_HD inline void atomic_or_u32(uint32_t *p, uint32_t v) {
+SMG_HD inline uint32_t atomic_or_u32(uint32_t *p, uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  atomicOr(p, v);
+  return atomicOr(p, v);
 #else
-  *p |= v;
+  uint32_t o = *p; *p |= v; return o;
 #endif
 }
 SMG_HD inline unsigned long long atomic_add_u64(unsigned long long *p, unsigned long long v) {

@@ -11,7 +11,8 @@
 // finished one per lane with the sequential routine.  Ranges that start at or beyond `nneed`
 // (everything behind the depth cut) are left unsorted: no later stage reads them.
 //
-// Elements are packed (key << 22) | index: keys are cover differences (< 1024), indices < 2^22.
+// Elements are packed (key << IB) | index: 32-bit words with IB = 22 for reads up to 255 bases (keys are cover
+// differences < 1024), 64-bit words with IB = 32 for longer reads.
 #pragma once
 #include "smg_exec.h"
 
@@ -23,10 +24,10 @@ enum : int { WSORT_IDXBITS = 22, WSORT_SMALL = 32, WSORT_LISTCAP = 256, WSORT_LS
 #define SMG_KVKEY(v) ((v) >> IB)       // IB: index bits of the packed element (template parameter of the routines below)
 
 // the reference's routine on the sub-range [lo, hi] of a packed array; stk: >= 2*log2(hi-lo+1)+2 ints
-template <int IB = WSORT_IDXBITS>
-SMG_HD inline void qsort_kv_range(uint32_t *a, int lo, int hi, int *stk) {
+template <int IB = WSORT_IDXBITS, class T = uint32_t>
+SMG_HD inline void qsort_kv_range(T *a, int lo, int hi, int *stk) {
   int i, j, mid, sp = 0;
-  uint32_t pv, t;
+  T pv, t;
 #define SMG_SWP(x, y) { t = a[x]; a[x] = a[y]; a[y] = t; }
   for (;;) {
     if (hi - lo < 7) {                                   // sort.c:240-251 insertion sort of short ranges
@@ -45,7 +46,7 @@ SMG_HD inline void qsort_kv_range(uint32_t *a, int lo, int hi, int *stk) {
       if (SMG_KVKEY(a[lo]) > SMG_KVKEY(a[lo + 1])) SMG_SWP(lo, lo + 1)
       i = lo + 1; j = hi;
       pv = a[lo + 1];
-      const uint32_t pk = SMG_KVKEY(pv);
+      const T pk = SMG_KVKEY(pv);
       for (;;) {
         do i++; while (SMG_KVKEY(a[i]) < pk);
         do j--; while (SMG_KVKEY(a[j]) > pk);
@@ -62,12 +63,12 @@ SMG_HD inline void qsort_kv_range(uint32_t *a, int lo, int hi, int *stk) {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // One partition step of [lo, hi] (hi - lo >= 7) by the wave; returns the reference's final i and j.
-template <int IB = WSORT_IDXBITS>
-__device__ inline void wave_partition_kv(uint32_t *a, int lo, int hi, uint32_t *pairs, int &out_i, int &out_j) {
+template <int IB = WSORT_IDXBITS, class T = uint32_t>
+__device__ inline void wave_partition_kv(T *a, int lo, int hi, uint32_t *pairs, int &out_i, int &out_j) {
   const int lane = (int)threadIdx.x;
   const uint64_t lt = (1ull << lane) - 1ull;
   if (lane == 0) {                                        // median of three to lo+1 (sort.c:252-262)
-    uint32_t t;
+    T t;
     const int mid = (lo + hi) >> 1;
 #define SMG_SWP(x, y) { t = a[x]; a[x] = a[y]; a[y] = t; }
     SMG_SWP(mid, lo + 1)
@@ -77,7 +78,7 @@ __device__ inline void wave_partition_kv(uint32_t *a, int lo, int hi, uint32_t *
 #undef SMG_SWP
   }
   __syncthreads();
-  const uint32_t pv = a[lo + 1], pk = SMG_KVKEY(pv);
+  const T pv = a[lo + 1], pk = SMG_KVKEY(pv);
   int L = lo + 2, R = hi - 1;                             // next unread position of either pointer
   uint64_t mA = 0, mB = 0;                                // unconsumed stops of i (bit l = baseA + l) and j (baseB - l)
   int baseA = 0, baseB = 0, prevA = -1, prevB = -1, fi = 0, fj = 0;
@@ -101,7 +102,7 @@ __device__ inline void wave_partition_kv(uint32_t *a, int lo, int hi, uint32_t *
     const bool inpair = lane < m, valid = inpair && posA <= posB;
     const uint64_t minv = __ballot(inpair && !valid);
     uint64_t mstrict = __ballot(valid && posA < posB);    // real swaps (a pair with posA == posB swaps nothing)
-    if (valid && posA != posB) { const uint32_t u = a[posA], w = a[posB]; a[posA] = w; a[posB] = u; }
+    if (valid && posA != posB) { const T u = a[posA], w = a[posB]; a[posA] = w; a[posB] = u; }
     __syncthreads();
     if (minv) mstrict &= (1ull << __builtin_ctzll(minv)) - 1ull;
     if (mstrict) { const int ls = 63 - __builtin_clzll(mstrict); prevA = __shfl(posA, ls); prevB = __shfl(posB, ls); }
@@ -126,8 +127,8 @@ __device__ inline void wave_partition_kv(uint32_t *a, int lo, int hi, uint32_t *
 
 // Sort a[0..n) like the reference does, at least up to position nneed.  wk: WSORT_WORDS words (LDS).
 // wk: 256 + 2 * LISTCAP + 64 * LSTK words (WSORT_WORDS with the defaults); LSTK >= 2 * log2(WSORT_SMALL) + 2
-template <int IB = WSORT_IDXBITS, int LISTCAP = WSORT_LISTCAP, int LSTK = WSORT_LSTK>
-SMG_HD inline void wave_sort_kv(uint32_t *a, int n, int nneed, uint32_t *wk) {
+template <int IB = WSORT_IDXBITS, int LISTCAP = WSORT_LISTCAP, int LSTK = WSORT_LSTK, class T = uint32_t>
+SMG_HD inline void wave_sort_kv(T *a, int n, int nneed, uint32_t *wk) {
   if (n < 2) return;
 #if defined(__HIP_DEVICE_COMPILE__)
   const int lane = (int)threadIdx.x;
@@ -149,14 +150,14 @@ SMG_HD inline void wave_sort_kv(uint32_t *a, int n, int nneed, uint32_t *wk) {
       slist[2 * ns] = lo; slist[2 * ns + 1] = hi; ns++;   // every lane writes the same words
       if (ns == LISTCAP) {
         __syncthreads();
-        for (int t = lane; t < ns; t += 64) qsort_kv_range<IB>(a, slist[2 * t], slist[2 * t + 1], lstk);
+        for (int t = lane; t < ns; t += 64) qsort_kv_range<IB, T>(a, slist[2 * t], slist[2 * t + 1], lstk);
         __syncthreads();
         ns = 0;
       }
       continue;
     }
     int i, j;
-    wave_partition_kv<IB>(a, lo, hi, pairs, i, j);
+    wave_partition_kv<IB, T>(a, lo, hi, pairs, i, j);
     // [lo, j-1] and [i, hi]: keep the smaller one, park the larger (bounded stack)
     int plo, phi;
     if (hi - i + 1 >= j - lo) { plo = i; phi = hi; hi = j - 1; }
@@ -165,12 +166,12 @@ SMG_HD inline void wave_sort_kv(uint32_t *a, int n, int nneed, uint32_t *wk) {
     have = true;
   }
   __syncthreads();
-  for (int t = lane; t < ns; t += 64) qsort_kv_range<IB>(a, slist[2 * t], slist[2 * t + 1], lstk);
+  for (int t = lane; t < ns; t += 64) qsort_kv_range<IB, T>(a, slist[2 * t], slist[2 * t + 1], lstk);
   __syncthreads();
 #else
   (void)nneed; (void)wk;
   int stk[128];
-  qsort_kv_range<IB>(a, 0, n - 1, stk);
+  qsort_kv_range<IB, T>(a, 0, n - 1, stk);
 #endif
 }
 

@@ -130,7 +130,8 @@ int main(int argc, char **argv) {
       CandsV2Scratch c2 = cands_v2_carve(ldsmem.data(), ldsmem.size(), cscr.data() + cbytes * r, qmax, ix.s, hcap_strand, ngrp, candcap, true);
       c2.window = window;
       unsigned long long ph[16] = {0};
-      stage_cands_v2(b, ix, p, r, c2, ph);
+      if (len > 255) stage_cands_v2<true>(b, ix, p, r, c2, ph);
+      else stage_cands_v2<false>(b, ix, p, r, c2, ph);
       nwin_strands += ph[11]; nhbm_strands += ph[14];
     } else {
       CandScratch cx = cand_scratch_carve(cscr.data() + cbytes * r, qmax, ix.s, hcap, ngrp, segcap, candcap);

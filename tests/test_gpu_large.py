@@ -155,21 +155,27 @@ def test_candidate_pool_overflow_is_reported_per_read(oracle_built, tmp_path, mo
         gix.close()
 
 
-def test_long_reads_match_oracle(oracle_built, tmp_path):
-    """BASELINE configs[4] shape in small: 1.5 kbp reads with 3/5/4 % substitutions/insertions/deletions, k=20 s=13
-    (HASH32MIX with nbits_perf): sequential candidate stage, strip K2a kernel, wide-band K3."""
+@pytest.mark.parametrize("k,s,nreads", [(20, 13, 14), (13, 6, 40)], ids=["k20s13", "k13s6"])
+def test_long_reads_match_oracle(k, s, nreads, oracle_built, tmp_path):
+    """BASELINE configs[4] shape in small: reads of 0.3-3 kbp with 3/5/4 % substitutions/insertions/deletions (every
+    fifth read an exact copy: narrow bands, K2b), k=20 s=13 (HASH32MIX with nbits_perf) and k=13 s=6 (many more hits):
+    wave-parallel candidate stage for long reads, strip K2a kernel, wide-band K3."""
     from smalt_amd import api, synth
     ch = synth.make_reference(3, 700_000, seed=51, repeat_frac=0.1, n_fam=3, cons_len=400, divergence=0.05)
     rng = np.random.default_rng(52)
     seqs = [synth.codes_to_ascii(c) for c in ch]
     rb = []
-    for i in range(14):
-        c = int(rng.integers(0, 3)); p = int(rng.integers(0, 700_000 - 1700))
-        src = bytearray(seqs[c][p:p + 1500])
+    for i in range(nreads):
+        c = int(rng.integers(0, 3))
+        ln = 1500 if nreads == 14 else int(rng.integers(300, 3000))
+        p = int(rng.integers(0, 700_000 - ln - 200))
+        src = bytearray(seqs[c][p:p + ln])
         out = bytearray()
         for ch_ in src:
             u = rng.random()
-            if u < 0.03:
+            if nreads != 14 and i % 5 == 0:
+                out.append(ch_)
+            elif u < 0.03:
                 out.append(b"ACGT"[int(rng.integers(0, 4))])
             elif u < 0.08:
                 out.append(ch_); out.append(b"ACGT"[int(rng.integers(0, 4))])
@@ -181,7 +187,7 @@ def test_long_reads_match_oracle(oracle_built, tmp_path):
         if i % 2:
             r = r[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
         rb.append(r)
-    oix0 = ol.build_index(seqs, ["c%d" % i for i in range(3)], 20, 13)
+    oix0 = ol.build_index(seqs, ["c%d" % i for i in range(3)], k, s)
     pre = str(tmp_path / "long")
     assert ol.lib().or_index_write(oix0, pre.encode()) == 0
     oix = ol.lib().or_index_read(pre.encode())

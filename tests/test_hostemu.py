@@ -30,3 +30,56 @@ def test_stage_logic_matches_reference_dump(entry, window, emu_bin, oracle_built
     for i, (x, y) in enumerate(zip(a, b)):
         assert x == y, "line %d" % (i + 1)
     assert len(a) == len(b)
+
+
+def _mutate(rng, src, sub, ins, dele):
+    out = bytearray()
+    for ch in src:
+        u = rng.random()
+        if u < sub:
+            out.append(b"ACGT"[int(rng.integers(0, 4))])
+        elif u < sub + ins:
+            out.append(ch)
+            out.append(b"ACGT"[int(rng.integers(0, 4))])
+        elif u < sub + ins + dele:
+            continue
+        else:
+            out.append(ch)
+    return bytes(out)
+
+
+@pytest.mark.parametrize("k,s,opts", [(13, 6, ""), (20, 13, ""), (13, 6, "-x")], ids=["k13s6", "k20s13", "k13s6-x"])
+def test_long_reads_wave_form_equals_sequential_form(k, s, opts, emu_bin, oracle_built, tmp_path):
+    """Reads of 256 bases and more: the wave-parallel candidate stage (wide covers, coverage masks in memory, 64-bit
+    ranking words) against the sequential restatement, which the committed reference dumps pin.  The reads carry
+    substitutions and indels (hit regions of many segments), some are exact copies (narrow bands: K2b)."""
+    import numpy as np
+    import oracle_lib as ol
+    from smalt_amd import synth
+    ch = synth.make_reference(3, 400_000, seed=71, repeat_frac=0.2, n_fam=4, cons_len=500, divergence=0.04)
+    seqs = [synth.codes_to_ascii(c) for c in ch]
+    rng = np.random.default_rng(72)
+    fq = tmp_path / "long.fq"
+    with open(fq, "wb") as f:
+        for i in range(24):
+            c = int(rng.integers(0, 3))
+            ln = int(rng.integers(256, 3000))
+            p = int(rng.integers(0, 400_000 - ln - 1))
+            src = seqs[c][p:p + ln]
+            r = src if i % 6 == 0 else _mutate(rng, src, 0.02, 0.03, 0.03)
+            if i % 2:
+                r = r[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
+            f.write(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)))
+    oix = ol.build_index(seqs, ["c%d" % i for i in range(3)], k, s)
+    pre = str(tmp_path / "longix")
+    assert ol.lib().or_index_write(oix, pre.encode()) == 0
+    ol.lib().or_index_free(oix)
+    outs = []
+    for force in ("v1", ""):
+        env = dict(os.environ, EMU_CANDS=force)
+        outs.append(subprocess.run([emu_bin] + opts.split() + [pre, str(fq)], check=True, capture_output=True, text=True, env=env).stdout)
+    a, b = outs[0].split("\n"), outs[1].split("\n")
+    assert len(a) > 100
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x == y, "line %d" % (i + 1)
+    assert len(a) == len(b)
