@@ -985,6 +985,9 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
           const unsigned long long li = atomic_add_u64(b.work + WK_LONG_TASKS, 1ull);
           if (b.long_list && li < b.long_cap) b.long_list[li] = rc_off + i;
         }
+      } else if ((c.flags & RCF_BANDED) && !(c.flags & RCF_ERR) && qlen > 255) {   // K2b of a long read: wave kernel
+        const unsigned long long li = atomic_add_u64(b.work + WK_STRIP_TASKS, 1ull);
+        if (b.strip_list && li < b.strip_cap) b.strip_list[li] = rc_off + i;
       }
       c.rid = r; c.pad = 0;
       b.rcpool[rc_off + i] = c;

@@ -753,6 +753,137 @@ __global__ void __launch_bounds__(64) k_sw_strip_raw(const uint8_t *qcodes, cons
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// K2b (alignSmiWatBandFast, alignment.c:1029-1233) for long reads: one wave per task, the strip scheme of
+// sw_strip_core with the restricted cell update and the band as an activity mask.  Row r of the band visits the
+// columns [js(r), jl(r)): js(r) = q_left for ever when the band starts clipped at the read's left end (the
+// reference never advances it then), l_edge + r otherwise; jl(r) = min(r_edge + 1 + r, q_len).  Cells outside keep
+// H and E (the reference's row buffers persist) and hand F = 0 to the right; every value a visited cell reads
+// from an unvisited neighbour is then what the reference reads (0 for a cell never visited, else the stale
+// buffer value, which only cells on the same diagonal -- visited or never visited together -- can reach).
+// A strip sweeps only the rows in which it has visited cells.
+// ---------------------------------------------------------------------------------------
+__device__ inline int band_fast_wave(const Band &bp, const uint8_t *q, const uint8_t *win /* row i of the window */, int2 *bnd, uint32_t wcap,
+                                     const uint2 *tab, int2 *ring /* LDS [256] */, int bias, int gi, int ge) {
+  constexpr int C = SW_STRIP_C;
+  const int g = (int)threadIdx.x;
+  const bool clipped = bp.q_left > bp.l_edge;
+  const int j0 = clipped ? bp.q_left : bp.l_edge;
+  const int nrows = bp.s_len - bp.s_left;
+  if (nrows <= 0) return 0;
+  const int jmax = min(bp.r_edge + nrows, bp.q_len);          // jl(nrows - 1)
+  if (jmax <= j0 || (uint32_t)nrows > wcap) return 0;
+  const int nstrip = (jmax - j0 + 64 * C - 1) / (64 * C);
+  int2 *ring_in = ring, *ring_out = ring + 128;
+  int best = 0, plo = 0, phi = 0;                             // [plo, phi): rows the previous strip swept
+  for (int sidx = 0; sidx < nstrip; sidx++) {
+    const int c_lo = j0 + sidx * 64 * C, c_hi = c_lo + 64 * C;
+    const int r_lo = max(c_lo - bp.r_edge, 0);
+    const int r_hi = clipped ? nrows : min(nrows, c_hi - bp.l_edge);
+    const int nr = r_hi - r_lo;
+    const int2 *bprev = bnd + (size_t)((sidx + 1) & 1) * wcap;
+    int2 *bnext = bnd + (size_t)(sidx & 1) * wcap;
+    const int jb = c_lo + g * C;
+    uint32_t sel[C];
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) sel[cc] = 0x0c0c0c00u | (jb + cc < bp.q_len ? (uint32_t)(q[jb + cc] & 7) : 5u);
+    int H[C], E[C];
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) { H[cc] = 0; E[cc] = 0; }
+    int F = 0, prev_hl = 0;
+#define SMG_BGET(r) ((sidx > 0 && (r) >= plo && (r) < phi) ? bprev[(r)] : make_int2(0, 0))
+    __syncthreads();
+    if (sidx > 0) {
+      ring_in[g] = SMG_BGET(r_lo + g);
+      if (g == 0) prev_hl = SMG_BGET(r_lo - 1).x;
+    }
+    __syncthreads();
+    const int nstep = nr + 63;
+    for (int step = 0; step < nstep; step++) {
+      const int rel = step - g, row = r_lo + rel;
+      if (sidx > 0 && (step & 63) == 0) ring_in[((step >> 6) + 1) % 2 * 64 + g] = SMG_BGET(r_lo + step + 64 + g);
+      const bool rowok = rel >= 0 && rel < nr;
+      const uint32_t rb = rowok ? win[bp.s_left + row] : 5u;
+      const uint2 tr = tab[rb];
+      int hl = wave_shr1(H[C - 1]);
+      int fin = wave_shr1(F);
+      if (g == 0) {
+        if (sidx > 0) { const int2 v = ring_in[(step >> 6) % 2 * 64 + (step & 63)]; hl = v.x; fin = v.y; }
+        else { hl = 0; fin = 0; }
+      }
+      int diag = prev_hl;
+      prev_hl = hl;
+      F = fin;
+      if (rowok) {
+        const int jsr = clipped ? bp.q_left : bp.l_edge + row;
+        const int jlr = min(bp.r_edge + 1 + row, bp.q_len);
+#pragma unroll
+        for (int cc = 0; cc < C; cc++) {
+          const int hold = H[cc];
+          const int j = jb + cc;
+          if (j >= jsr && j < jlr) {
+            const int hin = diag + (int)__builtin_amdgcn_perm(tr.y, tr.x, sel[cc]) - bias;
+            bool cand;
+            (void)cell_update(H[cc], E[cc], F, hin, gi, ge, cand);
+            if (cand && hin > best) best = hin;
+          } else F = 0;
+          diag = hold;
+        }
+      } else F = 0;
+      if (sidx + 1 < nstrip) {                       // hand the last column to the next strip
+        if (g == 63 && rowok) ring_out[rel & 127] = make_int2(H[C - 1], F);
+        const int rdone = step - 63;                 // row lane 63 has just finished
+        if (rdone >= 0 && ((rdone & 63) == 63 || rdone == nr - 1)) {
+          __syncthreads();
+          const int base = rdone & ~63, r2 = base + g;
+          if (r2 <= rdone && r2 < nr) bnext[r_lo + r2] = ring_out[r2 & 127];
+        }
+      }
+      if (sidx > 0 && (step & 63) == 63) __syncthreads();   // the read-ahead chunk is in place before lane 0 turns to it
+    }
+#undef SMG_BGET
+    plo = r_lo; phi = r_hi;
+    __threadfence();
+  }
+  for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
+  return best;
+}
+
+// banded tasks of long reads (S7 lists them with the strip tasks) and K2a tasks whose score left 16 bits
+__global__ void __launch_bounds__(64) k_sw_band(Batch b, DevIndex ix, MapPar p, int2 *bnd_all, uint8_t *win_all, uint32_t wcap) {
+  const unsigned long long nlist = b.work[WK_STRIP_TASKS];
+  if (nlist == 0 || !b.strip_list || nlist > b.strip_cap) return;       // k_sw_scalar takes whatever is left
+  __shared__ uint2 tab[8];
+  __shared__ int2 ring[256];
+  const int bias = (p.mismatch < p.mismatch - p.match ? -p.mismatch : -(p.mismatch - p.match));
+  sw_tab8(tab, p, bias);
+  __syncthreads();
+  int2 *bnd = bnd_all + (size_t)blockIdx.x * 2 * wcap;
+  uint8_t *win = win_all + (size_t)blockIdx.x * wcap;
+  for (uint32_t tl = blockIdx.x; tl < (uint32_t)nlist; tl += gridDim.x) {
+    const uint32_t t = b.strip_list[tl];
+    const RCand c = b.rcpool[t];
+    const uint32_t qlen = read_len(b, c.rid), wlen = (uint32_t)(c.re - c.rs + 1);
+    if (!(c.flags & RCF_BANDED) || (c.flags & (RCF_ERR | RCF_BSCORED)) || wlen > wcap) continue;     // wave-uniform
+    Band bd;
+    if (band_init(bd, c.band_l, c.band_r, (int)c.qs, (int)c.qe, (int)qlen, 0, (int)wlen - 1, (int)wlen)) {
+      if (threadIdx.x == 0) b.rcpool[t].flags = c.flags | RCF_ERR;
+      continue;
+    }
+    const uint64_t gbase = (c.sqidx < 0 ? 0ull : ix.sop[c.sqidx]) + c.rs;
+    const uint8_t *q = ((c.flags & RCF_REVERSE) ? b.codes_rc : b.codes) + b.read_off[c.rid];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < wlen; i += 64) win[i] = (uint8_t)ref_code(ix.packed, gbase + i);
+    __threadfence();
+    __syncthreads();
+    const int best = band_fast_wave(bd, q, win, bnd, wcap, tab, ring, bias, -p.gap_init, -p.gap_ext);
+    if (threadIdx.x == 0) {
+      b.rcpool[t].swscor = best;
+      b.rcpool[t].flags = c.flags | RCF_SCORED | RCF_BSCORED;
+    }
+  }
+}
+
 // K2a for tasks the register-tiled kernel does not cover (long reads / long windows) and
 // K2b (banded score-only pass, alignment.c:1029) -- one lane per task, rows in HBM scratch.
 __global__ void __launch_bounds__(64) k_sw_scalar(Batch b, DevIndex ix, MapPar p, int *rows, uint32_t rowlen, int full_gc) {
@@ -763,7 +894,7 @@ __global__ void __launch_bounds__(64) k_sw_scalar(Batch b, DevIndex ix, MapPar p
   score_matrix(M, p.match, p.mismatch);
   for (uint32_t t = tid; t < ntask; t += nthr) {
     RCand c = b.rcpool[t];
-    if (c.flags & (RCF_ERR | RCF_SCORED)) { if (!(c.flags & RCF_BANDED) || (c.flags & RCF_ERR)) continue; }
+    if (c.flags & (RCF_ERR | RCF_SCORED)) { if (!(c.flags & RCF_BANDED) || (c.flags & (RCF_ERR | RCF_BSCORED))) continue; }
     const uint32_t qlen = read_len(b, c.rid), wlen = (uint32_t)(c.re - c.rs + 1);
     const uint8_t *q = ((c.flags & RCF_REVERSE) ? b.codes_rc : b.codes) + b.read_off[c.rid];
     const uint64_t gbase = (c.sqidx < 0 ? 0ull : ix.sop[c.sqidx]) + c.rs;
@@ -958,6 +1089,7 @@ int launch_sw_strip(hipStream_t s, const Batch &b, const DevIndex &ix, const Map
   if (sw16_ok(p) && (uint64_t)b.qmax * (uint64_t)p.match < 60000ull)          // 16-bit halves hold every score of these reads
     hipLaunchKernelGGL(k_sw_strip16, dim3(grid), dim3(64), 0, s, b, ix, p, (uint2 *)bnd, (uint16_t *)win, wcap);
   hipLaunchKernelGGL(k_sw_strip, dim3(grid), dim3(64), 0, s, b, ix, p, (int2 *)bnd, win, wcap);
+  hipLaunchKernelGGL(k_sw_band, dim3(grid), dim3(64), 0, s, b, ix, p, (int2 *)bnd, win, wcap);
   SMG_LAUNCH_CHECK();
   return 0;
 }
