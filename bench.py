@@ -173,7 +173,7 @@ def main():
     offs = torch.arange(sub + 1, dtype=torch.int64, device=dev) * args.read_len
     torch.cuda.synchronize()
 
-    ms_acc, work_acc = {}, [0] * 24
+    ms_acc, work_acc = {}, [0] * 32
 
     def one_step(collect):
         mapped = total_res = 0
@@ -189,7 +189,7 @@ def main():
                 ms, wk = mp.timers()
                 for kk, v in ms.items():
                     ms_acc[kk] = ms_acc.get(kk, 0.0) + v
-                for i in range(24):
+                for i in range(32):
                     work_acc[i] += wk[i]
         for bi, b0 in enumerate(range(0, args.reads, sub)):
             n = min(sub, args.reads - b0)
@@ -261,6 +261,7 @@ def main():
             "roofline_sw": roof_sw, "roofline_seed": roof_seed,
             "kernel_ms_per_step": {kk: v / args.steps for kk, v in ms_acc.items()},
             "dominant_kernel": dom,
+            "align_phase": {"ticks_window_band_trace": work_acc[24:27], "band_passes": work_acc[27], "aligned_candidates": work_acc[28], "band_steps": work_acc[29], "sequential_passes": work_acc[30], "band_width_sum": work_acc[31]},
             "cands_phase_share": [round(x / max(1, sum(work_acc[8:17])), 4) for x in work_acc[8:17]],
             "cands_phase_ticks": sum(work_acc[8:17]),
             "cands_windows": {"hits_in_windowed_strands": work_acc[20], "window_gather_share": round(work_acc[21] / max(1, sum(work_acc[8:17])), 4),

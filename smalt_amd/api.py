@@ -207,9 +207,9 @@ class Mapper:
         return out
 
     def timers(self):
-        ms = (C.c_double * 24)()
-        wk = (C.c_uint64 * 24)()
-        n = lib().smaltgpu_timers(self.h, ms, wk, 24)
+        ms = (C.c_double * 32)()
+        wk = (C.c_uint64 * 32)()
+        n = lib().smaltgpu_timers(self.h, ms, wk, 32)
         names = [lib().smaltgpu_timer_name(i).decode() for i in range(n)]
         return dict(zip(names, list(ms)[:n])), list(wk)
 

@@ -153,6 +153,7 @@ struct smaltgpu_mapper {
   int *sw_rows = nullptr; uint32_t sw_rowlen = 0, sw_threads = 0;
   void *strip_bnd = nullptr; uint8_t *strip_win = nullptr; uint32_t strip_grid = 0;   // k_sw_strip: boundary columns + decoded window per workgroup
   uint8_t *align_scr = nullptr; size_t align_bytes = 0; uint32_t align_slots = 0;
+  uint8_t *align_scr2 = nullptr; size_t align_bytes2 = 0; uint32_t align_slots2 = 0; uint64_t dircap2 = 0;   // second K3 pass: few slots with full-size direction matrices
   uint32_t wincap = 0, rescap_slot = 0, dstrcap_slot = 0; uint64_t dircap = 0;
   // host mirrors
   std::vector<ReadStat> h_stat;
@@ -272,8 +273,22 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
     DA(m->strip_win, (size_t)m->strip_grid * m->wincap * 2);      // code pairs of the packed strip kernel
     m->dircap = (uint64_t)(m->qmax + 64) * (m->wincap + 8);
     m->rescap_slot = 512; m->dstrcap_slot = 512 * (m->qmax / 4 + 48);
+    if (m->dircap > (4ull << 20)) {
+      // Long reads: a full direction matrix (read x window) is 10-300 MB, a band rarely needs a tenth of it.  The many
+      // slots of the first pass hold a sixteenth; a read whose band does not fit is deferred to a second pass over a
+      // few full-size slots.
+      m->dircap2 = m->dircap;
+      m->dircap = m->dircap / 16 > (4ull << 20) ? m->dircap / 16 : (4ull << 20);
+      if (const char *e = getenv("SMALTGPU_ALIGN_DIRCAP")) { const long v = atol(e); if (v >= 4096 && (uint64_t)v < m->dircap2) m->dircap = (uint64_t)v; }   // test hook
+      m->align_bytes2 = align_scratch_bytes(m->qmax, m->wincap, m->dircap2, m->rescap_slot, m->dstrcap_slot);
+      m->align_slots2 = max_batch_reads < 16 ? max_batch_reads : 16;
+      DA(m->align_scr2, m->align_bytes2 * m->align_slots2);
+    }
     m->align_bytes = align_scratch_bytes(m->qmax, m->wincap, m->dircap, m->rescap_slot, m->dstrcap_slot);
     uint64_t budget = 8ull << 30;
+    if (m->align_bytes * 512 > budget) budget = m->align_bytes * 512;      // long reads: direction matrices of 10-300 MB per slot
+    if (budget > (48ull << 30)) budget = 48ull << 30;
+    if (const char *e = getenv("SMALTGPU_SLOT_BUDGET_GB")) { const uint64_t g = (uint64_t)atol(e) << 30; if (g > 0 && g < budget) budget = g; }
     uint64_t slots = budget / m->align_bytes;
     if (slots > 8192) slots = 8192;
     if (slots < 16) slots = 16;
@@ -292,7 +307,7 @@ extern "C" void smaltgpu_mapper_free(smaltgpu_mapper *m) {
   (void)hipSetDevice(m->device);
   void *ps[] = {m->d_bases, m->d_quals, m->d_codes, m->d_codes_rc, m->d_off, m->b.hi, m->b.seeds, m->b.qmask, m->b.ch, m->b.ctl,
                 m->b.stat, m->b.rcpool, m->b.long_list, m->b.strip_list, m->strip_bnd, m->strip_win, m->b.respool, m->b.dstrpool, m->d_counters, m->seed_scr, m->cand_scr, m->cand_scr_dbg,
-                m->sw_rows, m->align_scr};
+                m->sw_rows, m->align_scr, m->align_scr2};
   for (void *p : ps) if (p) (void)hipFree(p);
   for (int i = 0; i <= T_NUM; i++) if (m->ev[i]) (void)hipEventDestroy(m->ev[i]);
   if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -363,7 +378,8 @@ static int run_pipeline(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_
   HIPCHK(hipEventRecord(m->ev[T_REPLAY], s));
   if (!rv) rv = launch_replay(s, b, d, p);
   HIPCHK(hipEventRecord(m->ev[T_ALIGN], s));
-  if (!rv) rv = launch_align(s, b, d, p, m->align_scr, m->align_bytes, m->align_slots, m->wincap, m->dircap, m->rescap_slot, m->dstrcap_slot);
+  if (!rv) rv = launch_align(s, b, d, p, m->align_scr, m->align_bytes, m->align_slots, m->wincap, m->dircap, m->rescap_slot, m->dstrcap_slot, m->align_scr2 ? 1 : 0);
+  if (!rv && m->align_scr2) rv = launch_align(s, b, d, p, m->align_scr2, m->align_bytes2, m->align_slots2, m->wincap, m->dircap2, m->rescap_slot, m->dstrcap_slot, 2);
   HIPCHK(hipEventRecord(m->ev[T_NUM], s));
   if (rv) return fail(SMALTGPU_ENODEV, "kernel launch failed: %s", hipGetErrorString((hipError_t)rv));
   return SMALTGPU_OK;

@@ -27,7 +27,7 @@ inline size_t cand_slot_bytes(const CandGeom &g, uint32_t qmax, int s) {
 int launch_cands(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint8_t *scratch, uint32_t nslots, const CandGeom &g);
 int launch_replay(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p);
 int launch_align(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint8_t *scratch, size_t sbytes, uint32_t nslots,
-                 uint32_t wincap, uint64_t dircap, uint32_t rescap, uint32_t dstrcap);
+                 uint32_t wincap, uint64_t dircap, uint32_t rescap, uint32_t dstrcap, int pass);
 int sw_full_geometry(uint32_t qmax_len, int *G, int *C);
 int launch_sw_full(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t qmax_len, uint32_t ntask_cap, uint32_t grid);
 int launch_sw_strip(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, void *bnd, uint8_t *win, uint32_t wcap, uint32_t grid);

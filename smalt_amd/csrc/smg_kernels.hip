@@ -61,6 +61,9 @@ __global__ void __launch_bounds__(64) k_seed(Batch b, DevIndex ix, MapPar p, uin
 
 // S3 - S7: one wave per read.  Reads the wave-parallel form covers (smg_cands.hpp) keep their
 // per-strand working set in LDS; everything else takes the sequential restatement on the HBM slot.
+// LONGK: the mapper takes reads of 256 bases and more; every read then goes through the general instance of the
+// wave-parallel form (mappers for short reads keep the lean one: fewer registers, more resident waves).
+template <bool LONGK>
 __global__ void __launch_bounds__(64) k_cands(Batch b, DevIndex ix, MapPar p, uint8_t *gscratch, CandGeom g, uint32_t lds_bytes) {
   extern __shared__ __align__(16) uint8_t lds[];
   unsigned long long nhit = 0;
@@ -71,8 +74,7 @@ __global__ void __launch_bounds__(64) k_cands(Batch b, DevIndex ix, MapPar p, ui
     if (cands_v2_applicable(p, ix.k, ix.s, read_len(b, r))) {
       CandsV2Scratch x = cands_v2_carve(lds + LDS_GUARD, lds_bytes, base, b.qmax, ix.s, g.hcap_strand, g.ngrp, g.candcap, g.debug != 0);
       x.window = g.window; x.lds_hits = g.lds_hits; x.tab = g.tab;
-      if (read_len(b, r) > 255) nhit += stage_cands_v2<true>(b, ix, p, r, x, ph);
-      else nhit += stage_cands_v2<false>(b, ix, p, r, x, ph);
+      nhit += stage_cands_v2<LONGK>(b, ix, p, r, x, ph);
     } else {
       CandScratch x = cand_scratch_carve(base, b.qmax, ix.s, g.hcap, g.ngrp, g.segcap, g.candcap);
       nhit += stage_cands(b, ix, p, r, x);
@@ -99,12 +101,14 @@ __global__ void __launch_bounds__(256) k_replay(Batch b, DevIndex ix, MapPar p) 
 // K3: one wave per read; hot arrays in LDS, results and oversized direction matrices in the HBM slot
 template <bool WIDE>
 __global__ void __launch_bounds__(64) k_align(Batch b, DevIndex ix, MapPar p, uint8_t *gscratch, size_t gbytes, uint32_t wincap,
-                                              uint64_t dircap, uint32_t rescap, uint32_t dstrcap, uint32_t lds_bytes) {
+                                              uint64_t dircap, uint32_t rescap, uint32_t dstrcap, uint32_t lds_bytes, int pass) {
   extern __shared__ __align__(16) uint8_t lds[];
   uint8_t *base = gscratch + gbytes * blockIdx.x;
   AlignScratch x = align_scratch_carve_lds(lds_bytes ? lds + LDS_GUARD : nullptr, lds_bytes, base, b.qmax, wincap, dircap, rescap, dstrcap);
+  x.pass = pass;
   __shared__ uint32_t qslot;
-  for (uint32_t r = next_item(b.next_item + 2, &qslot); r < b.nreads; r = next_item(b.next_item + 2, &qslot)) {
+  uint32_t *cursor = b.next_item + (pass == 2 ? 3 : 2);
+  for (uint32_t r = next_item(cursor, &qslot); r < b.nreads; r = next_item(cursor, &qslot)) {
     stage_align<WIDE>(b, ix, p, r, x);
     __syncthreads();
   }
@@ -1018,7 +1022,8 @@ int launch_cands(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar
   if (!b.nreads) return 0;
   uint32_t grid = b.nreads < nslots ? b.nreads : nslots;
   const uint32_t lds_bytes = (uint32_t)(((strand_work_bytes<uint16_t>(g.lds_hits) + 15) & ~(size_t)15) + (size_t)5 * g.tab * 4);
-  hipLaunchKernelGGL(k_cands, dim3(grid), dim3(64), lds_bytes + LDS_GUARD, s, b, ix, p, scratch, g, lds_bytes);
+  if (b.qmax > 255) hipLaunchKernelGGL(k_cands<true>, dim3(grid), dim3(64), lds_bytes + LDS_GUARD, s, b, ix, p, scratch, g, lds_bytes);
+  else hipLaunchKernelGGL(k_cands<false>, dim3(grid), dim3(64), lds_bytes + LDS_GUARD, s, b, ix, p, scratch, g, lds_bytes);
   SMG_LAUNCH_CHECK();
   return 0;
 }
@@ -1031,14 +1036,16 @@ int launch_replay(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPa
 }
 
 int launch_align(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint8_t *scratch, size_t sbytes, uint32_t nslots,
-                 uint32_t wincap, uint64_t dircap, uint32_t rescap, uint32_t dstrcap) {
+                 uint32_t wincap, uint64_t dircap, uint32_t rescap, uint32_t dstrcap, int pass) {
   if (!b.nreads) return 0;
   uint32_t grid = b.nreads < nslots ? b.nreads : nslots;
   size_t small = align_lds_small_bytes(b.qmax, wincap);
   static const uint32_t lds_kb = getenv("SMALTGPU_ALIGN_LDS_KB") ? (uint32_t)atoi(getenv("SMALTGPU_ALIGN_LDS_KB")) : 8u;   // tuning hook; 8 KB = 20 workgroups per CU
-  uint32_t lds_bytes = small + 4096 <= lds_kb * 1024 ? lds_kb * 1024 - LDS_GUARD : 0;      // rows + window + direction bytes
-  if (b.qmax > 256) hipLaunchKernelGGL(k_align<true>, dim3(grid), dim3(64), lds_bytes ? lds_bytes + LDS_GUARD : 0, s, b, ix, p, scratch, sbytes, wincap, dircap, rescap, dstrcap, lds_bytes);
-  else hipLaunchKernelGGL(k_align<false>, dim3(grid), dim3(64), lds_bytes ? lds_bytes + LDS_GUARD : 0, s, b, ix, p, scratch, sbytes, wincap, dircap, rescap, dstrcap, lds_bytes);
+  uint32_t kb = lds_kb;
+  if (b.qmax > 256 && small + 4096 > (size_t)kb * 1024 && small + 8192 <= 64 * 1024) kb = (uint32_t)((small + 8192 + 1023) / 1024);   // long reads: read, window and traceback string stay in LDS
+  uint32_t lds_bytes = small + 4096 <= (size_t)kb * 1024 ? kb * 1024 - LDS_GUARD : 0;      // rows + window + direction bytes
+  if (b.qmax > 256) hipLaunchKernelGGL(k_align<true>, dim3(grid), dim3(64), lds_bytes ? lds_bytes + LDS_GUARD : 0, s, b, ix, p, scratch, sbytes, wincap, dircap, rescap, dstrcap, lds_bytes, pass);
+  else hipLaunchKernelGGL(k_align<false>, dim3(grid), dim3(64), lds_bytes ? lds_bytes + LDS_GUARD : 0, s, b, ix, p, scratch, sbytes, wincap, dircap, rescap, dstrcap, lds_bytes, pass);
   SMG_LAUNCH_CHECK();
   return 0;
 }

@@ -614,38 +614,23 @@ SMG_HD inline int band_init(Band &b, int l_edge, int r_edge, int q_left, int q_r
   return (b.band_width >= 0) ? 0 : -1;
 }
 
-// returns direction; cand: whether the cell may raise the running maximum
+// returns direction; cand: whether the cell may raise the running maximum.
+// The reference spells the update out as a tree of cases on the signs of E and F (alignment.c:884-983).  With
+// e = max(E, 0), f = max(F, 0) and m = max(e, f) the tree is: the diagonal wins iff H > m (strictly); otherwise the
+// cell takes m, from E when e >= f (DIR_COL) else from F (DIR_ROW), or direction 0 when m == 0; a positive gap
+// score is extended (minus ge) whatever the outcome, a non-positive one is left alone; and when the diagonal wins
+// with H > gi both gap scores are raised to H - gi.  Branch-free, which is what 64 lanes in lock step need.
 SMG_HD inline int cell_update(int &Hj, int &E, int &F, int H, int gi, int ge, bool &cand) {
-  int dir;
-  cand = false;
-  if (F > 0) {
-    if (E > 0) {
-      if (H > E) {
-        if (H > F) {
-          Hj = H; F -= ge; E -= ge; dir = DIR_DIA;
-          if (H > gi) { cand = true; int t = H - gi; if (F < t) F = t; if (E < t) E = t; }
-        } else { Hj = F; F -= ge; E -= ge; dir = DIR_ROW; }
-      } else {
-        if (E >= F) { Hj = E; dir = DIR_COL; } else { Hj = F; dir = DIR_ROW; }
-        E -= ge; F -= ge;
-      }
-    } else {
-      if (H > F) {
-        Hj = H; F -= ge; dir = DIR_DIA;
-        if (H > gi) { cand = true; E = H - gi; if (F < E) F = E; }
-      } else { Hj = F; F -= ge; dir = DIR_ROW; }
-    }
-  } else if (E > 0) {
-    if (H > E) {
-      Hj = H; E -= ge; dir = DIR_DIA;
-      if (H > gi) { cand = true; F = H - gi; if (E < F) E = F; }
-    } else { Hj = E; E -= ge; dir = DIR_COL; }
-  } else {
-    if (H > 0) {
-      Hj = H; dir = DIR_DIA;
-      if (H > gi) { cand = true; F = E = H - gi; }
-    } else { Hj = 0; dir = 0; }
-  }
+  const int e = E > 0 ? E : 0, f = F > 0 ? F : 0;
+  const int m = e > f ? e : f;
+  const bool dia = H > m;
+  Hj = dia ? H : m;
+  const int dir = dia ? (int)DIR_DIA : (m == 0 ? 0 : (e >= f ? (int)DIR_COL : (int)DIR_ROW));
+  const int t = H - gi;
+  cand = dia && H > gi;
+  const int Ed = E - (E > 0 ? ge : 0), Fd = F - (F > 0 ? ge : 0);
+  E = (cand && t > Ed) ? t : Ed;
+  F = (cand && t > Fd) ? t : Fd;
   return dir;
 }
 

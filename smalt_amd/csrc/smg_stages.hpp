@@ -43,7 +43,8 @@ struct Batch {                          // one block of reads resident in HBM
 };
 enum : int { WK_LOOKUPS = 0, WK_HITS = 1, WK_CELLS_FULL = 2, WK_TASKS_FULL = 3, WK_CELLS_BAND = 4, WK_NCAND = 5, WK_NKEPT = 6,
               WK_QN_TASKS = 7 /* ranked candidates of reads with non-ACGT codes */, WK_LONG_TASKS = 17 /* windows > SW_SHORT_WMAX */, WK_STRIP_TASKS = 18 /* beyond the register tiling */,
-              WK_PHASE0 = 8 /* .. 23: shader-clock ticks per phase of k_cands (diagnostic) */, WK_NWORK = 24 };
+              WK_PHASE0 = 8 /* .. 23: shader-clock ticks per phase of k_cands (diagnostic) */,
+              WK_ALIGN0 = 24 /* .. 31: k_align ticks (window fetch, band pass, traceback + results), band passes, aligned candidates, band steps, sequential passes, sum of band widths */, WK_NWORK = 32 };
 
 // The score kernels walk the candidate pool linearly.  A read whose ranked candidates do not fit keeps none
 // (SMG_ERR_CAP); the part of its reservation that still lies inside the pool is filled with inert entries.
@@ -699,6 +700,7 @@ struct AlignScratch {
   int32_t *state;             // [16] lane-0 state visible to the wave
   uint8_t *qcodes; uint32_t qstride;   // [2][qstride] the read in both orientations
   uint8_t *win_lds, *dtmp_lds; uint32_t win_lds_cap;   // LDS copies for windows of ordinary length (else the HBM arrays)
+  int pass;                   // 0: only pass; 1: first of two (a band that does not fit defers the read); 2: second (deferred reads only)
 };
 
 SMG_HD inline size_t align_scratch_bytes(uint32_t qmax, uint32_t wincap, uint64_t dircap, uint32_t rescap, uint32_t dstrcap) {
@@ -722,6 +724,7 @@ SMG_HD inline AlignScratch align_scratch_carve(uint8_t *base, uint32_t qmax, uin
   x.dir = base; x.dircap = dircap;
   x.dir_lds = nullptr; x.dir_lds_cap = 0;
   x.win_lds = x.dtmp_lds = nullptr; x.win_lds_cap = 0;
+  x.pass = 0;
   return x;
 }
 
@@ -784,15 +787,46 @@ SMG_HD inline int band_track_scalar(const Band &bp, const uint8_t *q, const uint
 
 // makeMetaFromTrack (alignment.c:628-781): traceback into a REVERSED DiffStr; returns its
 // length (with terminator) or < 0
+// Direction bytes of a band pass.  tW == 0: the reference's layout (row-major, band_width - 1 bytes per row).
+// tW > 0: anti-diagonal-major, tW bytes per step t = row + column -- the cells the wave computes in one step are
+// neighbours in memory (at most band_width / 2 + 1 columns are live per step), which is what a direction matrix
+// in HBM needs; only cells the pass has computed are ever read back, so the layout is private to the two routines.
+SMG_HD inline size_t dir_index(const Band &bp, int tW, int ip, int j) {
+  if (!tW) return (size_t)ip * (size_t)(bp.band_width - 1) + (size_t)(j - bp.l_edge);
+  const int jmin = bp.q_left > bp.l_edge ? bp.q_left : bp.l_edge;
+  return (size_t)(ip + (j - jmin)) * (size_t)tW + (size_t)((j - jmin) % tW);
+}
+
 SMG_HD inline int traceback_scalar(uint8_t *ds, uint32_t dscap, int *qs, int *rs, const Band &bp, const uint8_t *dir,
                                    int max_i, int max_j, int max_scor, const uint8_t *q, const uint8_t *win,
-                                   const int8_t *M, int gi, int ge) {
+                                   const int8_t *M, int gi, int ge, int tW = 0) {
   uint32_t n = 0;
   int i, j, checksum = 0;
   bool gap_open = false;
   uint8_t nmatch = 0;
-  const uint8_t *dp = dir + (size_t)(max_i - bp.s_left) * (size_t)(bp.band_width - 1) + (size_t)(max_j - bp.l_edge);
+  const uint8_t *dp = dir + dir_index(bp, tW, max_i - bp.s_left, max_j);
 #define SMG_PUT(cnt, typ) { if (n + 2 >= dscap) return -2; ds[n++] = (uint8_t)((cnt) + ((typ) << DIFF_TYPSHIFT)); }
+  if (tW) {
+    for (i = max_i, j = max_j; i >= bp.s_left && j >= bp.q_left;) {
+      const uint8_t d = dir[dir_index(bp, tW, i - bp.s_left, j)];
+      if (!d) break;
+      if (d == DIR_DIA) {
+        int s = M[8 * (win[i] & 7) + (q[j] & 7)];
+        if (s > 0) {
+          if (nmatch > DIFF_MAXMISMATCH) { SMG_PUT(DIFF_MAXMISMATCH, DIFF_M) nmatch -= DIFF_MAXMISMATCH; }
+          else nmatch++;
+        } else { SMG_PUT(nmatch, DIFF_S) nmatch = 0; }
+        checksum += s;
+        gap_open = false;
+        i--; j--;
+        continue;
+      }
+      if (gap_open) checksum -= ge; else { checksum -= gi; gap_open = true; }
+      if (d & DIR_COL) { SMG_PUT(nmatch, DIFF_D) nmatch = 0; i--; continue; }
+      if (!(d & DIR_ROW)) return -1;
+      SMG_PUT(nmatch, DIFF_I) nmatch = 0; j--;
+    }
+  } else
   for (i = max_i, j = max_j; i >= bp.s_left && j >= bp.q_left && *dp;) {
     if (*dp == DIR_DIA) {
       int s = M[8 * (win[i] & 7) + (q[j] & 7)];
@@ -829,8 +863,11 @@ __device__ inline int wave_ror1(int v) {      // value of lane-1 (lane 0 takes l
 // H/E stay in registers.  A column that enters the band starts from H = E = 0 (:871-872), exactly
 // as the reference's row buffers do.  Ties of the maximum resolve to the first cell in row-major
 // order (:826-830) by reducing (score, row, column).
-__device__ inline int band_track_wave(const Band &bp, const uint8_t *q, const uint8_t *win, int match, int mismatch, int gi, int ge,
-                                      uint8_t *dir, int *max_i, int *max_j) {
+// PW: pointer type of the read and window codes -- LDS-typed where they live in LDS, so that their loads (ds_read, not
+// flat) never wait for the direction bytes a long read streams to HBM.
+template <class PW = const uint8_t *>
+__device__ inline int band_track_wave(const Band &bp, PW q, PW win, int match, int mismatch, int gi, int ge,
+                                      uint8_t *dir, int *max_i, int *max_j, int tW = 0) {
   const int lane = (int)threadIdx.x;
   const int nrows = bp.s_len - bp.s_left, l = bp.l_edge, r = bp.r_edge, bw = bp.band_width;
   const int jmin = bp.q_left > l ? bp.q_left : l;
@@ -860,7 +897,7 @@ __device__ inline int band_track_wave(const Band &bp, const uint8_t *q, const ui
       const int hb = Hcol;
       const int d = cell_update(Hnew, Ecol, F, Hin, gi, ge, cand);
       Hprev = hb; Hcol = Hnew; Fout = F; lastrow = ip; lastcol = j;
-      dir[(size_t)ip * (size_t)(bw - 1) + (size_t)(j - l)] = (uint8_t)d;
+      dir[tW ? (size_t)t * (size_t)tW + (size_t)((j - jmin) % tW) : (size_t)ip * (size_t)(bw - 1) + (size_t)(j - l)] = (uint8_t)d;
       if (cand && Hin > best) { best = Hin; bi = ip; bj = j; }
     }
   }
@@ -876,9 +913,9 @@ __device__ inline int band_track_wave(const Band &bp, const uint8_t *q, const ui
 // The same for wider bands.  Columns jmin + c + 64m of lane c that are inside the band at step t differ by 128
 // diagonals, so a lane has at most (r - l) / 128 + 1 live columns; column m keeps its state in register slot m % NS.
 // The left neighbour of (lane c, slot s) is (lane c - 1, slot s), for lane 0 (lane 63, slot s - 1).
-template <int NS>
-__device__ inline int band_track_wave_n(const Band &bp, const uint8_t *q, const uint8_t *win, int match, int mismatch, int gi, int ge,
-                                        uint8_t *dir, int *max_i, int *max_j) {
+template <int NS, class PW = const uint8_t *>
+__device__ inline int band_track_wave_n(const Band &bp, PW q, PW win, int match, int mismatch, int gi, int ge,
+                                        uint8_t *dir, int *max_i, int *max_j, int tW = 0) {
   const int lane = (int)threadIdx.x;
   const int nrows = bp.s_len - bp.s_left, l = bp.l_edge, r = bp.r_edge, bw = bp.band_width;
   const int jmin = bp.q_left > l ? bp.q_left : l;
@@ -896,6 +933,13 @@ __device__ inline int band_track_wave_n(const Band &bp, const uint8_t *q, const 
     const int mlo = x0 <= 0 ? 0 : (x0 + 127) >> 7;
     const int mhi = x1 < 0 ? -1 : x1 >> 7;
     const int mlo_s = mlo % NS;
+    int rbv[NS];                              // window codes of all live columns first: the loads overlap
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      const int m = mlo + (s - mlo_s + NS) % NS;
+      const int ip = t - lane - 64 * m;
+      rbv[s] = (m <= mhi && ip >= 0 && ip < nrows) ? win[bp.s_left + ip] & 7 : 5;
+    }
 #pragma unroll
     for (int s = 0; s < NS; s++) {
       const int m = mlo + (s - mlo_s + NS) % NS;
@@ -912,7 +956,7 @@ __device__ inline int band_track_wave_n(const Band &bp, const uint8_t *q, const 
           if (vrow == ip) { diag = vHp; F = vF; }
           else if (vrow == ip - 1) diag = vH;
         }
-        const int rb = win[bp.s_left + ip] & 7;
+        const int rb = rbv[s];
         const int w = (rb >= 4 || qc[s] >= 4) ? 0 : (rb == qc[s] ? match : mismatch);
         const int Hin = diag + w;
         int Hnew;
@@ -920,7 +964,7 @@ __device__ inline int band_track_wave_n(const Band &bp, const uint8_t *q, const 
         const int hb = Hcol[s];
         const int d = cell_update(Hnew, Ecol[s], F, Hin, gi, ge, cand);
         Hprev[s] = hb; Hcol[s] = Hnew; Fout[s] = F; lastrow[s] = ip; lastcol[s] = j;
-        dir[(size_t)ip * (size_t)(bw - 1) + (size_t)(j - l)] = (uint8_t)d;
+        dir[tW ? (size_t)t * (size_t)tW + (size_t)((j - jmin) % tW) : (size_t)ip * (size_t)(bw - 1) + (size_t)(j - l)] = (uint8_t)d;
         if (cand && (Hin > best || (Hin == best && (ip < bi || (ip == bi && j < bj))))) { best = Hin; bi = ip; bj = j; }
       }
     }
@@ -949,6 +993,8 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
   score_matrix(M, p.match, p.mismatch);
   const int gi = -p.gap_init, ge = -p.gap_ext;
 
+  unsigned long long aph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (x.pass == 2 && st.err != SMG_ERR_RETRY) return;       // wave-uniform: the first pass finished this read
   SMG_LANE0 {
     x.state[S_MINSW] = ctl.min_swatscor; x.state[S_SWMAX] = 0; x.state[S_SW2ND] = 0;
     x.state[S_NRES] = 0; x.state[S_NDSTR] = 0; x.state[S_ERR] = ch.err; x.state[S_SP] = 0; x.state[S_NALI] = 0;
@@ -984,10 +1030,13 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
     uint8_t *const win = wlen <= x.win_lds_cap ? x.win_lds : x.win;
     uint8_t *const dtmp = wlen <= x.win_lds_cap ? x.dtmp_lds : x.dtmp;
     const uint32_t dtmpcap = wlen <= x.win_lds_cap ? qlen + x.win_lds_cap + 16 : x.dtmpcap;
+    unsigned long long tq0 = phase_clock(), tq1;
     SMG_PAR_CHUNKS(base, wlen) {                           // fetch + decode the reference window (rmap.c:831-845)
       uint32_t i = base + SMG_LANE;
       if (i < wlen) win[i] = (uint8_t)ref_code(ix.packed, gbase + i);
     }
+    SMG_SYNC();
+    tq1 = phase_clock(); aph[0] += tq1 - tq0; tq0 = tq1; aph[4]++;
     // scalars of this candidate: every lane computes the same values from shared state
     const uint8_t *q = x.qcodes + ((c.flags & RCF_REVERSE) ? x.qstride : 0);
     int min_swatscor = x.state[S_MINSW];
@@ -1026,24 +1075,44 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
       uint8_t *dirm = x.dir;
       if (!nerr && !skip) {
         dneed = (uint64_t)band.band_width * (uint64_t)(band.s_len - band.s_left) + (uint64_t)band.band_width + 8;
-        if (dneed > x.dircap) nerr = SMG_ERR_CAP;
-        else if (dneed <= x.dir_lds_cap) dirm = x.dir_lds;
+        if (dneed <= x.dir_lds_cap) dirm = x.dir_lds;
       }
-      int max_i = 0, max_j = 0, max_scor = 0;
+      int max_i = 0, max_j = 0, max_scor = 0, tW = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (!nerr && !skip && dirm == x.dir && band.band_width >= 1 && (band.band_width <= 64 || (WIDE && (band.r_edge - band.l_edge) / 128 + 1 <= 12))) {
+        // direction matrix in HBM and a wave form: anti-diagonal-major layout (dir_index) if it fits
+        const int jmin = band.q_left > band.l_edge ? band.q_left : band.l_edge;
+        int jlast = band.r_edge + (band.s_len - band.s_left) - 1; if (jlast > band.q_len - 1) jlast = band.q_len - 1;
+        const int w = ((band.band_width / 2 + 2 + 63) / 64) * 64;
+        const int64_t tmax = (int64_t)(band.s_len - band.s_left - 1) + (jlast - jmin);
+        if (tmax >= 0 && (uint64_t)(tmax + 1) * (uint64_t)w + 8 <= x.dircap) tW = w;
+      }
+#endif
+      if (!nerr && !skip && !tW && dirm == x.dir && dneed > x.dircap) nerr = x.pass == 1 ? SMG_ERR_RETRY : SMG_ERR_CAP;
+      tq0 = phase_clock();
+      if (!nerr && !skip) { aph[3]++; aph[7] += (unsigned long long)band.band_width; aph[5] += (unsigned long long)(band.s_len - band.s_left) + (unsigned long long)(band.q_len - band.q_left); }
       if (!nerr && !skip) {
 #if defined(__HIP_DEVICE_COMPILE__)
         const int nslot = band.band_width >= 1 ? (band.r_edge - band.l_edge) / 128 + 1 : 0;    // live columns per lane
+        typedef SMG_LDSQ const uint8_t *PL;
+        const bool in_lds = WIDE && x.win_lds && win == x.win_lds;      // read and window both in the LDS block
         if (band.band_width >= 1 && band.band_width <= 64) {
-          max_scor = band_track_wave(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j);
+          if (in_lds) max_scor = band_track_wave<PL>(band, (PL)q, (PL)win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j, tW);
+          else max_scor = band_track_wave<const uint8_t *>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j, tW);
         } else if (WIDE && nslot >= 1 && nslot <= 2) {
-          max_scor = band_track_wave_n<2>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j);
+          if (in_lds) max_scor = band_track_wave_n<2, PL>(band, (PL)q, (PL)win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j, tW);
+          else max_scor = band_track_wave_n<2, const uint8_t *>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j, tW);
         } else if (WIDE && nslot >= 1 && nslot <= 4) {
-          max_scor = band_track_wave_n<4>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j);
+          if (in_lds) max_scor = band_track_wave_n<4, PL>(band, (PL)q, (PL)win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j, tW);
+          else max_scor = band_track_wave_n<4, const uint8_t *>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j, tW);
         } else if (WIDE && nslot >= 1 && nslot <= 7) {
-          max_scor = band_track_wave_n<7>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j);
+          if (in_lds) max_scor = band_track_wave_n<7, PL>(band, (PL)q, (PL)win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j, tW);
+          else max_scor = band_track_wave_n<7, const uint8_t *>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j, tW);
         } else if (WIDE && nslot >= 1 && nslot <= 12) {
-          max_scor = band_track_wave_n<12>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j);
+          if (in_lds) max_scor = band_track_wave_n<12, PL>(band, (PL)q, (PL)win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j, tW);
+          else max_scor = band_track_wave_n<12, const uint8_t *>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j, tW);
         } else {
+          aph[6]++;
           SMG_LANE0 { x.state[8] = band_track_scalar(band, q, win, M, gi, ge, x.Hp, x.Ep, dirm, &max_i, &max_j); x.state[9] = max_i; x.state[10] = max_j; }
           SMG_SYNC();
           max_scor = x.state[8]; max_i = x.state[9]; max_j = x.state[10];
@@ -1053,11 +1122,12 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
 #endif
       }
       SMG_SYNC();
+      tq1 = phase_clock(); aph[1] += tq1 - tq0; tq0 = tq1;
       SMG_LANE0 {
         int nsp = sp - 1, err = nerr;
         if (!err && !skip && max_scor >= minscore) {
           int qs, rs;
-          const int dn = traceback_scalar(dtmp, dtmpcap, &qs, &rs, band, dirm, max_i, max_j, max_scor, q, win, M, gi, ge);
+          const int dn = traceback_scalar(dtmp, dtmpcap, &qs, &rs, band, dirm, max_i, max_j, max_scor, q, win, M, gi, ge, tW);
           if (dn < 0) err = (dn == -2) ? SMG_ERR_CAP : SMG_ERR_ASSERT;
           const int qe = max_j, re = max_i;
           if (!err && !(qs + minscorlen > qe + 1)) {
@@ -1085,6 +1155,7 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
         x.state[S_SP] = nsp;
       }
       SMG_SYNC();
+      tq1 = phase_clock(); aph[2] += tq1 - tq0; tq0 = tq1;
     }
     SMG_LANE0 {
       const int nali = x.state[S_NALI];
@@ -1144,7 +1215,7 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
     st.res_off = atomic_add_u64(b.res_count, st.nres);
     st.dstr_off = atomic_add_u64(b.dstr_count, st.err ? 0 : nd);
     if (st.res_off + st.nres > b.rescap || st.dstr_off + nd > b.dstrcap) { st.err = SMG_ERR_CAP; st.nres = 0; }
-    if (st.err) atomic_add_u32((uint32_t *)b.err_flag, 1u);
+    if (st.err && st.err != SMG_ERR_RETRY) atomic_add_u32((uint32_t *)b.err_flag, 1u);
     x.state[S_NRES] = (int32_t)st.nres; x.state[S_NDSTR] = st.err ? 0 : (int32_t)nd;
   }
   SMG_SYNC();
@@ -1154,6 +1225,7 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
     SMG_PAR_CHUNKS(base, nres) { uint32_t i = base + SMG_LANE; if (i < nres) b.respool[ro + i] = x.res[i]; }
     SMG_PAR_CHUNKS(base, nd) { uint32_t i = base + SMG_LANE; if (i < nd) b.dstrpool[dof + i] = x.dstr[i]; }
   }
+  SMG_LANE0 { if (aph[4]) for (int i = 0; i < 8; i++) (void)atomic_add_u64(b.work + WK_ALIGN0 + i, aph[i]); }
 }
 
 }  // namespace smg

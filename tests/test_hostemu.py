@@ -83,3 +83,12 @@ def test_long_reads_wave_form_equals_sequential_form(k, s, opts, emu_bin, oracle
     for i, (x, y) in enumerate(zip(a, b)):
         assert x == y, "line %d" % (i + 1)
     assert len(a) == len(b)
+
+
+def test_branch_free_cell_update_equals_case_tree(tmp_path):
+    """K2b / K3 cell update: the product's branch-free form against the reference's case tree, exhaustively over all
+    orderings of its operands (tests/hostemu/cell_equiv.cpp)."""
+    exe = str(tmp_path / "cell_equiv")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "hostemu", "cell_equiv.cpp")], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert out.startswith("ok ")
