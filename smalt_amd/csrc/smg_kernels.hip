@@ -466,7 +466,6 @@ __global__ void __launch_bounds__(64) k_sw_full16_raw(const uint8_t *qcodes, con
 // 32-bit lanes, full 8-byte score rows: any code (N) and any score below 2^31.
 // ---------------------------------------------------------------------------------------
 enum : int { SW_STRIP_C = 16 };
-__device__ inline int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true); }
 
 // win: window codes (HBM, wlen bytes), bnd: 2 x wcap (H, F) pairs of this workgroup
 __device__ inline int sw_strip_core(const uint8_t *q, uint32_t qlen, const uint8_t *win, uint32_t wlen, int2 *bnd, uint32_t wcap,

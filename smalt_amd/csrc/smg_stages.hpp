@@ -701,10 +701,12 @@ struct AlignScratch {
   uint8_t *qcodes; uint32_t qstride;   // [2][qstride] the read in both orientations
   uint8_t *win_lds, *dtmp_lds; uint32_t win_lds_cap;   // LDS copies for windows of ordinary length (else the HBM arrays)
   int pass;                   // 0: only pass; 1: first of two (a band that does not fit defers the read); 2: second (deferred reads only)
+  void *bnd; uint32_t bndcap; // [2 * bndcap] (H, F) pairs: hand-over between the strips of band_track_strip (long reads only)
 };
 
 SMG_HD inline size_t align_scratch_bytes(uint32_t qmax, uint32_t wincap, uint64_t dircap, uint32_t rescap, uint32_t dstrcap) {
   size_t n = ((size_t)qmax + 2) * 8 + wincap + dircap + ((size_t)qmax + wincap + 16) + (size_t)rescap * sizeof(Result) + dstrcap + 128 * 4 + 64 + 256 + 2 * ((size_t)qmax + 8);
+  if (qmax > 256) n += (size_t)wincap * 16 + 64;
   return (n + 255) & ~(size_t)255;
 }
 
@@ -721,6 +723,9 @@ SMG_HD inline AlignScratch align_scratch_carve(uint8_t *base, uint32_t qmax, uin
   x.dtmpcap = qmax + wincap + 16;
   x.dtmp = base; base += x.dtmpcap;
   x.dstr = base; base += dstrcap; x.dstrcap = dstrcap;
+  x.bnd = nullptr; x.bndcap = 0;
+  if (qmax > 256) { base = (uint8_t *)(((uintptr_t)base + 15) & ~(uintptr_t)15); x.bnd = (void *)base; x.bndcap = wincap; base += (size_t)wincap * 16; }
+  base = (uint8_t *)(((uintptr_t)base + 15) & ~(uintptr_t)15);
   x.dir = base; x.dircap = dircap;
   x.dir_lds = nullptr; x.dir_lds_cap = 0;
   x.win_lds = x.dtmp_lds = nullptr; x.win_lds_cap = 0;
@@ -787,6 +792,41 @@ SMG_HD inline int band_track_scalar(const Band &bp, const uint8_t *q, const uint
 
 // makeMetaFromTrack (alignment.c:628-781): traceback into a REVERSED DiffStr; returns its
 // length (with terminator) or < 0
+// ---- strip form of the band pass (wide bands of long reads) ---------------------------------------------------
+// Columns are cut into strips of 64 x 16 (origin j0: the band's first column rounded down to 16); lane g owns 16
+// consecutive columns and sweeps the strip's rows one row behind lane g-1.  Row r visits [js(r), jl(r)) with
+// js(r) = max(q_left, l_edge + r) and jl(r) = min(r_edge + 1 + r, q_len); strip s sweeps the rows [r_lo, r_hi) in which
+// it has visited cells.  Directions take 2 bits: a lane packs its 16 cells of a row into one word and the wave
+// writes word (t, g) of the strip at step t -- 256 contiguous bytes per step.
+struct StripGeom { int j0, l, r, nrows, nstrip; };
+SMG_HD inline StripGeom strip_geom(const Band &bp) {
+  StripGeom sg;
+  const int jmin = bp.q_left > bp.l_edge ? bp.q_left : bp.l_edge;
+  sg.l = bp.l_edge; sg.r = bp.r_edge; sg.nrows = bp.s_len - bp.s_left;
+  int jmax = bp.r_edge + sg.nrows; if (jmax > bp.q_len) jmax = bp.q_len;      // one past the last column visited
+  sg.j0 = jmin & ~15;
+  sg.nstrip = (sg.nrows > 0 && jmax > sg.j0) ? (jmax - sg.j0 + 1023) / 1024 : 0;
+  return sg;
+}
+SMG_HD inline void strip_rows(const StripGeom &sg, int sidx, int *r_lo, int *r_hi) {
+  const int c_lo = sg.j0 + sidx * 1024, c_hi = c_lo + 1024;
+  int lo = c_lo - sg.r; if (lo < 0) lo = 0;
+  int hi = c_hi - sg.l; if (hi > sg.nrows) hi = sg.nrows;
+  *r_lo = lo; *r_hi = hi;
+}
+SMG_HD inline uint64_t strip_words(const StripGeom &sg, int upto) {          // direction words of the strips [0, upto)
+  uint64_t n = 0;
+  for (int sidx = 0; sidx < upto; sidx++) { int lo, hi; strip_rows(sg, sidx, &lo, &hi); if (hi > lo) n += (uint64_t)(hi - lo + 63) * 64; }
+  return n;
+}
+// direction of cell (ip, j); cache: {strip, its first word, its first row} of the previous call
+SMG_HD inline int strip_dir(const StripGeom &sg, const uint32_t *dirw, int ip, int j, int *cache_sidx, uint64_t *cache_base, int *cache_rlo) {
+  const int o = j - sg.j0, sidx = o >> 10, g = (o >> 4) & 63, cc = o & 15;
+  if (sidx != *cache_sidx) { int hi; *cache_sidx = sidx; *cache_base = strip_words(sg, sidx); strip_rows(sg, sidx, cache_rlo, &hi); }
+  const uint32_t w = dirw[*cache_base + (uint64_t)(ip - *cache_rlo + g) * 64 + (uint64_t)g];
+  return (int)((w >> (2 * cc)) & 3u);
+}
+
 // Direction bytes of a band pass.  tW == 0: the reference's layout (row-major, band_width - 1 bytes per row).
 // tW > 0: anti-diagonal-major, tW bytes per step t = row + column -- the cells the wave computes in one step are
 // neighbours in memory (at most band_width / 2 + 1 columns are live per step), which is what a direction matrix
@@ -799,16 +839,18 @@ SMG_HD inline size_t dir_index(const Band &bp, int tW, int ip, int j) {
 
 SMG_HD inline int traceback_scalar(uint8_t *ds, uint32_t dscap, int *qs, int *rs, const Band &bp, const uint8_t *dir,
                                    int max_i, int max_j, int max_scor, const uint8_t *q, const uint8_t *win,
-                                   const int8_t *M, int gi, int ge, int tW = 0) {
+                                   const int8_t *M, int gi, int ge, int tW = 0, const StripGeom *sg = nullptr) {
   uint32_t n = 0;
+  int c_sidx = -1, c_rlo = 0;                  // strip layout (tW < 0): directions come from strip_dir
+  uint64_t c_base = 0;
   int i, j, checksum = 0;
   bool gap_open = false;
   uint8_t nmatch = 0;
-  const uint8_t *dp = dir + dir_index(bp, tW, max_i - bp.s_left, max_j);
+  const uint8_t *dp = dir + (tW < 0 ? 0 : dir_index(bp, tW, max_i - bp.s_left, max_j));
 #define SMG_PUT(cnt, typ) { if (n + 2 >= dscap) return -2; ds[n++] = (uint8_t)((cnt) + ((typ) << DIFF_TYPSHIFT)); }
   if (tW) {
     for (i = max_i, j = max_j; i >= bp.s_left && j >= bp.q_left;) {
-      const uint8_t d = dir[dir_index(bp, tW, i - bp.s_left, j)];
+      const uint8_t d = tW < 0 ? (uint8_t)strip_dir(*sg, (const uint32_t *)dir, i - bp.s_left, j, &c_sidx, &c_base, &c_rlo) : dir[dir_index(bp, tW, i - bp.s_left, j)];
       if (!d) break;
       if (d == DIR_DIA) {
         int s = M[8 * (win[i] & 7) + (q[j] & 7)];
@@ -851,9 +893,107 @@ SMG_HD inline int traceback_scalar(uint8_t *ds, uint32_t dscap, int *qs, int *rs
   return (checksum != max_scor) ? -1 : (int)n;
 }
 
+#if defined(__HIPCC__)
+__device__ inline int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true); }
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ inline int wave_ror1(int v) {      // value of lane-1 (lane 0 takes lane 63)
   return __builtin_amdgcn_update_dpp(v, v, 0x13C /* wave_ror:1 */, 0xf, 0xf, false);
+}
+
+// alignSmiWatBand (alignment.c:788-1027) in strip form; bnd: 2 x wcap (H, F) pairs in HBM for the hand-over between
+// strips (as sw_strip_core, smg_kernels.hip).  Cells outside the band keep H and E and pass F = 0: what a visited cell
+// reads from an unvisited neighbour is then what the reference's row buffers hold (see band_fast_wave).
+template <class PW>
+__device__ inline int band_track_strip(const Band &bp, const StripGeom &sg, PW q, PW win, int match, int mismatch, int gi, int ge,
+                                       uint32_t *dirw, int2 *bnd, uint32_t wcap, int *max_i, int *max_j) {
+  constexpr int C = 16;
+  __shared__ int2 ring[256];
+  const int g = (int)threadIdx.x;
+  int2 *ring_in = ring, *ring_out = ring + 128;
+  int best = 0, bi = 0, bj = 0, plo = 0, phi = 0;
+  uint64_t sbase = 0;
+  for (int sidx = 0; sidx < sg.nstrip; sidx++) {
+    int r_lo, r_hi;
+    strip_rows(sg, sidx, &r_lo, &r_hi);
+    const int nr = r_hi - r_lo;
+    if (nr <= 0) continue;
+    const int2 *bprev = bnd + (size_t)((sidx + 1) & 1) * wcap;
+    int2 *bnext = bnd + (size_t)(sidx & 1) * wcap;
+    const int jb = sg.j0 + sidx * 1024 + g * C;
+    int qc[C];
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) qc[cc] = (jb + cc >= 0 && jb + cc < bp.q_len) ? (int)(q[jb + cc] & 7) : 5;
+    int H[C], E[C];
+#pragma unroll
+    for (int cc = 0; cc < C; cc++) { H[cc] = 0; E[cc] = 0; }
+    int F = 0, prev_hl = 0, sbest = 0, sbi = 0, sbj = 0;
+#define SMG_BGET(rr) ((sidx > 0 && (rr) >= plo && (rr) < phi) ? bprev[(rr)] : make_int2(0, 0))
+    __syncthreads();
+    if (sidx > 0) {
+      ring_in[g] = SMG_BGET(r_lo + g);
+      if (g == 0) prev_hl = SMG_BGET(r_lo - 1).x;
+    }
+    __syncthreads();
+    const int nstep = nr + 63;
+    for (int step = 0; step < nstep; step++) {
+      const int rel = step - g, row = r_lo + rel;
+      if (sidx > 0 && (step & 63) == 0) ring_in[((step >> 6) + 1) % 2 * 64 + g] = SMG_BGET(r_lo + step + 64 + g);
+      const bool rowok = rel >= 0 && rel < nr;
+      const int rb = rowok ? (int)(win[bp.s_left + row] & 7) : 5;
+      int hl = wave_shr1(H[C - 1]);
+      int fin = wave_shr1(F);
+      if (g == 0) {
+        if (sidx > 0) { const int2 v = ring_in[(step >> 6) % 2 * 64 + (step & 63)]; hl = v.x; fin = v.y; }
+        else { hl = 0; fin = 0; }
+      }
+      int diag = prev_hl;
+      prev_hl = hl;
+      F = fin;
+      if (rowok) {
+        const int jsr = max(bp.q_left, sg.l + row);
+        const int jlr = min(sg.r + 1 + row, bp.q_len);
+        const int wm = rb >= 4 ? 0 : match, wx = rb >= 4 ? 0 : mismatch;
+        uint32_t dw = 0;
+#pragma unroll
+        for (int cc = 0; cc < C; cc++) {
+          const int hold = H[cc];
+          const int j = jb + cc;
+          if (j >= jsr && j < jlr) {
+            const int hin = diag + (qc[cc] >= 4 ? 0 : (qc[cc] == rb ? wm : wx));
+            bool cand;
+            const int d = cell_update(H[cc], E[cc], F, hin, gi, ge, cand);
+            dw |= (uint32_t)d << (2 * cc);
+            if (cand && hin > sbest) { sbest = hin; sbi = row; sbj = j; }
+          } else F = 0;
+          diag = hold;
+        }
+        dirw[sbase + (uint64_t)step * 64 + (uint64_t)g] = dw;
+      } else F = 0;
+      if (sidx + 1 < sg.nstrip) {                    // hand the last column to the next strip
+        if (g == 63 && rowok) ring_out[rel & 127] = make_int2(H[C - 1], F);
+        const int rdone = step - 63;                 // row lane 63 has just finished
+        if (rdone >= 0 && ((rdone & 63) == 63 || rdone == nr - 1)) {
+          __syncthreads();
+          const int base = rdone & ~63, r2 = base + g;
+          if (r2 <= rdone && r2 < nr) bnext[r_lo + r2] = ring_out[r2 & 127];
+        }
+      }
+      if (sidx > 0 && (step & 63) == 63) __syncthreads();   // the read-ahead chunk is in place before lane 0 turns to it
+    }
+#undef SMG_BGET
+    if (sbest > best || (sbest == best && sbest > 0 && (sbi < bi || (sbi == bi && sbj < bj)))) { best = sbest; bi = sbi; bj = sbj; }
+    plo = r_lo; phi = r_hi;
+    sbase += (uint64_t)(nr + 63) * 64;
+    __threadfence();
+  }
+  for (int o = 32; o > 0; o >>= 1) {                 // ties: first cell in row-major order (alignment.c:826-830)
+    const int ob = __shfl_xor(best, o), oi = __shfl_xor(bi, o), oj = __shfl_xor(bj, o);
+    if (ob > best || (ob == best && (oi < bi || (oi == bi && oj < bj)))) { best = ob; bi = oi; bj = oj; }
+  }
+  *max_i = best > 0 ? bp.s_left + bi : 0;
+  *max_j = best > 0 ? bj : 0;
+  return best;
 }
 
 // alignSmiWatBand (alignment.c:788-1027) by the whole wave for bands up to 64 columns wide.
@@ -1087,6 +1227,11 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
         const int64_t tmax = (int64_t)(band.s_len - band.s_left - 1) + (jlast - jmin);
         if (tmax >= 0 && (uint64_t)(tmax + 1) * (uint64_t)w + 8 <= x.dircap) tW = w;
       }
+      StripGeom sg;
+      if (WIDE && !nerr && !skip && dirm == x.dir && band.band_width >= 256 && x.bnd && (uint32_t)(band.s_len - band.s_left) <= x.bndcap) {
+        sg = strip_geom(band);                  // wide band: strip form, 2-bit directions
+        if (sg.nstrip > 0 && strip_words(sg, sg.nstrip) * 4 + 16 <= x.dircap) tW = -1;
+      }
 #endif
       if (!nerr && !skip && !tW && dirm == x.dir && dneed > x.dircap) nerr = x.pass == 1 ? SMG_ERR_RETRY : SMG_ERR_CAP;
       tq0 = phase_clock();
@@ -1096,7 +1241,10 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
         const int nslot = band.band_width >= 1 ? (band.r_edge - band.l_edge) / 128 + 1 : 0;    // live columns per lane
         typedef SMG_LDSQ const uint8_t *PL;
         const bool in_lds = WIDE && x.win_lds && win == x.win_lds;      // read and window both in the LDS block
-        if (band.band_width >= 1 && band.band_width <= 64) {
+        if (WIDE && tW < 0) {
+          if (in_lds) max_scor = band_track_strip<PL>(band, sg, (PL)q, (PL)win, p.match, p.mismatch, gi, ge, (uint32_t *)dirm, (int2 *)x.bnd, x.bndcap, &max_i, &max_j);
+          else max_scor = band_track_strip<const uint8_t *>(band, sg, q, win, p.match, p.mismatch, gi, ge, (uint32_t *)dirm, (int2 *)x.bnd, x.bndcap, &max_i, &max_j);
+        } else if (band.band_width >= 1 && band.band_width <= 64) {
           if (in_lds) max_scor = band_track_wave<PL>(band, (PL)q, (PL)win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j, tW);
           else max_scor = band_track_wave<const uint8_t *>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j, tW);
         } else if (WIDE && nslot >= 1 && nslot <= 2) {
@@ -1127,7 +1275,11 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
         int nsp = sp - 1, err = nerr;
         if (!err && !skip && max_scor >= minscore) {
           int qs, rs;
+          #if defined(__HIP_DEVICE_COMPILE__)
+          const int dn = traceback_scalar(dtmp, dtmpcap, &qs, &rs, band, dirm, max_i, max_j, max_scor, q, win, M, gi, ge, tW, &sg);
+#else
           const int dn = traceback_scalar(dtmp, dtmpcap, &qs, &rs, band, dirm, max_i, max_j, max_scor, q, win, M, gi, ge, tW);
+#endif
           if (dn < 0) err = (dn == -2) ? SMG_ERR_CAP : SMG_ERR_ASSERT;
           const int qe = max_j, re = max_i;
           if (!err && !(qs + minscorlen > qe + 1)) {
