@@ -27,11 +27,12 @@ def main():
     ap.add_argument("--gpu-threads", type=int, default=0, help="worker threads of the bound program (0: same as --threads)")
     ap.add_argument("--nchr", type=int, default=24)
     ap.add_argument("--chr-mbp", type=float, default=125.0)
+    ap.add_argument("--read-len", type=int, default=150)
     a = ap.parse_args()
     import torch
     from smalt_amd import gpuindex, indexfile
     dev = torch.device("cuda", 0)
-    k, s, rlen = 13, 6, 150
+    k, s, rlen = 13, 6, a.read_len
     chrlen = int(a.chr_mbp * 1e6)
     sop = np.arange(a.nchr + 1, dtype=np.int64) * chrlen
     names = ["chr%d" % (i + 1) for i in range(a.nchr)]
@@ -63,7 +64,7 @@ def main():
                 raise SystemExit("%s failed: %s" % (binary, r.stderr.decode()[-1500:]))
             return time.time() - t
         small, cpu_fq, gpu_fq = os.path.join(tmp, "s.fq"), os.path.join(tmp, "c.fq"), os.path.join(tmp, "g.fq")
-        nsmall = 2000
+        nsmall = min(2000, max(10, a.cpu_reads // 10))
         write_fq(small, nsmall)
         write_fq(cpu_fq, a.cpu_reads)
         write_fq(gpu_fq, a.reads)
