@@ -103,6 +103,19 @@ void smaltgpu_index_free(smaltgpu_index *ix);
 int smaltgpu_index_info(const smaltgpu_index *ix, smaltgpu_index_desc *desc_out); /* device pointers */
 void smaltgpu_params_default(smaltgpu_params *p, const smaltgpu_index *ix);
 
+/* ---- index construction (replaces `smalt index`: selectHashTyp smalt.c:268-332, hashTableSetUp
+ * hashidx.c:829-998, seqSetCompress sequence.c:1360-1424, and the writers hashTableWrite hashidx.c:1214-1255 +
+ * seqSetWriteBinFil sequence.c:2448-2519).  `bases`: the reference sequences concatenated, letters as in FASTA (anything
+ * but ACGTU in either case counts as N); `seq_off`: nseq + 1 offsets into it (host memory); `names`: nseq strings.
+ * _build takes host memory, _build_device bases already in HBM.  The image is built entirely on the device and is
+ * ready for smaltgpu_mapper_create; smaltgpu_index_save writes <prefix>.sma / <prefix>.smi byte-compatible with the
+ * reference's files.  build_ms (may be NULL) receives the device time of the construction. ---- */
+int smaltgpu_index_build(smaltgpu_index **out, int device, const uint8_t *bases, const uint64_t *seq_off, const char *const *names,
+                         int64_t nseq, int32_t k, int32_t s, float *build_ms);
+int smaltgpu_index_build_device(smaltgpu_index **out, int device, const uint8_t *d_bases, const uint64_t *seq_off, const char *const *names,
+                                int64_t nseq, int32_t k, int32_t s, float *build_ms);
+int smaltgpu_index_save(const smaltgpu_index *ix, const char *prefix);
+
 /* ---- mapper (replaces rmapCreate rmap.c:1511 / rmapDelete :1597) ---- */
 int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_index *ix, uint32_t max_batch_reads,
                            uint32_t max_read_len);

@@ -74,6 +74,11 @@ def lib():
         L.smaltgpu_index_load.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_int]
         L.smaltgpu_index_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(IndexDesc), C.c_int]
         L.smaltgpu_index_free.argtypes = [C.c_void_p]
+        L.smaltgpu_index_build.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_char_p), C.c_int64,
+                                           C.c_int32, C.c_int32, C.POINTER(C.c_float)]
+        L.smaltgpu_index_build_device.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_char_p), C.c_int64,
+                                                  C.c_int32, C.c_int32, C.POINTER(C.c_float)]
+        L.smaltgpu_index_save.argtypes = [C.c_void_p, C.c_char_p]
         L.smaltgpu_index_info.argtypes = [C.c_void_p, C.POINTER(IndexDesc)]
         L.smaltgpu_params_default.argtypes = [C.POINTER(Params), C.c_void_p]
         L.smaltgpu_mapper_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32, C.c_uint32]
@@ -121,6 +126,42 @@ class Index:
         h = C.c_void_p()
         _check(lib().smaltgpu_index_create(C.byref(h), C.byref(desc), device))
         return cls(h)
+
+    @classmethod
+    def build(cls, seqs: Sequence[bytes], names: Sequence[str], k: int, s: int, device: int = 0) -> "Index":
+        """Build the index image on the device from reference sequences (replaces `smalt index`: hashTableSetUp
+        hashidx.c:829-998 + seqSetCompress sequence.c:1360-1424).  `build_ms` holds the device time."""
+        cat = b"".join(seqs)
+        off = (C.c_uint64 * (len(seqs) + 1))()
+        o = 0
+        for i, q in enumerate(seqs):
+            off[i] = o
+            o += len(q)
+        off[len(seqs)] = o
+        nm = (C.c_char_p * len(seqs))(*[n.encode() for n in names])
+        h = C.c_void_p()
+        ms = C.c_float(0.0)
+        _check(lib().smaltgpu_index_build(C.byref(h), device, cat, off, nm, C.c_int64(len(seqs)), k, s, C.byref(ms)))
+        ix = cls(h)
+        ix.build_ms = float(ms.value)
+        return ix
+
+    @classmethod
+    def build_device(cls, d_bases_ptr: int, seq_off: Sequence[int], names: Sequence[str], k: int, s: int, device: int = 0) -> "Index":
+        """Same from bases already in HBM (`d_bases_ptr`: device address of the concatenated sequences)."""
+        n = len(names)
+        off = (C.c_uint64 * (n + 1))(*[int(x) for x in seq_off])
+        nm = (C.c_char_p * n)(*[x.encode() for x in names])
+        h = C.c_void_p()
+        ms = C.c_float(0.0)
+        _check(lib().smaltgpu_index_build_device(C.byref(h), device, C.c_void_p(d_bases_ptr), off, nm, C.c_int64(n), k, s, C.byref(ms)))
+        ix = cls(h)
+        ix.build_ms = float(ms.value)
+        return ix
+
+    def save(self, prefix: str) -> None:
+        """Write <prefix>.sma / <prefix>.smi, byte-compatible with the reference's index files."""
+        _check(lib().smaltgpu_index_save(self.h, prefix.encode()))
 
     def info(self) -> IndexDesc:
         d = IndexDesc()

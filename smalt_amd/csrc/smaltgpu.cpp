@@ -13,6 +13,7 @@
 #include "../../include/smaltgpu.h"
 #include "smg_dump.hpp"
 #include "smg_indexfile.hpp"
+#include "smg_indexbuild.h"
 #include "smg_kernels.h"
 
 using namespace smg;
@@ -44,6 +45,9 @@ struct smaltgpu_index {
   std::vector<uint64_t> sop;       // host copy
   void *bufs[8] = {nullptr};
   int nbufs = 0;
+  std::vector<std::string> names;  // set by smaltgpu_index_build (what smaltgpu_index_save writes)
+  uint32_t maxpos = 0;
+  bool built = false;
 };
 
 template <class T>
@@ -100,6 +104,88 @@ extern "C" int smaltgpu_index_load(smaltgpu_index **out, const char *prefix, int
   ds.idx = h.idx.data(); ds.pos = h.pos.data(); ds.wordidx = h.wordidx.data(); ds.posidx = h.posidx.data();
   ds.nseq = h.nseq; ds.sop = h.sop.data(); ds.packed = h.packed.data(); ds.on_device = 0;
   return smaltgpu_index_create(out, &ds, device);
+}
+
+// ---- index construction on the device (smg_indexbuild.hip) ----
+extern "C" int smaltgpu_index_build_device(smaltgpu_index **out, int device, const uint8_t *d_bases, const uint64_t *seq_off, const char *const *names,
+                                           int64_t nseq, int32_t k, int32_t s, float *build_ms) {
+  if (!out || !d_bases || !seq_off || !names) return fail(SMALTGPU_EARG, "null argument");
+  if (k < 1 || k > 21 || s < 1 || nseq < 1 || nseq >= (1 << KEY_SEQBITS)) return fail(SMALTGPU_EARG, "unsupported index geometry (k=%d s=%d nseq=%lld)", k, s, (long long)nseq);
+  for (int64_t i = 0; i < nseq; i++) if (seq_off[i + 1] - seq_off[i] > 0x7fffffffull) return fail(SMALTGPU_EARG, "sequence %lld is longer than 2^31-1 bases (hashidx.c:592)", (long long)i);
+  HIPCHK(hipSetDevice(device));
+  BuiltIndex b;
+  char err[256] = "";
+  if (build_index_device(d_bases, seq_off[nseq], seq_off, (int)nseq, k, s, &b, err, sizeof(err))) return fail(SMALTGPU_EARG, "index construction failed: %s", err);
+  smaltgpu_index_desc ds;
+  memset(&ds, 0, sizeof(ds));
+  ds.k = k; ds.s = s; ds.typ = b.typ; ds.nbits_key = b.nbits_key; ds.nbits_lo = b.nbits_lo; ds.npos = b.npos; ds.nwords = b.nwords;
+  ds.idx = b.idx; ds.pos = b.pos; ds.wordidx = b.wordidx; ds.posidx = b.posidx; ds.nseq = nseq; ds.sop = seq_off; ds.packed = b.packed; ds.on_device = 1;
+  smaltgpu_index *ix = nullptr;
+  const int rv = smaltgpu_index_create(&ix, &ds, device);
+  if (rv) { (void)hipFree(b.idx); (void)hipFree(b.pos); (void)hipFree(b.wordidx); (void)hipFree(b.posidx); (void)hipFree(b.packed); return rv; }
+  void *own[5] = {b.idx, b.pos, b.wordidx, b.posidx, b.packed};      // adopted: freed with the index
+  for (void *p : own) if (p && ix->nbufs < 8) ix->bufs[ix->nbufs++] = p;
+  ix->maxpos = b.maxpos; ix->built = true;
+  for (int64_t i = 0; i < nseq; i++) ix->names.emplace_back(names[i] ? names[i] : "");
+  if (build_ms) *build_ms = b.build_ms;
+  *out = ix;
+  return SMALTGPU_OK;
+}
+
+extern "C" int smaltgpu_index_build(smaltgpu_index **out, int device, const uint8_t *bases, const uint64_t *seq_off, const char *const *names,
+                                    int64_t nseq, int32_t k, int32_t s, float *build_ms) {
+  if (!out || !bases || !seq_off || !names || nseq < 1) return fail(SMALTGPU_EARG, "null argument");
+  HIPCHK(hipSetDevice(device));
+  uint8_t *d = nullptr;
+  const uint64_t tot = seq_off[nseq];
+  HIPCHK(hipMalloc((void **)&d, tot ? tot : 1));
+  if (hipMemcpy(d, bases, tot, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return fail(SMALTGPU_ENODEV, "copy of the reference to the device failed"); }
+  const int rv = smaltgpu_index_build_device(out, device, d, seq_off, names, nseq, k, s, build_ms);
+  (void)hipFree(d);
+  return rv;
+}
+
+// seqSetWriteBinFil (sequence.c:2448-2519) + hashTableWrite (hashidx.c:1214-1255) in the container of filio.c:48-77
+extern "C" int smaltgpu_index_save(const smaltgpu_index *ix, const char *prefix) {
+  if (!ix || !prefix) return fail(SMALTGPU_EARG, "null argument");
+  if (!ix->built) return fail(SMALTGPU_EARG, "only an index made by smaltgpu_index_build can be saved");
+  HIPCHK(hipSetDevice(ix->device));
+  const DevIndex &d = ix->d;
+  auto container = [](FILE *fp, uint64_t siz, uint32_t typ, uint32_t version, const uint32_t *h8) {
+    uint32_t f[12] = {0x73212173u, 0x6E378A19u, (uint32_t)(siz + 12), typ, version, 8, 0, 0, 0, 0, 0, 0};
+    return fwrite(f, 4, 12, fp) == 12 && fwrite(h8, 4, 8, fp) == 8;
+  };
+  auto put_dev = [](FILE *fp, const uint32_t *dev, size_t n) {        // device words to the file, 64 MB at a time
+    std::vector<uint32_t> buf(n < (16u << 20) ? n : (16u << 20));
+    for (size_t o = 0; o < n;) {
+      const size_t c = n - o < buf.size() ? n - o : buf.size();
+      if (hipMemcpy(buf.data(), dev + o, c * 4, hipMemcpyDeviceToHost) != hipSuccess || fwrite(buf.data(), 4, c, fp) != c) return false;
+      o += c;
+    }
+    return true;
+  };
+  std::string nm;
+  for (const std::string &x : ix->names) { nm += x; nm.push_back('\0'); }
+  const uint64_t namsiz = nm.size(), nseq = (uint64_t)d.nseq, seqsiz = d.totlen / 10 + 1;
+  uint32_t h[8] = {(uint32_t)nseq, (uint32_t)(nseq >> 32), (uint32_t)namsiz, (uint32_t)(namsiz >> 32), (uint32_t)d.totlen, (uint32_t)(d.totlen >> 32), 2u /* compressed */, 0};
+  FILE *fp = fopen((std::string(prefix) + ".sma").c_str(), "wb");
+  if (!fp) return fail(SMALTGPU_EFILE, "cannot write %s.sma", prefix);
+  std::vector<uint32_t> seqlen((size_t)nseq);
+  for (uint64_t i = 0; i < nseq; i++) seqlen[(size_t)i] = (uint32_t)(ix->sop[(size_t)i + 1] - ix->sop[(size_t)i]);
+  bool ok = container(fp, 8 + seqsiz + nseq + ((namsiz - 1) / 4 + 1), 1, 4, h) && fwrite(nm.data(), 1, namsiz, fp) == namsiz &&
+            fwrite(seqlen.data(), 4, (size_t)nseq, fp) == (size_t)nseq && put_dev(fp, d.packed, (size_t)seqsiz);
+  ok = (fclose(fp) == 0) && ok;
+  if (!ok) return fail(SMALTGPU_EFILE, "short write to %s.sma", prefix);
+  uint32_t g[8] = {(uint32_t)d.k, (uint32_t)d.s, d.npos, ix->maxpos, (uint32_t)d.typ, (uint32_t)d.nbits_key, (uint32_t)d.nbits_lo, d.nwords};
+  uint64_t totsiz = (uint64_t)d.npos + d.nkeys + 1;
+  if (d.typ != IDX_PERFECT) totsiz += ((uint64_t)d.nwords + 1) * 2;
+  fp = fopen((std::string(prefix) + ".smi").c_str(), "wb");
+  if (!fp) return fail(SMALTGPU_EFILE, "cannot write %s.smi", prefix);
+  ok = container(fp, totsiz, 2, 3, g) && put_dev(fp, d.idx, (size_t)d.nkeys + 1) && put_dev(fp, d.pos, d.npos);
+  if (ok && d.typ != IDX_PERFECT) ok = put_dev(fp, d.wordidx, (size_t)d.nwords + 1) && put_dev(fp, d.posidx, (size_t)d.nwords + 1);
+  ok = (fclose(fp) == 0) && ok;
+  if (!ok) return fail(SMALTGPU_EFILE, "short write to %s.smi", prefix);
+  return SMALTGPU_OK;
 }
 
 extern "C" void smaltgpu_index_free(smaltgpu_index *ix) {
