@@ -234,6 +234,7 @@ struct smaltgpu_mapper {
   uint8_t *d_counters = nullptr;            // rc_count | res_count | dstr_count | err_flag | work[8]
   uint8_t *seed_scr = nullptr; size_t seed_bytes = 0; uint32_t seed_slots = 0;
   uint8_t *cand_scr = nullptr; size_t cand_bytes = 0; uint32_t cand_slots = 0;
+  CandGeom cg2; uint8_t *cand_scr2 = nullptr; size_t cand_bytes2 = 0; uint32_t cand_slots2 = 0;   // second pass of the candidate stage: full-size slots
   CandGeom cg;
   uint8_t *cand_scr_dbg = nullptr; uint32_t cand_dbg_reads = 0;
   int *sw_rows = nullptr; uint32_t sw_rowlen = 0, sw_threads = 0;
@@ -340,6 +341,21 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
     if (m->cg.lds_hits > 2048) m->cg.lds_hits = 2048;
     m->cg.tab = m->qmax + 8 < (uint32_t)CANDS_TAB ? m->qmax + 8 : (uint32_t)CANDS_TAB;    // a read has fewer seeds than bases
     m->cg.slot_bytes = m->cand_bytes = cand_slot_bytes(m->cg, m->qmax, d.s);
+    memset(&m->cg2, 0, sizeof(m->cg2));
+    if (m->cand_bytes > (64ull << 20)) {
+      // Long reads: the worst case (4 x the reference's hit-list allocation per strand, every hit a candidate of its own)
+      // is gigabytes per slot.  The slots of the first pass hold 24 hits per read base and strand; a read that
+      // overflows one is deferred to a second launch over a few worst-case slots.
+      m->cg2 = m->cg; m->cg2.pass = 2; m->cand_bytes2 = m->cand_bytes;
+      uint32_t hs = next_pow2((uint64_t)24 * m->qmax);
+      if (const char *e = getenv("SMALTGPU_CANDS_HCAP")) { const long v = atol(e); if (v >= 1024) hs = next_pow2((uint64_t)v); }   // test hook
+      if (hs < m->cg.hcap_strand) {
+        m->cg.hcap_strand = hs; m->cg.hcap = 2 * hs; m->cg.segcap = hs; m->cg.candcap = 2 * hs; m->cg.pass = 1;
+        m->cg.slot_bytes = m->cand_bytes = cand_slot_bytes(m->cg, m->qmax, d.s);
+        m->cand_slots2 = max_batch_reads < 8 ? max_batch_reads : 8;
+        DA(m->cand_scr2, m->cand_bytes2 * m->cand_slots2);
+      } else { memset(&m->cg2, 0, sizeof(m->cg2)); m->cand_bytes2 = 0; }
+    }
     uint64_t budget = 64ull << 30;     // of 288 GB: more slots than resident workgroups lets the hardware balance uneven reads
     if (const char *e = getenv("SMALTGPU_SLOT_BUDGET_GB")) { const long g = atol(e); if (g > 0) budget = (uint64_t)g << 30; }   // many mappers on one device
     uint64_t slots = budget / m->cand_bytes;
@@ -392,7 +408,7 @@ extern "C" void smaltgpu_mapper_free(smaltgpu_mapper *m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   void *ps[] = {m->d_bases, m->d_quals, m->d_codes, m->d_codes_rc, m->d_off, m->b.hi, m->b.seeds, m->b.qmask, m->b.ch, m->b.ctl,
-                m->b.stat, m->b.rcpool, m->b.long_list, m->b.strip_list, m->strip_bnd, m->strip_win, m->b.respool, m->b.dstrpool, m->d_counters, m->seed_scr, m->cand_scr, m->cand_scr_dbg,
+                m->b.stat, m->b.rcpool, m->b.long_list, m->b.strip_list, m->strip_bnd, m->strip_win, m->b.respool, m->b.dstrpool, m->d_counters, m->seed_scr, m->cand_scr, m->cand_scr2, m->cand_scr_dbg,
                 m->sw_rows, m->align_scr, m->align_scr2};
   for (void *p : ps) if (p) (void)hipFree(p);
   for (int i = 0; i <= T_NUM; i++) if (m->ev[i]) (void)hipEventDestroy(m->ev[i]);
@@ -440,12 +456,15 @@ static int run_pipeline(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_
   uint8_t *cscr = m->cand_scr;
   uint32_t cslots = m->cand_slots;
   int slot_per_read = 0;
+  CandGeom cgeom = m->cg;
+  const bool two_pass = m->cand_scr2 != nullptr && !m->debug;
+  const size_t cbytes_dbg = m->cand_bytes;      // debug batches (dumps read the slot of every read): one pass over first-pass-sized slots
   if (m->debug) {
     if (n > 2048) return fail(SMALTGPU_EARG, "debug batches are limited to 2048 reads");
     if (m->cand_dbg_reads < n) {
       if (m->cand_scr_dbg) (void)hipFree(m->cand_scr_dbg);
       m->cand_scr_dbg = nullptr;
-      HIPCHK(hipMalloc((void **)&m->cand_scr_dbg, m->cand_bytes * n));
+      HIPCHK(hipMalloc((void **)&m->cand_scr_dbg, cbytes_dbg * n));
       m->cand_dbg_reads = n;
     }
     cscr = m->cand_scr_dbg; cslots = n; slot_per_read = 1;
@@ -455,7 +474,8 @@ static int run_pipeline(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_
   HIPCHK(hipEventRecord(m->ev[T_SEED], s));
   if (!rv) rv = launch_seed(s, b, d, p, m->seed_scr, m->seed_bytes, m->seed_slots);
   HIPCHK(hipEventRecord(m->ev[T_CANDS], s));
-  { CandGeom g = m->cg; g.ngrp = ngrp; g.debug = slot_per_read; if (!rv) rv = launch_cands(s, b, d, p, cscr, cslots, g); }
+  { CandGeom g = cgeom; g.ngrp = ngrp; g.debug = slot_per_read; if (!two_pass) g.pass = 0; if (!rv) rv = launch_cands(s, b, d, p, cscr, cslots, g); }
+  if (two_pass) { CandGeom g = m->cg2; g.ngrp = ngrp; g.debug = 0; g.pass = 2; if (!rv) rv = launch_cands(s, b, d, p, m->cand_scr2, m->cand_slots2, g); }
   HIPCHK(hipEventRecord(m->ev[T_SW_FULL], s));
   if (!rv) rv = launch_sw_full(s, b, d, p, m->max_len, b.rccap, 8192);
   HIPCHK(hipEventRecord(m->ev[T_SW_SCALAR], s));

@@ -429,6 +429,7 @@ struct CandsV2Scratch {
   FillDecision *dec; uint32_t ngrp;
   uint64_t *dbg_words; uint32_t *dbg_first, *dbg_cnt;   // debug: packed hit words grouped as the dump expects (or null)
   LongWork lw;                           // reads of 256 bases and more
+  int pass;                              // 1: first of two passes -- a read that overflows this slot is deferred (SMG_ERR_RETRY)
 };
 
 SMG_HD inline size_t cands_v2_hbm_bytes(uint32_t qmax, int s, uint32_t hcap_strand, uint32_t ngrp, uint32_t candcap, bool debug) {
@@ -456,6 +457,7 @@ SMG_HD inline CandsV2Scratch cands_v2_carve(uint8_t *lds, size_t lds_bytes, uint
     x.dbg_first = (uint32_t *)b; b += (size_t)ngrp * 2 * 4;
     x.dbg_cnt = (uint32_t *)b;
   } else { x.dbg_words = nullptr; x.dbg_first = x.dbg_cnt = nullptr; }
+  x.pass = 0;
   x.lw.ccov = x.lw.mlist = x.lw.mask = nullptr;
   if (qmax > 255) {
     b = (uint8_t *)(((uintptr_t)b + 15) & ~(uintptr_t)15);
@@ -942,6 +944,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     if (LONG) wave_sort_kv<32, WSORT_LISTCAP, WSORT_LSTK, uint64_t>(kv64, (int)nmin, (int)nrank, wk);
     else wave_sort_kv(kv, (int)nmin, (int)nrank, wk);    // sort.c:233 tie order
   }
+  if (x.pass == 1 && err == SMG_ERR_CAP) err = SMG_ERR_RETRY;      // slot capacity: the second pass has full-size slots
   SMG_LANE0 {
     ch.ncand = ncand; ch.n_sort = nrank; ch.n_mincover = nmin; ch.max_cover = max_cover; ch.max2nd_cover = max2nd;
     ch.err = err;

@@ -18,6 +18,7 @@ struct CandGeom {              // scratch geometry of the candidate stage (both 
   int debug;                   // keep per-read slots + the grouped hit words for smaltgpu_dump_read
   uint32_t window;             // test hook: hits per LDS window of the candidate stage (0 = default)
   uint32_t lds_hits, tab;      // LDS block of the candidate stage: hits of the working set, per-list table entries
+  int pass;                    // 0: only pass; 1: first of two (a read that overflows its slot is deferred); 2: second pass over full-size slots
 };
 inline size_t cand_slot_bytes(const CandGeom &g, uint32_t qmax, int s) {
   size_t a = cand_scratch_bytes(qmax, s, g.hcap, g.ngrp, g.segcap, g.candcap);

@@ -69,12 +69,16 @@ __global__ void __launch_bounds__(64) k_cands(Batch b, DevIndex ix, MapPar p, ui
   unsigned long long nhit = 0;
   unsigned long long ph[16] = {0};
   __shared__ uint32_t qslot;
-  for (uint32_t r = next_item(b.next_item + 1, &qslot); r < b.nreads; r = next_item(b.next_item + 1, &qslot)) {
+  uint32_t *cursor = b.next_item + (g.pass == 2 ? 4 : 1);
+  for (uint32_t r = next_item(cursor, &qslot); r < b.nreads; r = next_item(cursor, &qslot)) {
+    if (g.pass == 2 && b.ch[r].err != SMG_ERR_RETRY) continue;       // wave-uniform: the first pass finished this read
     uint8_t *base = gscratch + g.slot_bytes * (g.debug ? r : blockIdx.x);
     if (cands_v2_applicable(p, ix.k, ix.s, read_len(b, r))) {
       CandsV2Scratch x = cands_v2_carve(lds + LDS_GUARD, lds_bytes, base, b.qmax, ix.s, g.hcap_strand, g.ngrp, g.candcap, g.debug != 0);
-      x.window = g.window; x.lds_hits = g.lds_hits; x.tab = g.tab;
+      x.window = g.window; x.lds_hits = g.lds_hits; x.tab = g.tab; x.pass = g.pass;
       nhit += stage_cands_v2<LONGK>(b, ix, p, r, x, ph);
+    } else if (g.pass == 1) {                                        // the sequential form waits for the full-size slots
+      if (threadIdx.x == 0) { CandHdr &ch = b.ch[r]; ch.ncand = ch.n_sort = ch.n_mincover = ch.n_reserved = 0; ch.rc_off = 0; ch.err = SMG_ERR_RETRY; }
     } else {
       CandScratch x = cand_scratch_carve(base, b.qmax, ix.s, g.hcap, g.ngrp, g.segcap, g.candcap);
       nhit += stage_cands(b, ix, p, r, x);

@@ -155,15 +155,18 @@ def test_candidate_pool_overflow_is_reported_per_read(oracle_built, tmp_path, mo
         gix.close()
 
 
-@pytest.mark.parametrize("k,s,nreads,dircap", [(20, 13, 14, 0), (13, 6, 40, 0), (13, 6, 40, 65536)], ids=["k20s13", "k13s6", "k13s6-deferred"])
+@pytest.mark.parametrize("k,s,nreads,dircap", [(20, 13, 14, 0), (13, 6, 40, 0), (13, 6, 40, 65536), (13, 6, 40, -4096)],
+                         ids=["k20s13", "k13s6", "k13s6-deferred-k3", "k13s6-deferred-cands"])
 def test_long_reads_match_oracle(k, s, nreads, dircap, oracle_built, tmp_path, monkeypatch):
     """BASELINE configs[4] shape in small: reads of 0.3-3 kbp with 3/5/4 % substitutions/insertions/deletions (every
     fifth read an exact copy: narrow bands, K2b), k=20 s=13 (HASH32MIX with nbits_perf) and k=13 s=6 (many more hits):
     wave-parallel candidate stage for long reads, strip K2a kernel, wide-band K3 in two passes (small direction-matrix slots
     for all reads, full-size slots for the reads a band of which does not fit)."""
     from smalt_amd import api, synth
-    if dircap:      # first-pass direction matrices of 64 KB: most reads are deferred to the second K3 pass (full-size slots)
+    if dircap > 0:  # first-pass direction matrices of 64 KB: most reads are deferred to the second K3 pass (full-size slots)
         monkeypatch.setenv("SMALTGPU_ALIGN_DIRCAP", str(dircap))
+    if dircap < 0:  # first-pass candidate slots of 4096 hits per strand: most reads are deferred to the second candidate pass
+        monkeypatch.setenv("SMALTGPU_CANDS_HCAP", str(-dircap))
     ch = synth.make_reference(3, 700_000, seed=51, repeat_frac=0.1, n_fam=3, cons_len=400, divergence=0.05)
     rng = np.random.default_rng(52)
     seqs = [synth.codes_to_ascii(c) for c in ch]
