@@ -110,6 +110,8 @@ __global__ void __launch_bounds__(64) k_align(Batch b, DevIndex ix, MapPar p, ui
   uint8_t *base = gscratch + gbytes * blockIdx.x;
   AlignScratch x = align_scratch_carve_lds(lds_bytes ? lds + LDS_GUARD : nullptr, lds_bytes, base, b.qmax, wincap, dircap, rescap, dstrcap);
   x.pass = pass;
+  __shared__ int2 strip_ring[WIDE ? 256 : 1];
+  x.ring = WIDE ? (void *)strip_ring : nullptr;
   __shared__ uint32_t qslot;
   uint32_t *cursor = b.next_item + (pass == 2 ? 3 : 2);
   for (uint32_t r = next_item(cursor, &qslot); r < b.nreads; r = next_item(cursor, &qslot)) {

@@ -701,6 +701,7 @@ struct AlignScratch {
   uint8_t *qcodes; uint32_t qstride;   // [2][qstride] the read in both orientations
   uint8_t *win_lds, *dtmp_lds; uint32_t win_lds_cap;   // LDS copies for windows of ordinary length (else the HBM arrays)
   int pass;                   // 0: only pass; 1: first of two (a band that does not fit defers the read); 2: second (deferred reads only)
+  void *ring;                 // LDS [256] (H, F) pairs of band_track_strip (set by k_align<true>)
   void *bnd; uint32_t bndcap; // [2 * bndcap] (H, F) pairs: hand-over between the strips of band_track_strip (long reads only)
 };
 
@@ -723,7 +724,7 @@ SMG_HD inline AlignScratch align_scratch_carve(uint8_t *base, uint32_t qmax, uin
   x.dtmpcap = qmax + wincap + 16;
   x.dtmp = base; base += x.dtmpcap;
   x.dstr = base; base += dstrcap; x.dstrcap = dstrcap;
-  x.bnd = nullptr; x.bndcap = 0;
+  x.bnd = nullptr; x.bndcap = 0; x.ring = nullptr;
   if (qmax > 256) { base = (uint8_t *)(((uintptr_t)base + 15) & ~(uintptr_t)15); x.bnd = (void *)base; x.bndcap = wincap; base += (size_t)wincap * 16; }
   base = (uint8_t *)(((uintptr_t)base + 15) & ~(uintptr_t)15);
   x.dir = base; x.dircap = dircap;
@@ -798,18 +799,20 @@ SMG_HD inline int band_track_scalar(const Band &bp, const uint8_t *q, const uint
 // js(r) = max(q_left, l_edge + r) and jl(r) = min(r_edge + 1 + r, q_len); strip s sweeps the rows [r_lo, r_hi) in which
 // it has visited cells.  Directions take 2 bits: a lane packs its 16 cells of a row into one word and the wave
 // writes word (t, g) of the strip at step t -- 256 contiguous bytes per step.
-struct StripGeom { int j0, l, r, nrows, nstrip; };
-SMG_HD inline StripGeom strip_geom(const Band &bp) {
+struct StripGeom { int j0, l, r, nrows, nstrip, cbits; };   // cbits: log2 of the columns per lane (3 or 4)
+SMG_HD inline StripGeom strip_geom(const Band &bp, int cbits) {
   StripGeom sg;
+  sg.cbits = cbits;
+  const int cw = 64 << cbits;                  // columns per strip
   const int jmin = bp.q_left > bp.l_edge ? bp.q_left : bp.l_edge;
   sg.l = bp.l_edge; sg.r = bp.r_edge; sg.nrows = bp.s_len - bp.s_left;
   int jmax = bp.r_edge + sg.nrows; if (jmax > bp.q_len) jmax = bp.q_len;      // one past the last column visited
-  sg.j0 = jmin & ~15;
-  sg.nstrip = (sg.nrows > 0 && jmax > sg.j0) ? (jmax - sg.j0 + 1023) / 1024 : 0;
+  sg.j0 = jmin & ~((1 << cbits) - 1);
+  sg.nstrip = (sg.nrows > 0 && jmax > sg.j0) ? (jmax - sg.j0 + cw - 1) / cw : 0;
   return sg;
 }
 SMG_HD inline void strip_rows(const StripGeom &sg, int sidx, int *r_lo, int *r_hi) {
-  const int c_lo = sg.j0 + sidx * 1024, c_hi = c_lo + 1024;
+  const int c_lo = sg.j0 + sidx * (64 << sg.cbits), c_hi = c_lo + (64 << sg.cbits);
   int lo = c_lo - sg.r; if (lo < 0) lo = 0;
   int hi = c_hi - sg.l; if (hi > sg.nrows) hi = sg.nrows;
   *r_lo = lo; *r_hi = hi;
@@ -821,7 +824,7 @@ SMG_HD inline uint64_t strip_words(const StripGeom &sg, int upto) {          // 
 }
 // direction of cell (ip, j); cache: {strip, its first word, its first row} of the previous call
 SMG_HD inline int strip_dir(const StripGeom &sg, const uint32_t *dirw, int ip, int j, int *cache_sidx, uint64_t *cache_base, int *cache_rlo) {
-  const int o = j - sg.j0, sidx = o >> 10, g = (o >> 4) & 63, cc = o & 15;
+  const int o = j - sg.j0, sidx = o >> (6 + sg.cbits), g = (o >> sg.cbits) & 63, cc = o & ((1 << sg.cbits) - 1);
   if (sidx != *cache_sidx) { int hi; *cache_sidx = sidx; *cache_base = strip_words(sg, sidx); strip_rows(sg, sidx, cache_rlo, &hi); }
   const uint32_t w = dirw[*cache_base + (uint64_t)(ip - *cache_rlo + g) * 64 + (uint64_t)g];
   return (int)((w >> (2 * cc)) & 3u);
@@ -904,11 +907,9 @@ __device__ inline int wave_ror1(int v) {      // value of lane-1 (lane 0 takes l
 // alignSmiWatBand (alignment.c:788-1027) in strip form; bnd: 2 x wcap (H, F) pairs in HBM for the hand-over between
 // strips (as sw_strip_core, smg_kernels.hip).  Cells outside the band keep H and E and pass F = 0: what a visited cell
 // reads from an unvisited neighbour is then what the reference's row buffers hold (see band_fast_wave).
-template <class PW>
+template <class PW, int C>
 __device__ inline int band_track_strip(const Band &bp, const StripGeom &sg, PW q, PW win, int match, int mismatch, int gi, int ge,
-                                       uint32_t *dirw, int2 *bnd, uint32_t wcap, int *max_i, int *max_j) {
-  constexpr int C = 16;
-  __shared__ int2 ring[256];
+                                       uint32_t *dirw, int2 *bnd, uint32_t wcap, int2 *ring /* LDS [256] */, int *max_i, int *max_j) {
   const int g = (int)threadIdx.x;
   int2 *ring_in = ring, *ring_out = ring + 128;
   int best = 0, bi = 0, bj = 0, plo = 0, phi = 0;
@@ -920,7 +921,7 @@ __device__ inline int band_track_strip(const Band &bp, const StripGeom &sg, PW q
     if (nr <= 0) continue;
     const int2 *bprev = bnd + (size_t)((sidx + 1) & 1) * wcap;
     int2 *bnext = bnd + (size_t)(sidx & 1) * wcap;
-    const int jb = sg.j0 + sidx * 1024 + g * C;
+    const int jb = sg.j0 + sidx * (64 * C) + g * C;
     int qc[C];
 #pragma unroll
     for (int cc = 0; cc < C; cc++) qc[cc] = (jb + cc >= 0 && jb + cc < bp.q_len) ? (int)(q[jb + cc] & 7) : 5;
@@ -1228,8 +1229,8 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
         if (tmax >= 0 && (uint64_t)(tmax + 1) * (uint64_t)w + 8 <= x.dircap) tW = w;
       }
       StripGeom sg;
-      if (WIDE && !nerr && !skip && dirm == x.dir && band.band_width >= 256 && x.bnd && (uint32_t)(band.s_len - band.s_left) <= x.bndcap) {
-        sg = strip_geom(band);                  // wide band: strip form, 2-bit directions
+      if (WIDE && !nerr && !skip && dirm == x.dir && band.band_width >= 256 && x.bnd && x.ring && (uint32_t)(band.s_len - band.s_left) <= x.bndcap) {
+        sg = strip_geom(band, band.band_width < 2048 ? 3 : 4);      // wide band: strip form, 2-bit directions; narrower strips fit the band better
         if (sg.nstrip > 0 && strip_words(sg, sg.nstrip) * 4 + 16 <= x.dircap) tW = -1;
       }
 #endif
@@ -1242,8 +1243,13 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
         typedef SMG_LDSQ const uint8_t *PL;
         const bool in_lds = WIDE && x.win_lds && win == x.win_lds;      // read and window both in the LDS block
         if (WIDE && tW < 0) {
-          if (in_lds) max_scor = band_track_strip<PL>(band, sg, (PL)q, (PL)win, p.match, p.mismatch, gi, ge, (uint32_t *)dirm, (int2 *)x.bnd, x.bndcap, &max_i, &max_j);
-          else max_scor = band_track_strip<const uint8_t *>(band, sg, q, win, p.match, p.mismatch, gi, ge, (uint32_t *)dirm, (int2 *)x.bnd, x.bndcap, &max_i, &max_j);
+          if (sg.cbits == 3) {
+            if (in_lds) max_scor = band_track_strip<PL, 8>(band, sg, (PL)q, (PL)win, p.match, p.mismatch, gi, ge, (uint32_t *)dirm, (int2 *)x.bnd, x.bndcap, (int2 *)x.ring, &max_i, &max_j);
+            else max_scor = band_track_strip<const uint8_t *, 8>(band, sg, q, win, p.match, p.mismatch, gi, ge, (uint32_t *)dirm, (int2 *)x.bnd, x.bndcap, (int2 *)x.ring, &max_i, &max_j);
+          } else {
+            if (in_lds) max_scor = band_track_strip<PL, 16>(band, sg, (PL)q, (PL)win, p.match, p.mismatch, gi, ge, (uint32_t *)dirm, (int2 *)x.bnd, x.bndcap, (int2 *)x.ring, &max_i, &max_j);
+            else max_scor = band_track_strip<const uint8_t *, 16>(band, sg, q, win, p.match, p.mismatch, gi, ge, (uint32_t *)dirm, (int2 *)x.bnd, x.bndcap, (int2 *)x.ring, &max_i, &max_j);
+          }
         } else if (band.band_width >= 1 && band.band_width <= 64) {
           if (in_lds) max_scor = band_track_wave<PL>(band, (PL)q, (PL)win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j, tW);
           else max_scor = band_track_wave<const uint8_t *>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j, tW);
