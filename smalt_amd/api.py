@@ -206,11 +206,15 @@ class Mapper:
         off[n] = t
         return b"".join(reads), (b"".join(quals) if quals is not None else None), off
 
-    def map_batch(self, reads: Sequence[bytes], quals: Optional[Sequence[bytes]], params: Params):
-        """-> (list per read of result dicts in the reference's raw order, list of stat dicts)."""
+    def map_batch(self, reads: Sequence[bytes], quals: Optional[Sequence[bytes]], params: Params, allow_read_errors: bool = False):
+        """-> (list per read of result dicts in the reference's raw order, list of stat dicts).
+        allow_read_errors: do not raise when single reads failed (device-side limit or the reference's own per-read
+        errors such as ERRCODE_SWATSCOR); their stat carries `err` and they have no results."""
         bases, q, off = self._pack(reads, quals)
         out = BatchOut()
-        _check(lib().smaltgpu_map_batch(self.h, bases, q, off, len(reads), C.byref(params), C.byref(out)))
+        rv = lib().smaltgpu_map_batch(self.h, bases, q, off, len(reads), C.byref(params), C.byref(out))
+        if rv != 0 and not (allow_read_errors and rv in (-5, -6) and out.nreads == len(reads)):
+            _check(rv)
         return self._unpack(out)
 
     def map_batch_raw(self, bases, off, quals, params: Params) -> BatchOut:
