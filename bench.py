@@ -49,7 +49,7 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(args, ref_pack, idx, pos, sop, names, k, s, reads_ascii, nreads, rlen):
+def cpu_baseline(args, ref_pack, idx, pos, sop, names, k, s, reads_ascii, nreads, rlen, gix=None):
     """Time the UNMODIFIED reference (`oracle/_ref/smalt map -n T`) on a bounded sample of the same
     reads against the same index (kind "reference"); falls back to the oracle port."""
     smalt = os.path.join(ROOT, "oracle", "_ref", "smalt")
@@ -64,8 +64,11 @@ def cpu_baseline(args, ref_pack, idx, pos, sop, names, k, s, reads_ascii, nreads
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
         prefix = os.path.join(tmp, "bench")
         tot = int(sop[-1])
-        indexfile.write_sma(prefix, names, sop, ref_pack)
-        indexfile.write_smi_perfect(prefix, k, s, idx, pos, (tot + s - 1) // s - 1)
+        if idx is None:
+            gix.save(prefix)                       # index built by the library: its own writer
+        else:
+            indexfile.write_sma(prefix, names, sop, ref_pack)
+            indexfile.write_smi_perfect(prefix, k, s, idx, pos, (tot + s - 1) // s - 1)
         rd = reads_ascii[: n2 * rlen].reshape(n2, rlen)
 
         def write_fq(path, n):
@@ -137,14 +140,28 @@ def main():
     # ---- setup (untimed): reference + index image in HBM; rank 0 builds, RCCL broadcast ----
     t0 = time.time()
     image = {}
+    # small references (4^k > 2 * bases / s) get the collision-type index: every rank builds it from the broadcast
+    # reference with the library's own builder (smaltgpu_index_build_device); the default 3 Gbp reference gets the perfect
+    # type and its image is broadcast as a whole
+    native_build = 4 ** k > 2 * (tot // s)
     if rank == 0:
         ref = gpuindex.make_reference_gpu(nchr, chrlen, 20261004, dev)
-        packed = gpuindex.pack_reference(ref)
-        idx, pos = gpuindex.build_perfect_index(ref, sop, k, s)
-        image = {"idx": idx, "pos": pos, "packed": packed, "ref": ref}
-    image, bcast_s = shard.broadcast_image(image, dev, 0, order=("idx", "pos", "packed", "ref"))     # RCCL over xGMI for N > 1
-    idx, pos, packed, ref = image["idx"], image["pos"], image["packed"], image["ref"]
+        if native_build:
+            image = {"ref": ref}
+        else:
+            packed = gpuindex.pack_reference(ref)
+            idx, pos = gpuindex.build_perfect_index(ref, sop, k, s)
+            image = {"idx": idx, "pos": pos, "packed": packed, "ref": ref}
+    image, bcast_s = shard.broadcast_image(image, dev, 0, order=("ref",) if native_build else ("idx", "pos", "packed", "ref"))     # RCCL over xGMI for N > 1
+    ref = image["ref"]
+    idx, pos, packed = (None, None, None) if native_build else (image["idx"], image["pos"], image["packed"])
     bcast_ms = bcast_s * 1e3
+    gix = None
+    if native_build:
+        lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+        ascii_ref = lut[ref.long()]
+        gix = api.Index.build_device(ascii_ref.data_ptr(), [int(x) for x in sop], names, k, s, local)
+        del ascii_ref
     # reads of this rank (weak scaling: every rank maps args.reads reads of its own)
     torch.cuda.synchronize()
     t_idx = time.time() - t0
@@ -155,16 +172,17 @@ def main():
     if rank == 0:
         print("[bench] setup: reference+index %.1f s, reads %.1f s" % (t_idx, setup_s - t_idx), file=sys.stderr, flush=True)
 
-    desc = api.IndexDesc()
-    desc.k, desc.s, desc.typ, desc.nbits_key, desc.nbits_lo = k, s, 0, 2 * k, 0
-    desc.npos, desc.nwords = int(pos.numel()), 0
-    desc.idx, desc.pos, desc.packed = idx.data_ptr(), pos.data_ptr(), packed.data_ptr()
-    desc.wordidx = desc.posidx = None
-    desc.nseq = nchr
-    sop_u64 = np.ascontiguousarray(sop.astype(np.uint64))
-    desc.sop = sop_u64.ctypes.data
-    desc.on_device = 1
-    gix = api.Index.from_desc(desc, local)
+    if gix is None:
+        desc = api.IndexDesc()
+        desc.k, desc.s, desc.typ, desc.nbits_key, desc.nbits_lo = k, s, 0, 2 * k, 0
+        desc.npos, desc.nwords = int(pos.numel()), 0
+        desc.idx, desc.pos, desc.packed = idx.data_ptr(), pos.data_ptr(), packed.data_ptr()
+        desc.wordidx = desc.posidx = None
+        desc.nseq = nchr
+        sop_u64 = np.ascontiguousarray(sop.astype(np.uint64))
+        desc.sop = sop_u64.ctypes.data
+        desc.on_device = 1
+        gix = api.Index.from_desc(desc, local)
     par = gix.default_params()
     sub = min(args.sub_batch, args.reads)
     os.environ.setdefault("SMALTGPU_CANDS_PER_READ", "768")
@@ -279,8 +297,9 @@ def main():
             line["host_buffers"] = {"reads_per_s": sub / (time.time() - th), "reads": sub, "note": "PCIe-inclusive, not `value`"}
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
             try:
-                line["cpu_baseline"] = cpu_baseline(args, packed.cpu().numpy(), idx.cpu().numpy(), pos.cpu().numpy(), sop, names, k, s,
-                                                    reads_ascii.cpu().numpy(), args.reads, args.read_len)
+                line["cpu_baseline"] = cpu_baseline(args, None if native_build else packed.cpu().numpy(), None if native_build else idx.cpu().numpy(),
+                                                    None if native_build else pos.cpu().numpy(), sop, names, k, s,
+                                                    reads_ascii.cpu().numpy(), args.reads, args.read_len, gix)
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 line["cpu_baseline"] = dict(value=None, unit="mapped reads/s", cores=0, kind="reference", sample="failed: %r" % (e,))
         print(json.dumps(line))
