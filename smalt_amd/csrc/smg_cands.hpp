@@ -163,7 +163,15 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
   if (!n) return 0;
   unsigned long long t0 = phase_clock(), t1;
 #define SMG_PH(i) { t1 = phase_clock(); ph[i] += t1 - t0; t0 = t1; }
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (StrandWork<IT>::L && n <= 1024) {          // LDS working set: keys sorted in registers
+    if (n <= 256) wave_sort_u64_reg<4>(w.dat, n);
+    else if (n <= 512) wave_sort_u64_reg<8>(w.dat, n);
+    else wave_sort_u64_reg<16>(w.dat, n);
+  } else wave_sort_u64(w.dat, n);
+#else
   wave_sort_u64(w.dat, n);
+#endif
   SMG_SYNC();
   SMG_PH(2)
   uint32_t max_dshift = (uint32_t)(k * SEGMENTING_DIFFSHIFT / s) & 0xffffu;     // segment.c:426-429

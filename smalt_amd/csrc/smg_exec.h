@@ -167,4 +167,60 @@ SMG_HD inline void wave_sort_u64(P a, uint32_t n) {
 #endif
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// The same network with the keys in registers, for arrays of at most 64 * E keys in LDS.  Lane l holds the logical
+// elements E * l .. E * l + E - 1 (which unsorted key starts where is free, so the load is coalesced); comparators
+// whose span stays below E are compare-exchanges between a lane's own registers, the others pair register r of a lane
+// with register r (mirror step: E - 1 - r) of the lane at distance span / E and keep the smaller or the larger key
+// by side.  34 of the 55 steps of a 1024-key sort touch neither LDS nor another lane.
+__device__ inline uint64_t shfl_xor_u64(uint64_t v, int mask) {
+  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask);
+  return ((uint64_t)hi << 32) | lo;
+}
+template <int E, class P>
+__device__ inline void wave_sort_u64_reg(P a, uint32_t n) {
+  if (n < 2) return;
+  const uint32_t lane = threadIdx.x;
+  uint64_t v[E];
+#pragma unroll
+  for (int r = 0; r < E; r++) { const uint32_t idx = (uint32_t)r * 64u + lane; v[r] = idx < n ? a[idx] : ~0ull; }
+#pragma unroll
+  for (int k = 2; k <= 64 * E; k <<= 1) {              // the whole network: the coalesced load spreads the keys over all lanes
+    if (k <= E) {                                      // mirror step inside the lane
+#pragma unroll
+      for (int r = 0; r < E; r++) {
+        const int q = r ^ (k - 1);
+        if (r < q) { const uint64_t x = v[r], y = v[q]; const bool sw = x > y; v[r] = sw ? y : x; v[q] = sw ? x : y; }
+      }
+    } else {                                           // mirror step across lanes
+      const int m = k / E - 1;
+      const bool lower = (lane & (uint32_t)(k / (2 * E))) == 0;
+      uint64_t pv[E];
+#pragma unroll
+      for (int r = 0; r < E; r++) pv[r] = shfl_xor_u64(v[E - 1 - r], m);
+#pragma unroll
+      for (int r = 0; r < E; r++) { const bool take = lower ? (pv[r] < v[r]) : (pv[r] > v[r]); v[r] = take ? pv[r] : v[r]; }
+    }
+#pragma unroll
+    for (int j = k / 4; j >= 1; j >>= 1) {
+      if (j < E) {
+#pragma unroll
+        for (int r = 0; r < E; r++) {
+          if (!(r & j)) { const uint64_t x = v[r], y = v[r | j]; const bool sw = x > y; v[r] = sw ? y : x; v[r | j] = sw ? x : y; }
+        }
+      } else {
+        const int m = j / E;
+        const bool lower = (lane & (uint32_t)m) == 0;
+#pragma unroll
+        for (int r = 0; r < E; r++) { const uint64_t o = shfl_xor_u64(v[r], m); const bool take = lower ? (o < v[r]) : (o > v[r]); v[r] = take ? o : v[r]; }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < E; r++) { const uint32_t i = (uint32_t)E * lane + (uint32_t)r; if (i < n) a[i] = v[r]; }
+  __syncthreads();
+}
+#endif
+
 }  // namespace smg
