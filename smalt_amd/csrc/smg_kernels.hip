@@ -69,6 +69,14 @@ __global__ void __launch_bounds__(64) k_cands(Batch b, DevIndex ix, MapPar p, ui
   unsigned long long nhit = 0;
   unsigned long long ph[16] = {0};
   __shared__ uint32_t qslot;
+  // the first k-mer serial of every sequence goes to LDS (behind the working set): each hit looks its sequence up
+  // there (a binary search = five reads) instead of in global memory
+  if (lds_bytes && ix.nseq > 0 && ix.nseq < 512) {
+    uint32_t *sl = (uint32_t *)(lds + LDS_GUARD + lds_bytes);
+    for (int i = (int)threadIdx.x; i <= ix.nseq; i += 64) sl[i] = ix.seqlo[i];
+    ix.seqlo = sl;
+    __syncthreads();
+  }
   uint32_t *cursor = b.next_item + (g.pass == 2 ? 4 : 1);
   for (uint32_t r = next_item(cursor, &qslot); r < b.nreads; r = next_item(cursor, &qslot)) {
     if (g.pass == 2 && b.ch[r].err != SMG_ERR_RETRY) continue;       // wave-uniform: the first pass finished this read
@@ -1027,8 +1035,9 @@ int launch_cands(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar
   if (!b.nreads) return 0;
   uint32_t grid = b.nreads < nslots ? b.nreads : nslots;
   const uint32_t lds_bytes = (uint32_t)(((strand_work_bytes<uint16_t>(g.lds_hits) + 15) & ~(size_t)15) + (size_t)5 * g.tab * 4);
-  if (b.qmax > 255) hipLaunchKernelGGL(k_cands<true>, dim3(grid), dim3(64), lds_bytes + LDS_GUARD, s, b, ix, p, scratch, g, lds_bytes);
-  else hipLaunchKernelGGL(k_cands<false>, dim3(grid), dim3(64), lds_bytes + LDS_GUARD, s, b, ix, p, scratch, g, lds_bytes);
+  const size_t seq_bytes = (ix.nseq > 0 && ix.nseq < 512) ? (((size_t)ix.nseq + 1) * 4 + 15) & ~(size_t)15 : 0;     // LDS copy of seqlo
+  if (b.qmax > 255) hipLaunchKernelGGL(k_cands<true>, dim3(grid), dim3(64), lds_bytes + LDS_GUARD + seq_bytes, s, b, ix, p, scratch, g, lds_bytes);
+  else hipLaunchKernelGGL(k_cands<false>, dim3(grid), dim3(64), lds_bytes + LDS_GUARD + seq_bytes, s, b, ix, p, scratch, g, lds_bytes);
   SMG_LAUNCH_CHECK();
   return 0;
 }
