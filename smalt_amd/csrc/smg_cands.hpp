@@ -683,12 +683,23 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
               const uint32_t t = (uint32_t)(((uint64_t)room * rem) / remaining) + 1;
               uint32_t lo = 0, hi = t < rem ? t : rem;       // first offset whose key is not below the bound
               const uint32_t *pp = ix.pos + g_poff[l] + cur;
-              const uint32_t qo = g_qo[l];
+              // Along one list the key grows with the position, so the bound turns into a position once per list:
+              // key(pos) < bound  <=>  pos < plim (the diagonal bound shifted by the list's read offset, clamped to
+              // the bound's sequence).
+              const int64_t qs = (int64_t)(g_qo[l] / (uint32_t)s);
+              const uint64_t db = bound & ((1ull << KEY_DIAGBITS) - 1ull);
+              int64_t plim = st != 0 ? (int64_t)db - qs : (int64_t)db - (int64_t)(1ull << 32) + qs;
+              if (seqbyseq) {
+                const uint32_t sb = (uint32_t)(bound >> KEY_DIAGBITS);
+                if (sb >= (uint32_t)ix.nseq) plim = (int64_t)1 << 33;                 // no bound: every position is below it
+                else {
+                  const int64_t slo = (int64_t)ix.seqlo[sb], shi = sb + 1 < (uint32_t)ix.nseq ? (int64_t)ix.seqlo[sb + 1] : ((int64_t)1 << 33);
+                  plim = plim < slo ? slo : (plim > shi ? shi : plim);
+                }
+              } else if (bound == ~0ull) plim = (int64_t)1 << 33;
               while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1, pos = pp[mid];
-                uint64_t kh = hit_diag(st != 0, pos, qo, s);
-                if (seqbyseq) kh |= (uint64_t)seq_of_pos(ix.seqlo, ix.nseq, pos) << KEY_DIAGBITS;
-                if (kh < bound) lo = mid + 1; else hi = mid;
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((int64_t)pp[mid] < plim) lo = mid + 1; else hi = mid;
               }
               cnt = lo;
             }
