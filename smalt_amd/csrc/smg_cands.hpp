@@ -650,6 +650,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
       SMG_PAR_CHUNKS(base, nlist) { const uint32_t l = base + SMG_LANE; if (l < nlist) g_cur[l] = 0; }
       SMG_SYNC();
       uint32_t carry = 0, remaining = total, reg_base = 0, gproc = 0, last_grp = ~0u;
+      uint64_t prev_bound = 0;
       int rv = 0;
       while (remaining > 0 || carry > 0) {
         if (carry + nlist + 64 > W) { rv = SMG_WINDOW_FALLBACK; break; }
@@ -718,6 +719,10 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
         SMG_SYNC();
         const unsigned long long tb0 = phase_clock();
         if (carry + cnt_tot > W || (cnt_tot == 0 && remaining > 0)) { rv = SMG_ERR_ASSERT; break; }
+        const uint32_t sq_lo = seqbyseq ? (uint32_t)(prev_bound >> KEY_DIAGBITS) : 0u;
+        uint32_t sq_hi = seqbyseq ? (uint32_t)(bound >> KEY_DIAGBITS) : 0u;
+        if (sq_hi >= (uint32_t)ix.nseq) sq_hi = (uint32_t)ix.nseq - 1;
+        prev_bound = bound;
         for (uint32_t base = 0; base < cnt_tot; base += 4 * SMG_NLANES) {      // four independent index reads in flight per lane
           uint32_t pos[4], qo[4];
 #pragma unroll
@@ -734,7 +739,11 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
             const uint32_t h = base + (uint32_t)u * SMG_NLANES + SMG_LANE;
             if (h < cnt_tot) {
               uint64_t key = (hit_diag(st != 0, pos[u], qo[u], s) << KEY_QBITS) | qo[u];
-              if (seqbyseq) key |= (uint64_t)seq_of_pos(ix.seqlo, ix.nseq, pos[u]) << (KEY_DIAGBITS + KEY_QBITS);
+              if (seqbyseq) {                      // the window's keys lie between the previous bound and this one: so do their sequences
+                uint32_t lo = sq_lo, hi = sq_hi + 1;
+                while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (ix.seqlo[m] <= pos[u]) lo = m; else hi = m; }
+                key |= (uint64_t)lo << (KEY_DIAGBITS + KEY_QBITS);
+              }
               wl.dat[carry + h] = key;
             }
           }
