@@ -190,14 +190,31 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
   }
   const uint32_t reg_base = *reg_base_io;
 
-  // hits -> seeds
-  uint32_t nseed = 0;
+  // hits -> seeds, seeds -> constant-shift segments (makeSegmentsFromSeeds, segment.c:558-580), segments -> hit regions in
+  // one sweep over the hits.  All three boundaries are predicates on two neighbouring sorted hits: a seed ends at a
+  // region boundary, a change of diagonal, a gap of more than k bases or a change of the offset's residue modulo s; a
+  // segment ends where a seed ends for any reason but the gap (all hits of a seed share diagonal and residue, so the
+  // reference's comparison with the previous seed's first hit is a comparison with the previous hit); a region ends
+  // at a region boundary.
+  uint32_t nseed = 0, nsegm = 0, nreg = 0;
   SMG_PAR_CHUNKS(base, n) {
     const uint32_t i = base + SMG_LANE;
-    bool sb = false;
-    if (i < n) sb = (i == 0) || region_break(w.dat[i - 1], w.dat[i], dsthresh) || seed_break(w.dat[i - 1], w.dat[i], k, s);
-    const uint32_t slot = compact_slot(sb, nseed);
-    if (sb) w.seed_first[slot] = (IT)i;
+    bool sb = false, gb = false, rb = false;
+    if (i < n) {
+      if (i == 0) sb = gb = rb = true;
+      else {
+        const uint64_t ka = w.dat[i - 1], kb = w.dat[i];
+        rb = region_break(ka, kb, dsthresh);
+        gb = rb || key_diag(ka) != key_diag(kb) || ((key_q(kb) - key_q(ka)) % (uint32_t)s) != 0;
+        sb = gb || key_q(kb) > key_q(ka) + (uint32_t)k;
+      }
+    }
+    const uint32_t sslot = compact_slot(sb, nseed);
+    const uint32_t gslot = compact_slot(gb, nsegm);
+    const uint32_t rslot = compact_slot(rb, nreg);
+    if (sb) w.seed_first[sslot] = (IT)i;
+    if (gb) w.segm_first[gslot] = (IT)sslot;
+    if (rb) w.reg_first[rslot] = (IT)gslot;
   }
   SMG_SYNC();
   SMG_PAR_CHUNKS(base, nseed) {
@@ -206,22 +223,6 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
       const uint32_t last = (j + 1 < nseed ? (uint32_t)w.seed_first[j + 1] : n) - 1;
       w.seed_len[j] = (IT)(key_q(w.dat[last]) + (uint32_t)k - key_q(w.dat[w.seed_first[j]]));
     }
-  }
-  // seeds -> constant-shift segments (makeSegmentsFromSeeds, segment.c:558-580)
-  uint32_t nsegm = 0;
-  SMG_PAR_CHUNKS(base, nseed) {
-    const uint32_t j = base + SMG_LANE;
-    bool gb = false;
-    if (j < nseed) {
-      if (j == 0) gb = true;
-      else {
-        const uint32_t a = w.seed_first[j], ap = w.seed_first[j - 1];
-        const uint64_t ka = w.dat[a], kp = w.dat[ap];
-        gb = region_break(w.dat[a - 1], ka, dsthresh) || key_diag(ka) != key_diag(kp) || ((key_q(ka) - key_q(kp)) % (uint32_t)s) != 0;
-      }
-    }
-    const uint32_t slot = compact_slot(gb, nsegm);
-    if (gb) w.segm_first[slot] = (IT)j;
   }
   SMG_SYNC();
   SMG_PAR_CHUNKS(base, nsegm) {
@@ -234,18 +235,6 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
       w.segm_cover[m] = (IT)cov;
       w.cflag[m] = 0;
     }
-  }
-  // segments -> hit regions
-  uint32_t nreg = 0;
-  SMG_PAR_CHUNKS(base, nsegm) {
-    const uint32_t m = base + SMG_LANE;
-    bool rb = false;
-    if (m < nsegm) {
-      const uint32_t a = w.seed_first[w.segm_first[m]];
-      rb = (a == 0) || region_break(w.dat[a - 1], w.dat[a], dsthresh);
-    }
-    const uint32_t slot = compact_slot(rb, nreg);
-    if (rb) w.reg_first[slot] = (IT)m;
   }
   SMG_SYNC();
   SMG_PH(3)
