@@ -139,7 +139,12 @@ SMG_HD inline int derive_cand_c(SegCand &c, const StrandWork<IT> &w, uint32_t m0
 // registers.  Regions of one segment (nearly all of them) need no mask; the others are taken one after the other by
 // the whole wave, segment by segment as the reference does, the seeds of a segment spread over the lanes and the
 // mask (one bit per read base) in memory.  lw: covers per first segment, list of multi-segment regions, mask words.
-struct LongWork { uint32_t *ccov, *mlist, *mask; };
+struct LongWork {
+  uint32_t *ccov, *mlist, *mask;
+  // Early drop of candidates the cover filter of S6 can never keep: its threshold only grows with the largest and second
+  // largest cover seen so far, and its allowance is at most the cover deficit of strand [0] (prune_cdf0).
+  int prune_on; uint32_t prune_mcbm, prune_cdf0;
+};
 
 // bits [q, q + len) of a mask in memory; returns how many were clear (addCandsFast's cover_new, segment.c:1185-1200)
 SMG_HD inline uint32_t mask_add_mem(uint32_t *mask, uint32_t q, uint32_t len) {
@@ -326,9 +331,12 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
   // candidates in segment order: one lane per candidate derives the record (derriveSEGCAND) and writes it once
   uint32_t nc = *ncand_io;
   bool ovf = false;
+  uint32_t pthr = 0;                             // lower bound of the final cover threshold (segment.c:1700-1730)
+  if (lw.prune_on) { pthr = lw.prune_mcbm > mx ? 0 : mx - lw.prune_mcbm; if (pthr > mx2) pthr = mx2; }
   SMG_PAR_CHUNKS(base, nsegm) {
     const uint32_t m = base + SMG_LANE;
-    const bool f = m < nsegm && w.cflag[m];
+    bool f = m < nsegm && w.cflag[m];
+    if (f && lw.prune_on && (LONG ? lw.ccov[m] : (uint32_t)w.cflag[m]) + lw.prune_cdf0 < pthr) f = false;
     const uint32_t slot = compact_slot(f, nc);
     if (f) {
       uint32_t lo = 0, hi = nreg;                // hit region of segment m
@@ -456,6 +464,7 @@ SMG_HD inline CandsV2Scratch cands_v2_carve(uint8_t *lds, size_t lds_bytes, uint
   } else { x.dbg_words = nullptr; x.dbg_first = x.dbg_cnt = nullptr; }
   x.pass = 0;
   x.lw.ccov = x.lw.mlist = x.lw.mask = nullptr;
+  x.lw.prune_on = 0; x.lw.prune_mcbm = x.lw.prune_cdf0 = 0;
   if (qmax > 255) {
     b = (uint8_t *)(((uintptr_t)b + 15) & ~(uintptr_t)15);
     if (debug) b += (size_t)ngrp * 2 * 4;
@@ -578,6 +587,13 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
       }
     }
     SMG_SYNC();
+    if (st == 0 && !x.dbg_first) {           // strand [0]'s read-offset flags are final now: its cover deficit bounds the S6 allowance
+      uint32_t *cw = (LONG || !x.lds) ? (uint32_t *)x.hbm : (uint32_t *)x.lds;
+      const uint32_t nwq0 = LONG ? (qlen + 31) >> 5 : 8u;
+      x.lw.prune_cdf0 = wave_cover_deficit(hdr, seeds, qmask, qlen, k, s, cw, nwq0);
+      x.lw.prune_mcbm = mincov_below_max;
+      x.lw.prune_on = 1;
+    }
     SMG_PH(0)
     // ---- working set --------------------------------------------------------------------------
     //  mode 0: the whole strand fits the LDS working set
