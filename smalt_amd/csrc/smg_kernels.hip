@@ -276,18 +276,19 @@ __device__ inline Sw16Par sw16_par(const MapPar &p) {
   return s;
 }
 
-// wrow: per-row code pairs (low byte task A, high byte task B) of this lane group, nrow valid rows
+// wrow: per-row code pairs (code of task A | code of task B << 3) of this lane group, entry r + G - 1 = row r; the
+// entries before row 0 and from the last row up to nstep + G - 1 hold the N pair, so the sweep reads without bounds checks.
+// rowtab2[pair]: the biased ACGT score rows of both codes (one 8-byte LDS read per row).
 template <int G, int C>
-__device__ inline uint32_t sw16_core(const uint16_t *wrow, int nrow, int nstep, const uint32_t (&sel)[C], int g, const Sw16Par &sp, const uint32_t *rowtab) {
+__device__ inline uint32_t sw16_core(const uint16_t *wrow, int nstep, const uint32_t (&sel)[C], int g, const Sw16Par &sp, const uint2 *rowtab2) {
   us2 H[C], E[C];
 #pragma unroll
   for (int cc = 0; cc < C; cc++) { H[cc] = us2{0, 0}; E[cc] = us2{0, 0}; }
   us2 best = us2{0, 0}, F = us2{0, 0}, prev_hl = us2{0, 0};
   const uint32_t gmask = g == 0 ? 0u : 0xffffffffu;       // the first lane of a group has no left neighbour
   for (int step = 0; step < nstep; step++) {
-    const int row = step - g;
-    const uint32_t rp = (row >= 0 && row < nrow) ? wrow[row] : 0x0505u;
-    const uint32_t rowA = rowtab[rp & 0xffu], rowB = rowtab[rp >> 8];     // ACGT scores (+ bias) against this reference base
+    const uint2 rr = rowtab2[wrow[step - g + (G - 1)]];
+    const uint32_t rowA = rr.x, rowB = rr.y;                              // ACGT scores (+ bias) against this reference base
     const uint32_t hl = shr1_u32(as_u32(H[C - 1])) & gmask;
     const uint32_t fin = shr1_u32(as_u32(F)) & gmask;
     us2 carry = prev_hl;                       // H[row-1] of the column left of the block
@@ -332,6 +333,12 @@ __device__ inline uint32_t sw16_core(const uint16_t *wrow, int nrow, int nstep, 
 __device__ inline void sw16_rowtab(uint32_t *rowtab, const Sw16Par &sp) {
   if (threadIdx.x < 8) rowtab[threadIdx.x] = threadIdx.x < 4 ? sp.mm4 + (sp.dlt << (8 * threadIdx.x)) : sp.n4;
 }
+// the same for a pair of codes: entry a | b << 3
+__device__ inline void sw16_rowtab2(uint2 *rowtab2, const Sw16Par &sp) {
+  const uint32_t a = threadIdx.x & 7u, bq = threadIdx.x >> 3;
+  rowtab2[threadIdx.x] = make_uint2(a < 4 ? sp.mm4 + (sp.dlt << (8 * a)) : sp.n4, bq < 4 ? sp.mm4 + (sp.dlt << (8 * bq)) : sp.n4);
+}
+enum : uint32_t { SW16_NPAIR = 5u | (5u << 3) };
 
 template <int G, int C, int WMAX>
 __global__ void __launch_bounds__(64) k_sw_full16(Batch b, DevIndex ix, MapPar p, uint32_t ntask_cap) {
@@ -341,12 +348,12 @@ __global__ void __launch_bounds__(64) k_sw_full16(Batch b, DevIndex ix, MapPar p
   if (WMAX > SW_SHORT_WMAX && nlong == 0) return;
   const uint32_t *list = (WMAX > SW_SHORT_WMAX && b.long_list && nlong <= b.long_cap) ? b.long_list : nullptr;
   constexpr int NG = 64 / G;
-  __shared__ uint16_t win[NG][WMAX + 8];
-  __shared__ uint32_t rowtab[8];
+  __shared__ uint16_t win[NG][WMAX + 2 * G];
+  __shared__ uint2 rowtab2[64];
   const int lane = threadIdx.x, g = lane % G, grp = lane / G;
   const uint32_t ntask = list ? (uint32_t)nlong : min(*b.rc_count, ntask_cap), npair = (ntask + 1) / 2;
   const Sw16Par sp = sw16_par(p);
-  sw16_rowtab(rowtab, sp);
+  sw16_rowtab2(rowtab2, sp);
   const uint32_t ngroups = gridDim.x * NG;
   unsigned long long cells = 0, ntasks_done = 0;
   for (uint32_t t0 = blockIdx.x * NG; t0 < npair; t0 += ngroups) {
@@ -371,9 +378,12 @@ __global__ void __launch_bounds__(64) k_sw_full16(Batch b, DevIndex ix, MapPar p
       if (!live[u]) { qlen[u] = 0; wlen[u] = 0; }
     }
     const uint32_t wmax = wlen[0] > wlen[1] ? wlen[0] : wlen[1];
-    for (uint32_t i = g; i < wmax; i += G) {
+    int nstep = (int)wmax + G - 1;
+    for (int o = 32; o > 0; o >>= 1) nstep = max(nstep, __shfl_xor(nstep, o));
+    for (uint32_t e = g; e < (uint32_t)(nstep + G - 1); e += G) {        // entry e = row e - (G - 1); N pairs around the window
+      const uint32_t i = e - (uint32_t)(G - 1);                           // (wraps for the leading pad: fails both tests below)
       const uint32_t a = i < wlen[0] ? ref_code(ix.packed, gbase[0] + i) : 5u, bb = i < wlen[1] ? ref_code(ix.packed, gbase[1] + i) : 5u;
-      win[grp][i] = (uint16_t)(a | (bb << 8));
+      win[grp][e] = (uint16_t)(a | (bb << 3));
     }
     uint32_t sel[C];
 #pragma unroll
@@ -382,10 +392,8 @@ __global__ void __launch_bounds__(64) k_sw_full16(Batch b, DevIndex ix, MapPar p
       const uint32_t sa = j < qlen[0] ? (uint32_t)q[0][j] : 0x0cu, sb = j < qlen[1] ? 4u + (uint32_t)q[1][j] : 0x0cu;
       sel[cc] = 0x0c000c00u | sa | (sb << 16);
     }
-    int nstep = (int)wmax + G - 1;
-    for (int o = 32; o > 0; o >>= 1) nstep = max(nstep, __shfl_xor(nstep, o));
     __syncthreads();
-    const uint32_t bb = sw16_core<G, C>(win[grp], (int)wmax, nstep, sel, g, sp, rowtab);
+    const uint32_t bb = sw16_core<G, C>(win[grp], nstep, sel, g, sp, rowtab2);
     if (g == 0) {
 #pragma unroll
       for (int u = 0; u < 2; u++) {
@@ -411,12 +419,12 @@ __global__ void __launch_bounds__(64) k_sw_full16_raw(const uint8_t *qcodes, con
                                                        const uint32_t *r_off, uint32_t ntask, MapPar p, int32_t *scores) {
   constexpr int NG = 64 / G;
   constexpr int WMAX = SW_FULL_WMAX;
-  __shared__ uint16_t win[NG][WMAX + 8];
-  __shared__ uint32_t rowtab[8];
+  __shared__ uint16_t win[NG][WMAX + 2 * G];
+  __shared__ uint2 rowtab2[64];
   const int lane = threadIdx.x, g = lane % G, grp = lane / G;
   const uint32_t npair = (ntask + 1) / 2;
   const Sw16Par sp = sw16_par(p);
-  sw16_rowtab(rowtab, sp);
+  sw16_rowtab2(rowtab2, sp);
   const uint32_t ngroups = gridDim.x * NG;
   for (uint32_t t0 = blockIdx.x * NG; t0 < npair; t0 += ngroups) {
     const uint32_t tp = t0 + grp;
@@ -434,11 +442,14 @@ __global__ void __launch_bounds__(64) k_sw_full16_raw(const uint8_t *qcodes, con
       if (!live[u]) { qlen[u] = 0; wlen[u] = 0; }
     }
     const uint32_t wmax = wlen[0] > wlen[1] ? wlen[0] : wlen[1];
-    for (uint32_t i = g; i < wmax; i += G) {
+    int nstep = (int)wmax + G - 1;
+    for (int o = 32; o > 0; o >>= 1) nstep = max(nstep, __shfl_xor(nstep, o));
+    for (uint32_t e = g; e < (uint32_t)(nstep + G - 1); e += G) {
+      const uint32_t i = e - (uint32_t)(G - 1);
       uint32_t cd[2];
 #pragma unroll
       for (int u = 0; u < 2; u++) { const uint32_t x = i < wlen[u] ? (r[u][i] & 7u) : 5u; cd[u] = x == 7 ? 0 : ((x == 6 || x == 4) ? 5 : x); }
-      win[grp][i] = (uint16_t)(cd[0] | (cd[1] << 8));
+      win[grp][e] = (uint16_t)(cd[0] | (cd[1] << 3));
     }
     uint32_t sel[C];
     bool qn[2] = {false, false};
@@ -456,10 +467,8 @@ __global__ void __launch_bounds__(64) k_sw_full16_raw(const uint8_t *qcodes, con
     }
 #pragma unroll
     for (int u = 0; u < 2; u++) for (int o = G / 2; o > 0; o >>= 1) { const int other = __shfl_xor((int)qn[u], o); qn[u] = qn[u] || other != 0; }
-    int nstep = (int)wmax + G - 1;
-    for (int o = 32; o > 0; o >>= 1) nstep = max(nstep, __shfl_xor(nstep, o));
     __syncthreads();
-    const uint32_t bb = sw16_core<G, C>(win[grp], (int)wmax, nstep, sel, g, sp, rowtab);
+    const uint32_t bb = sw16_core<G, C>(win[grp], nstep, sel, g, sp, rowtab2);
     if (g == 0) {
 #pragma unroll
       for (int u = 0; u < 2; u++) {
