@@ -380,6 +380,7 @@ __global__ void __launch_bounds__(64) k_sw_full16(Batch b, DevIndex ix, MapPar p
     const uint32_t wmax = wlen[0] > wlen[1] ? wlen[0] : wlen[1];
     int nstep = (int)wmax + G - 1;
     for (int o = 32; o > 0; o >>= 1) nstep = max(nstep, __shfl_xor(nstep, o));
+    nstep = __builtin_amdgcn_readfirstlane(nstep);                         // wave-uniform: a scalar loop bound for the sweep
     for (uint32_t e = g; e < (uint32_t)(nstep + G - 1); e += G) {        // entry e = row e - (G - 1); N pairs around the window
       const uint32_t i = e - (uint32_t)(G - 1);                           // (wraps for the leading pad: fails both tests below)
       const uint32_t a = i < wlen[0] ? ref_code(ix.packed, gbase[0] + i) : 5u, bb = i < wlen[1] ? ref_code(ix.packed, gbase[1] + i) : 5u;
@@ -444,6 +445,7 @@ __global__ void __launch_bounds__(64) k_sw_full16_raw(const uint8_t *qcodes, con
     const uint32_t wmax = wlen[0] > wlen[1] ? wlen[0] : wlen[1];
     int nstep = (int)wmax + G - 1;
     for (int o = 32; o > 0; o >>= 1) nstep = max(nstep, __shfl_xor(nstep, o));
+    nstep = __builtin_amdgcn_readfirstlane(nstep);                         // wave-uniform: a scalar loop bound for the sweep
     for (uint32_t e = g; e < (uint32_t)(nstep + G - 1); e += G) {
       const uint32_t i = e - (uint32_t)(G - 1);
       uint32_t cd[2];
