@@ -263,6 +263,15 @@ __device__ inline us2 pk_subs(us2 a, us2 b) { return __builtin_elementwise_sub_s
 // sum of two packed pairs whose halves cannot overflow (score + biased substitution score < 65536, checked by the
 // launcher): one full-rate 32-bit add instead of a packed add at half the issue rate
 __device__ inline us2 pk_add_nc(us2 a, us2 b) { return as_us2(as_u32(a) + as_u32(b)); }
+// Packed maximum of three: gfx950's v_pk_maximum3_f16 on the u16 bit patterns.  Non-negative half floats order like
+// their bit patterns (denormals are kept in the default mode), and the values here stay far below 0x7C00 (infinity):
+// scores of reads up to 512 bases with match <= 15 plus the bias.  Checked bit for bit against the integer maximum
+// on 10^6 random triples including the denormal range.
+typedef _Float16 hf2 __attribute__((ext_vector_type(2)));
+__device__ inline us2 pk_max3(us2 a, us2 b, us2 c) {
+  const hf2 r = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_bit_cast(hf2, a), __builtin_bit_cast(hf2, b)), __builtin_bit_cast(hf2, c));
+  return __builtin_bit_cast(us2, r);
+}
 __device__ inline uint32_t shr1_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, true); }
 
 enum : int { SW16_BLK = 5 };
@@ -309,20 +318,25 @@ __device__ inline uint32_t sw16_core(const uint16_t *wrow, int nstep, const uint
         if (cc < C) {
           const us2 w = as_us2(__builtin_amdgcn_perm(rowB, rowA, sel[cc]));
           const us2 dg = u == 0 ? carry : H[cc - 1];
-          t3[u] = pk_max(pk_subs(pk_add_nc(dg, w), sp.bias), E[cc]);
+          t3[u] = pk_subs(pk_add_nc(dg, w), sp.bias);
         }
       }
 #pragma unroll
       for (int u = 0; u < SW16_BLK; u++) {
         const int cc = c0 + u;
         if (cc < C) {
-          const us2 hh = pk_max(t3[u], F);
-          best = pk_max(best, hh);
+          const us2 hh = pk_max3(t3[u], E[cc], F);
           H[cc] = hh;
           const us2 tt = pk_subs(hh, sp.gi);
           E[cc] = pk_max(pk_subs(E[cc], sp.ge), tt);
           F = pk_max(pk_subs(F, sp.ge), tt);
         }
+      }
+#pragma unroll
+      for (int u = 0; u < SW16_BLK; u += 2) {            // the running maximum takes the block's cells two at a time
+        const int cc = c0 + u;
+        if (cc + 1 < C && u + 1 < SW16_BLK) best = pk_max3(best, H[cc], H[cc + 1]);
+        else if (cc < C) best = pk_max(best, H[cc]);
       }
       carry = last_old;
     }
@@ -1092,7 +1106,7 @@ int sw_full_geometry(uint32_t qmax_len, int *G, int *C) {
 // the packed kernel's 16-bit lanes hold any score of a read of up to 512 bases
 static bool sw16_ok(const MapPar &p) {
   const int bias = (p.mismatch < p.mismatch - p.match ? -p.mismatch : -(p.mismatch - p.match));
-  return p.match > 0 && p.match * 512 + bias < 60000 && bias >= 0 && p.match + bias < 256 && p.mismatch + bias >= 0 &&
+  return p.match > 0 && p.match * 512 + bias + 256 < 0x7C00 /* pk_max3 */ && bias >= 0 && p.match + bias < 256 && p.mismatch + bias >= 0 &&
          -p.gap_init >= 0 && -p.gap_init < 30000 && -p.gap_ext >= 0 && -p.gap_ext < 30000;
 }
 
