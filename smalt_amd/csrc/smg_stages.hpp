@@ -837,7 +837,7 @@ SMG_HD inline int strip_dir(const StripGeom &sg, const uint32_t *dirw, int ip, i
 SMG_HD inline size_t dir_index(const Band &bp, int tW, int ip, int j) {
   if (!tW) return (size_t)ip * (size_t)(bp.band_width - 1) + (size_t)(j - bp.l_edge);
   const int jmin = bp.q_left > bp.l_edge ? bp.q_left : bp.l_edge;
-  return (size_t)(ip + (j - jmin)) * (size_t)tW + (size_t)((j - jmin) % tW);
+  return (size_t)(ip + (j - jmin)) * (size_t)tW + (size_t)((j - jmin) & (tW - 1));     // tW: a power of two
 }
 
 SMG_HD inline int traceback_scalar(uint8_t *ds, uint32_t dscap, int *qs, int *rs, const Band &bp, const uint8_t *dir,
@@ -1013,7 +1013,8 @@ __device__ inline int band_track_wave(const Band &bp, PW q, PW win, int match, i
   const int nrows = bp.s_len - bp.s_left, l = bp.l_edge, r = bp.r_edge, bw = bp.band_width;
   const int jmin = bp.q_left > l ? bp.q_left : l;
   int jlast = r + nrows - 1; if (jlast > bp.q_len - 1) jlast = bp.q_len - 1;
-  const int tmax = (nrows - 1) + (jlast - jmin);
+  const int tmax = __builtin_amdgcn_readfirstlane((nrows - 1) + (jlast - jmin));      // wave-uniform: scalar loop bound
+  const int tWm = tW - 1;                                                              // tW is a power of two
   int Hcol = 0, Ecol = 0, Hprev = 0, Fout = 0, lastrow = -2, lastcol = -1, qc = 5;
   int best = 0, bi = 0, bj = 0;
   for (int t = 0; t <= tmax; t++) {
@@ -1038,7 +1039,7 @@ __device__ inline int band_track_wave(const Band &bp, PW q, PW win, int match, i
       const int hb = Hcol;
       const int d = cell_update(Hnew, Ecol, F, Hin, gi, ge, cand);
       Hprev = hb; Hcol = Hnew; Fout = F; lastrow = ip; lastcol = j;
-      dir[tW ? (size_t)t * (size_t)tW + (size_t)((j - jmin) % tW) : (size_t)ip * (size_t)(bw - 1) + (size_t)(j - l)] = (uint8_t)d;
+      dir[tW ? (size_t)t * (size_t)tW + (size_t)((j - jmin) & tWm) : (size_t)ip * (size_t)(bw - 1) + (size_t)(j - l)] = (uint8_t)d;
       if (cand && Hin > best) { best = Hin; bi = ip; bj = j; }
     }
   }
@@ -1061,7 +1062,8 @@ __device__ inline int band_track_wave_n(const Band &bp, PW q, PW win, int match,
   const int nrows = bp.s_len - bp.s_left, l = bp.l_edge, r = bp.r_edge, bw = bp.band_width;
   const int jmin = bp.q_left > l ? bp.q_left : l;
   int jlast = r + nrows - 1; if (jlast > bp.q_len - 1) jlast = bp.q_len - 1;
-  const int tmax = (nrows - 1) + (jlast - jmin);
+  const int tmax = __builtin_amdgcn_readfirstlane((nrows - 1) + (jlast - jmin));      // wave-uniform: scalar loop bound
+  const int tWm = tW - 1;                                                              // tW is a power of two
   int Hcol[NS], Ecol[NS], Hprev[NS], Fout[NS], lastrow[NS], lastcol[NS], qc[NS];
 #pragma unroll
   for (int s = 0; s < NS; s++) { Hcol[s] = Ecol[s] = Hprev[s] = Fout[s] = 0; lastrow[s] = -2; lastcol[s] = -1; qc[s] = 5; }
@@ -1105,7 +1107,7 @@ __device__ inline int band_track_wave_n(const Band &bp, PW q, PW win, int match,
         const int hb = Hcol[s];
         const int d = cell_update(Hnew, Ecol[s], F, Hin, gi, ge, cand);
         Hprev[s] = hb; Hcol[s] = Hnew; Fout[s] = F; lastrow[s] = ip; lastcol[s] = j;
-        dir[tW ? (size_t)t * (size_t)tW + (size_t)((j - jmin) % tW) : (size_t)ip * (size_t)(bw - 1) + (size_t)(j - l)] = (uint8_t)d;
+        dir[tW ? (size_t)t * (size_t)tW + (size_t)((j - jmin) & tWm) : (size_t)ip * (size_t)(bw - 1) + (size_t)(j - l)] = (uint8_t)d;
         if (cand && (Hin > best || (Hin == best && (ip < bi || (ip == bi && j < bj))))) { best = Hin; bi = ip; bj = j; }
       }
     }
@@ -1224,7 +1226,8 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
         // direction matrix in HBM and a wave form: anti-diagonal-major layout (dir_index) if it fits
         const int jmin = band.q_left > band.l_edge ? band.q_left : band.l_edge;
         int jlast = band.r_edge + (band.s_len - band.s_left) - 1; if (jlast > band.q_len - 1) jlast = band.q_len - 1;
-        const int w = ((band.band_width / 2 + 2 + 63) / 64) * 64;
+        int w = 64;                              // power of two >= band_width / 2 + 2 (the live columns of one step)
+        while (w < band.band_width / 2 + 2) w <<= 1;
         const int64_t tmax = (int64_t)(band.s_len - band.s_left - 1) + (jlast - jmin);
         if (tmax >= 0 && (uint64_t)(tmax + 1) * (uint64_t)w + 8 <= x.dircap) tW = w;
       }
