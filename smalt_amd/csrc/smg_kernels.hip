@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(64) k_sw_full(Batch b, DevIndex ix, MapPar p, 
       b.rcpool[t].swscor = best;
       b.rcpool[t].flags = c.flags | RCF_SCORED | (best >= 65535 ? RCF_BANDED : 0u);   // ERRCODE_SWATEXCEED -> K2b
       cells += (unsigned long long)qlen * wlen;
-      ntasks_done++;
+      ntasks_done += best < 65535 ? 1 : 0;      /* a score that left 16 bits waits for K2b */
     }
     __syncthreads();
   }
@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(64) k_sw_full16(Batch b, DevIndex ix, MapPar p
           b.rcpool[t].swscor = best;
           b.rcpool[t].flags = c[u].flags | RCF_SCORED | (best >= 65535 ? RCF_BANDED : 0u);   // ERRCODE_SWATEXCEED -> K2b
           cells += (unsigned long long)qlen[u] * wlen[u];
-          ntasks_done++;
+          ntasks_done += best < 65535 ? 1 : 0;      /* a score that left 16 bits waits for K2b */
         }
       }
     }
@@ -732,7 +732,7 @@ __global__ void __launch_bounds__(64) k_sw_strip16(Batch b, DevIndex ix, MapPar 
           b.rcpool[tix[u]].swscor = best;
           b.rcpool[tix[u]].flags = c[u].flags | RCF_SCORED | (best >= 65535 ? RCF_BANDED : 0u);   // ERRCODE_SWATEXCEED -> K2b
           cells += (unsigned long long)qlen[u] * wlen[u];
-          ntasks_done++;
+          ntasks_done += best < 65535 ? 1 : 0;      /* a score that left 16 bits waits for K2b */
         }
       }
     }
@@ -770,7 +770,7 @@ __global__ void __launch_bounds__(64) k_sw_strip(Batch b, DevIndex ix, MapPar p,
       b.rcpool[t].swscor = best;
       b.rcpool[t].flags = c.flags | RCF_SCORED | (best >= 65535 ? RCF_BANDED : 0u);   // ERRCODE_SWATEXCEED -> K2b
       cells += (unsigned long long)qlen * wlen;
-      ntasks_done++;
+      ntasks_done += best < 65535 ? 1 : 0;      /* a score that left 16 bits waits for K2b */
     }
   }
   if (threadIdx.x == 0 && cells) { atomicAdd(b.work + WK_CELLS_FULL, cells); atomicAdd(b.work + WK_TASKS_FULL, ntasks_done); }
@@ -905,6 +905,7 @@ __global__ void __launch_bounds__(64) k_sw_band(Batch b, DevIndex ix, MapPar p, 
   __syncthreads();
   int2 *bnd = bnd_all + (size_t)blockIdx.x * 2 * wcap;
   uint8_t *win = win_all + (size_t)blockIdx.x * wcap;
+  unsigned long long nband = 0;
   for (uint32_t tl = blockIdx.x; tl < (uint32_t)nlist; tl += gridDim.x) {
     const uint32_t t = b.strip_list[tl];
     const RCand c = b.rcpool[t];
@@ -925,8 +926,10 @@ __global__ void __launch_bounds__(64) k_sw_band(Batch b, DevIndex ix, MapPar p, 
     if (threadIdx.x == 0) {
       b.rcpool[t].swscor = best;
       b.rcpool[t].flags = c.flags | RCF_SCORED | RCF_BSCORED;
+      nband++;
     }
   }
+  if (threadIdx.x == 0 && nband) atomicAdd(b.work + WK_TASKS_FULL, nband);
 }
 
 // K2a for tasks the register-tiled kernel does not cover (long reads / long windows) and
@@ -934,6 +937,7 @@ __global__ void __launch_bounds__(64) k_sw_band(Batch b, DevIndex ix, MapPar p, 
 __global__ void __launch_bounds__(64) k_sw_scalar(Batch b, DevIndex ix, MapPar p, int *rows, uint32_t rowlen, int full_gc) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
   const uint32_t ntask = min(*b.rc_count, b.rccap);      // the cursor runs past the pool when it overflows (reads keep SMG_ERR_CAP)
+  if (b.work[WK_TASKS_FULL] >= (unsigned long long)ntask) return;      // every ranked candidate has its score already (the usual case)
   int *Hp = rows + (size_t)tid * 2 * rowlen, *Ep = Hp + rowlen;
   int8_t M[64];
   score_matrix(M, p.match, p.mismatch);
