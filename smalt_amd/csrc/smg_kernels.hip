@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(64) k_seed(Batch b, DevIndex ix, MapPar p, uin
 // LONGK: the mapper takes reads of 256 bases and more; every read then goes through the general instance of the
 // wave-parallel form (mappers for short reads keep the lean one: fewer registers, more resident waves).
 template <bool LONGK>
-__global__ void __launch_bounds__(64) k_cands(Batch b, DevIndex ix, MapPar p, uint8_t *gscratch, CandGeom g, uint32_t lds_bytes) {
+__global__ void __launch_bounds__(64, 2) k_cands(Batch b, DevIndex ix, MapPar p, uint8_t *gscratch, CandGeom g, uint32_t lds_bytes) {
   extern __shared__ __align__(16) uint8_t lds[];
   unsigned long long nhit = 0;
   unsigned long long ph[16] = {0};
