@@ -598,6 +598,8 @@ __device__ inline void sw_tab8(uint2 *tab, const MapPar &p, int bias) {
 
 // The same in packed 16-bit halves: two tasks per wave (as k_sw_full16; reads without non-ACGT codes, scores < 65535).
 // win2: per-row code pairs (low byte task A, high byte task B); bnd: 2 x wcap packed (H pair, F pair).
+// M3: every value stays below 0x7C00, so the packed maximum of three (pk_max3) applies
+template <bool M3>
 __device__ inline uint32_t sw_strip16_core(const uint8_t *qa, uint32_t qlen_a, const uint8_t *qb, uint32_t qlen_b, const uint16_t *win2, uint32_t wmax,
                                            uint2 *bnd, uint32_t wcap, const uint32_t *rowtab, uint2 *ring /* LDS [256] */, const Sw16Par &sp) {
   constexpr int C = SW_STRIP_C;
@@ -649,17 +651,18 @@ __device__ inline uint32_t sw_strip16_core(const uint8_t *qa, uint32_t qlen_a, c
         for (int u = 0; u < 4; u++) {
           const us2 w = as_us2(__builtin_amdgcn_perm(rowB, rowA, sel[c0 + u]));
           const us2 dg = u == 0 ? carry : H[c0 + u - 1];
-          t3[u] = pk_max(pk_subs(pk_add_nc(dg, w), sp.bias), E[c0 + u]);
+          t3[u] = pk_subs(pk_add_nc(dg, w), sp.bias);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          const us2 hh = pk_max(t3[u], F);
-          best = pk_max(best, hh);
+          const us2 hh = M3 ? pk_max3(t3[u], E[c0 + u], F) : pk_max(pk_max(t3[u], E[c0 + u]), F);
+          if (!M3) best = pk_max(best, hh);
           H[c0 + u] = hh;
           const us2 tt = pk_subs(hh, sp.gi);
           E[c0 + u] = pk_max(pk_subs(E[c0 + u], sp.ge), tt);
           F = pk_max(pk_subs(F, sp.ge), tt);
         }
+        if (M3) { best = pk_max3(best, H[c0], H[c0 + 1]); best = pk_max3(best, H[c0 + 2], H[c0 + 3]); }
         carry = last_old;
       }
       if (sidx + 1 < nstrip) {
@@ -682,6 +685,7 @@ __device__ inline uint32_t sw_strip16_core(const uint8_t *qa, uint32_t qlen_a, c
 
 // packed strip kernel over the strip list: two consecutive list entries per wave; reads with non-ACGT codes are left
 // to k_sw_strip (32-bit lanes), which runs afterwards on whatever is still unscored
+template <bool M3>
 __global__ void __launch_bounds__(64) k_sw_strip16(Batch b, DevIndex ix, MapPar p, uint2 *bnd_all, uint16_t *win_all, uint32_t wcap) {
   const unsigned long long nlist = b.work[WK_STRIP_TASKS];
   if (nlist == 0 || !b.strip_list || nlist > b.strip_cap) return;
@@ -723,7 +727,7 @@ __global__ void __launch_bounds__(64) k_sw_strip16(Batch b, DevIndex ix, MapPar 
     }
     __threadfence();
     __syncthreads();
-    const uint32_t bb = sw_strip16_core(q[0], qlen[0], q[1], qlen[1], win, wmax, bnd, wcap, rowtab, ring, sp);
+    const uint32_t bb = sw_strip16_core<M3>(q[0], qlen[0], q[1], qlen[1], win, wmax, bnd, wcap, rowtab, ring, sp);
     if (threadIdx.x == 0) {
 #pragma unroll
       for (int u = 0; u < 2; u++) {
@@ -1140,7 +1144,11 @@ int launch_sw_full(hipStream_t s, const Batch &b, const DevIndex &ix, const MapP
 int launch_sw_strip(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, void *bnd, uint8_t *win, uint32_t wcap, uint32_t grid) {
   if (!b.nreads || !grid) return 0;
   if (sw16_ok(p) && (uint64_t)b.qmax * (uint64_t)p.match < 60000ull)          // 16-bit halves hold every score of these reads
-    hipLaunchKernelGGL(k_sw_strip16, dim3(grid), dim3(64), 0, s, b, ix, p, (uint2 *)bnd, (uint16_t *)win, wcap);
+  {
+    if ((uint64_t)b.qmax * (uint64_t)p.match + 512 < 0x7C00ull)                 // every value below the half-float infinity pattern: max3 form
+      hipLaunchKernelGGL(k_sw_strip16<true>, dim3(grid), dim3(64), 0, s, b, ix, p, (uint2 *)bnd, (uint16_t *)win, wcap);
+    else hipLaunchKernelGGL(k_sw_strip16<false>, dim3(grid), dim3(64), 0, s, b, ix, p, (uint2 *)bnd, (uint16_t *)win, wcap);
+  }
   hipLaunchKernelGGL(k_sw_strip, dim3(grid), dim3(64), 0, s, b, ix, p, (int2 *)bnd, win, wcap);
   hipLaunchKernelGGL(k_sw_band, dim3(grid), dim3(64), 0, s, b, ix, p, (int2 *)bnd, win, wcap);
   SMG_LAUNCH_CHECK();
