@@ -844,6 +844,7 @@ SMG_HD inline int traceback_scalar(uint8_t *ds, uint32_t dscap, int *qs, int *rs
                                    int max_i, int max_j, int max_scor, const uint8_t *q, const uint8_t *win,
                                    const int8_t *M, int gi, int ge, int tW = 0, const StripGeom *sg = nullptr) {
   uint32_t n = 0;
+  const int tb_match = M[0], tb_mismatch = M[1];   // (the matrix is read twice here, not once per step: it lives in scratch memory on the device)
   int c_sidx = -1, c_rlo = 0;                  // strip layout (tW < 0): directions come from strip_dir
   uint64_t c_base = 0;
   int i, j, checksum = 0;
@@ -856,7 +857,8 @@ SMG_HD inline int traceback_scalar(uint8_t *ds, uint32_t dscap, int *qs, int *rs
       const uint8_t d = tW < 0 ? (uint8_t)strip_dir(*sg, (const uint32_t *)dir, i - bp.s_left, j, &c_sidx, &c_base, &c_rlo) : dir[dir_index(bp, tW, i - bp.s_left, j)];
       if (!d) break;
       if (d == DIR_DIA) {
-        int s = M[8 * (win[i] & 7) + (q[j] & 7)];
+        const int rbc = win[i] & 7, qcc = q[j] & 7;
+        int s = (rbc >= 4 || qcc >= 4) ? 0 : (rbc == qcc ? tb_match : tb_mismatch);     // score.c:138-173 on the codes that occur (0-3, 5 = N)
         if (s > 0) {
           if (nmatch > DIFF_MAXMISMATCH) { SMG_PUT(DIFF_MAXMISMATCH, DIFF_M) nmatch -= DIFF_MAXMISMATCH; }
           else nmatch++;
@@ -874,7 +876,8 @@ SMG_HD inline int traceback_scalar(uint8_t *ds, uint32_t dscap, int *qs, int *rs
   } else
   for (i = max_i, j = max_j; i >= bp.s_left && j >= bp.q_left && *dp;) {
     if (*dp == DIR_DIA) {
-      int s = M[8 * (win[i] & 7) + (q[j] & 7)];
+      const int rbc = win[i] & 7, qcc = q[j] & 7;
+        int s = (rbc >= 4 || qcc >= 4) ? 0 : (rbc == qcc ? tb_match : tb_mismatch);     // score.c:138-173 on the codes that occur (0-3, 5 = N)
       if (s > 0) {
         if (nmatch > DIFF_MAXMISMATCH) { SMG_PUT(DIFF_MAXMISMATCH, DIFF_M) nmatch -= DIFF_MAXMISMATCH; }
         else nmatch++;
