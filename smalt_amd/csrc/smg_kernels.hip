@@ -398,10 +398,35 @@ __global__ void __launch_bounds__(64) k_sw_full16(Batch b, DevIndex ix, MapPar p
     int nstep = (int)wmax + G - 1;
     for (int o = 32; o > 0; o >>= 1) nstep = max(nstep, __shfl_xor(nstep, o));
     nstep = __builtin_amdgcn_readfirstlane(nstep);                         // wave-uniform: a scalar loop bound for the sweep
-    for (uint32_t e = g; e < (uint32_t)(nstep + G - 1); e += G) {        // entry e = row e - (G - 1); N pairs around the window
-      const uint32_t i = e - (uint32_t)(G - 1);                           // (wraps for the leading pad: fails both tests below)
-      const uint32_t a = i < wlen[0] ? ref_code(ix.packed, gbase[0] + i) : 5u, bb = i < wlen[1] ? ref_code(ix.packed, gbase[1] + i) : 5u;
-      win[grp][e] = (uint16_t)(a | (bb << 3));
+    {
+      // entry e = row e - (G - 1); N pairs around the window.  Every lane decodes a run of consecutive entries: one
+      // division per task to find the first packed word (10 bases per word), then shifts; the next word is loaded ahead.
+      const uint32_t nent = (uint32_t)(nstep + G - 1), per = (nent + G - 1) / G;
+      const uint32_t e0 = (uint32_t)g * per, e1 = e0 + per < nent ? e0 + per : nent;
+      const uint64_t lastw = ix.totlen / 10;
+      uint64_t wi[2] = {0, 0};
+      uint32_t wd[2] = {0, 0}, nx[2] = {0, 0}, off[2] = {0, 0};
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int i0 = (int)e0 - (G - 1);
+        const uint64_t pos = gbase[u] + (uint64_t)(i0 > 0 ? i0 : 0);
+        wi[u] = pos / 10; off[u] = (uint32_t)(pos - wi[u] * 10);
+        if (wlen[u] && e0 < e1) { wd[u] = ix.packed[wi[u] < lastw ? wi[u] : lastw]; nx[u] = ix.packed[wi[u] + 1 < lastw ? wi[u] + 1 : lastw]; }
+      }
+      for (uint32_t e = e0; e < e1; e++) {
+        const uint32_t i = e - (uint32_t)(G - 1);                         // (wraps for the leading pad: fails both tests below)
+        uint32_t cd[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          cd[u] = 5u;
+          if (i < wlen[u]) {
+            const uint32_t c = (wd[u] >> (3 * (9 - off[u]))) & 7u;
+            cd[u] = (c == 7) ? 0u : ((c == 6 || c == 4) ? 5u : c);
+            if (++off[u] == 10) { off[u] = 0; wi[u]++; wd[u] = nx[u]; nx[u] = ix.packed[wi[u] + 1 < lastw ? wi[u] + 1 : lastw]; }
+          }
+        }
+        win[grp][e] = (uint16_t)(cd[0] | (cd[1] << 3));
+      }
     }
     uint32_t sel[C];
 #pragma unroll
