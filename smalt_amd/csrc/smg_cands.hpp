@@ -531,6 +531,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     nhits_alloc = (int)alloc; nhits_max = (int)target;
   }
   const uint32_t ncut = (uint32_t)(p.ncut > 0 ? p.ncut : 0);
+  const uint32_t smagic = div_magic(s);
   int err = 0;
   uint32_t ncand = 0, max_cover = 0, max2nd = 0, nhits_total = 0;
   if (x.dbg_first) { SMG_PAR_CHUNKS(base, 2 * ngrp) { uint32_t g = base + SMG_LANE; if (g < 2 * ngrp) { x.dbg_first[g] = 0; x.dbg_cnt[g] = 0; } } }
@@ -670,7 +671,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
               const uint32_t t = (uint32_t)(((uint64_t)room * rem) / remaining) + 1;
               if (t < rem) {
                 const uint32_t pos = ix.pos[g_poff[l] + cur + t];
-                uint64_t kh = hit_diag(st != 0, pos, g_qo[l], s);
+                uint64_t kh = hit_diag_m(st != 0, pos, g_qo[l], smagic);
                 if (seqbyseq) kh |= (uint64_t)seq_of_pos(ix.seqlo, ix.nseq, pos) << KEY_DIAGBITS;
                 if (kh < bound) bound = kh;
               }
@@ -743,7 +744,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
           for (int u = 0; u < 4; u++) {
             const uint32_t h = base + (uint32_t)u * SMG_NLANES + SMG_LANE;
             if (h < cnt_tot) {
-              uint64_t key = (hit_diag(st != 0, pos[u], qo[u], s) << KEY_QBITS) | qo[u];
+              uint64_t key = (hit_diag_m(st != 0, pos[u], qo[u], smagic) << KEY_QBITS) | qo[u];
               if (seqbyseq) {                      // the window's keys lie between the previous bound and this one: so do their sequences
                 uint32_t lo = sq_lo, hi = sq_hi + 1;
                 while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (ix.seqlo[m] <= pos[u]) lo = m; else hi = m; }
@@ -816,7 +817,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
           for (int u = 0; u < 4; u++) {
             const uint32_t h = base + (uint32_t)u * SMG_NLANES + SMG_LANE;
             if (h < nkeys) {
-              uint64_t key = (hit_diag(st != 0, pos[u], qo[u], s) << KEY_QBITS) | qo[u];
+              uint64_t key = (hit_diag_m(st != 0, pos[u], qo[u], smagic) << KEY_QBITS) | qo[u];
               if (seqbyseq) key |= (uint64_t)seq_of_pos(ix.seqlo, ix.nseq, pos[u]) << (KEY_DIAGBITS + KEY_QBITS);
               dat[h] = key;
             }
@@ -895,6 +896,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   uint32_t cdf[2] = {0, 0};
   for (uint32_t st = 0; st < 2; st++) {
     const uint32_t rs = 2 * r + st;
+    if (st == 0 && x.lw.prune_on) { cdf[0] = x.lw.prune_cdf0; continue; }      // computed when strand [0]'s flags became final
     cdf[st] = wave_cover_deficit(b.hi[rs], b.seeds + (size_t)rs * b.qmax, b.qmask + (size_t)rs * b.qmax, qlen, k, s, LONG ? hist : wk, nwq);
   }
   SMG_LANE0 { ch.cover_deficit[0] = cdf[0]; ch.cover_deficit[1] = cdf[1]; }

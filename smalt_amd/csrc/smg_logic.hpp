@@ -198,6 +198,15 @@ SMG_HD inline uint64_t hit_diag(bool is_reverse, uint32_t pos, uint32_t q, int s
   return is_reverse ? ((uint64_t)pos + q / (uint32_t)s) : ((((uint64_t)pos) | offbit) - q / (uint32_t)s);
 }
 
+// the same with the division by the stride as a multiplication: magic = ceil(2^32 / s) (0 for s == 1), exact for
+// read offsets below 2^20 (the error of q * magic / 2^32 is below 2^-12 < 1 / s)
+SMG_HD inline uint32_t div_magic(int s) { return s > 1 ? (uint32_t)((0x100000000ull + (uint32_t)s - 1) / (uint32_t)s) : 0u; }
+SMG_HD inline uint64_t hit_diag_m(bool is_reverse, uint32_t pos, uint32_t q, uint32_t magic) {
+  const uint64_t offbit = 1ull << 32;
+  const uint32_t qs = magic ? (uint32_t)(((uint64_t)q * magic) >> 32) : q;
+  return is_reverse ? ((uint64_t)pos + qs) : ((((uint64_t)pos) | offbit) - qs);
+}
+
 SMG_HD inline uint32_t lower_bound_u32(const uint32_t *a, uint32_t n, uint32_t v) {
   uint32_t lo = 0, hi = n;
   while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; }
