@@ -28,8 +28,8 @@ sys.path.insert(0, ROOT)
 VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12     # lane-ops/s: 256 CU x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md); a packed 16-bit
                                                   # instruction issues every 4 cycles for 64 lanes x 2 halves = the same 32 cell-ops/clk/SIMD
 HBM_PEAK_GBS = 8000.0
-OPS_PER_CELL = 9.6                                # VALU ops per Gotoh cell of the packed kernel: 9.6 instructions per cell pair
-                                                  # (perm, add, sub, max3, 0.6 for the running maximum, sub, 2 x (sub, max)), each counting as 2 cell-ops
+OPS_PER_CELL = 8.6                                # VALU ops per Gotoh cell of the packed kernel: 8.6 instructions per cell pair
+                                                  # (perm, add, max3, add, 2 x (add, max3), 0.6 for the running maximum), each counting as 2 cell-ops
 
 
 def parse_args():

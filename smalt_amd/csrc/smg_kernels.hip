@@ -275,9 +275,27 @@ __device__ inline us2 pk_max3(us2 a, us2 b, us2 c) {
 __device__ inline uint32_t shr1_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, true); }
 
 enum : int { SW16_BLK = 5 };
-struct Sw16Par { uint32_t mm4, dlt, n4; us2 bias, gi, ge; };
-__device__ inline Sw16Par sw16_par(const MapPar &p) {
+struct Sw16Par { uint32_t mm4, dlt, n4; us2 bias, gi, ge; int fp; uint32_t hi_match, hi_mismatch; us2 ngi, nge; };
+// half-float bit pattern of a small integer (|n| <= 2048: exact)
+__device__ inline uint32_t f16_bits_of_int(int n) {
+  if (n == 0) return 0;
+  const uint32_t sign = n < 0 ? 0x8000u : 0u, a = (uint32_t)(n < 0 ? -n : n);
+  const int e = 31 - __clz((int)a);
+  return sign | ((uint32_t)(e + 15) << 10) | ((e <= 10 ? a << (10 - e) : a >> (e - 10)) & 0x3ffu);
+}
+// ncols: columns of the register tile (longest read of this instance)
+__device__ inline Sw16Par sw16_par(const MapPar &p, int ncols = 512) {
   Sw16Par s;
+  // Half-float form (sw16f_core): scores as half floats -- integers up to 2048 are exact -- so that the substitution
+  // score is signed (no bias to take off again) and gfx950's packed maximum3 floors the gap scores at 0 in the same
+  // instruction.  One v_perm fetches the HIGH bytes of both tasks' scores: match and mismatch must be half floats with a
+  // zero low byte (integers with at most three significant bits: 1, -2, 3, -4, 5, -6, ...).
+  const uint32_t fm = f16_bits_of_int(p.match), fx = f16_bits_of_int(p.mismatch);
+  s.fp = (fm & 0xffu) == 0 && (fx & 0xffu) == 0 && p.match > 0 && p.match * ncols <= 2040 && -p.gap_init >= 0 && -p.gap_init <= 2040 &&
+         -p.gap_ext >= 0 && -p.gap_ext <= 2040 && p.mismatch >= -1024;
+  s.hi_match = fm >> 8; s.hi_mismatch = fx >> 8;
+  { const uint32_t a = f16_bits_of_int(p.gap_init), e = f16_bits_of_int(p.gap_ext);      // gap_init, gap_ext are negative: added
+    s.ngi = us2{(unsigned short)a, (unsigned short)a}; s.nge = us2{(unsigned short)e, (unsigned short)e}; }
   const int bias = (p.mismatch < p.mismatch - p.match ? -p.mismatch : -(p.mismatch - p.match));
   s.mm4 = (uint32_t)((p.mismatch + bias) & 0xff) * 0x01010101u;      // a row of mismatches ...
   s.dlt = (uint32_t)(p.match - p.mismatch);                          // ... plus this at the byte of the matching base
@@ -346,6 +364,64 @@ __device__ inline uint32_t sw16_core(const uint16_t *wrow, int nstep, const uint
   return bb;
 }
 
+// The same sweep in half floats (Sw16Par::fp).  Per cell pair: perm (high bytes of both signed scores), add, max3 (value,
+// E, F -- both kept >= 0, which floors the value too), add (gap open), 2 x (add, max3 with 0) and 0.6 for the running
+// maximum: 8.6 instructions.  Every value is an integer of magnitude <= 2048, so the arithmetic is exact.
+__device__ inline hf2 hf_max3(hf2 a, hf2 b, hf2 c) { return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c); }
+template <int G, int C>
+__device__ inline uint32_t sw16f_core(const uint16_t *wrow, int nstep, const uint32_t (&sel)[C], int g, const Sw16Par &sp, const uint2 *rowtab2) {
+  hf2 H[C], E[C];
+  const hf2 zero = hf2{(_Float16)0, (_Float16)0};
+#pragma unroll
+  for (int cc = 0; cc < C; cc++) { H[cc] = zero; E[cc] = zero; }
+  hf2 best = zero, F = zero, prev_hl = zero;
+  const hf2 ngi = __builtin_bit_cast(hf2, sp.ngi), nge = __builtin_bit_cast(hf2, sp.nge);
+  const uint32_t gmask = g == 0 ? 0u : 0xffffffffu;
+  for (int step = 0; step < nstep; step++) {
+    const uint2 rr = rowtab2[wrow[step - g + (G - 1)]];
+    const uint32_t hl = shr1_u32(__builtin_bit_cast(uint32_t, H[C - 1])) & gmask;
+    const uint32_t fin = shr1_u32(__builtin_bit_cast(uint32_t, F)) & gmask;
+    hf2 carry = prev_hl;
+    prev_hl = __builtin_bit_cast(hf2, hl);
+    F = __builtin_bit_cast(hf2, fin);
+#pragma unroll
+    for (int c0 = 0; c0 < C; c0 += SW16_BLK) {
+      hf2 t3[SW16_BLK];
+      const hf2 last_old = H[(c0 + SW16_BLK - 1 < C) ? c0 + SW16_BLK - 1 : C - 1];
+#pragma unroll
+      for (int u = 0; u < SW16_BLK; u++) {
+        const int cc = c0 + u;
+        if (cc < C) {
+          const hf2 w = __builtin_bit_cast(hf2, __builtin_amdgcn_perm(rr.y, rr.x, sel[cc]));
+          const hf2 dg = u == 0 ? carry : H[cc - 1];
+          t3[u] = dg + w;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < SW16_BLK; u++) {
+        const int cc = c0 + u;
+        if (cc < C) {
+          const hf2 hh = hf_max3(t3[u], E[cc], F);
+          H[cc] = hh;
+          const hf2 tt = hh + ngi;
+          E[cc] = hf_max3(E[cc] + nge, tt, zero);
+          F = hf_max3(F + nge, tt, zero);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < SW16_BLK; u += 2) {
+        const int cc = c0 + u;
+        if (cc + 1 < C && u + 1 < SW16_BLK) best = hf_max3(best, H[cc], H[cc + 1]);
+        else if (cc < C) best = __builtin_elementwise_maximum(best, H[cc]);
+      }
+      carry = last_old;
+    }
+  }
+  for (int o = G / 2; o > 0; o >>= 1)
+    best = __builtin_elementwise_maximum(best, __builtin_bit_cast(hf2, (uint32_t)__shfl_xor((int)__builtin_bit_cast(uint32_t, best), o)));
+  return (uint32_t)(int)(float)best.x | ((uint32_t)(int)(float)best.y << 16);
+}
+
 // rowtab[code]: the four biased ACGT scores against reference code 0..7 (4, 5, 6: 'N' -> score 0; 7 decodes as A upstream)
 __device__ inline void sw16_rowtab(uint32_t *rowtab, const Sw16Par &sp) {
   if (threadIdx.x < 8) rowtab[threadIdx.x] = threadIdx.x < 4 ? sp.mm4 + (sp.dlt << (8 * threadIdx.x)) : sp.n4;
@@ -353,6 +429,12 @@ __device__ inline void sw16_rowtab(uint32_t *rowtab, const Sw16Par &sp) {
 // the same for a pair of codes: entry a | b << 3
 __device__ inline void sw16_rowtab2(uint2 *rowtab2, const Sw16Par &sp) {
   const uint32_t a = threadIdx.x & 7u, bq = threadIdx.x >> 3;
+  if (sp.fp) {                                  // high bytes of the half-float scores against A, C, G, T; N rows: 0
+    const uint32_t x4 = sp.hi_mismatch * 0x01010101u;
+    rowtab2[threadIdx.x] = make_uint2(a < 4 ? (x4 & ~(0xffu << (8 * a))) | (sp.hi_match << (8 * a)) : 0u,
+                                      bq < 4 ? (x4 & ~(0xffu << (8 * bq))) | (sp.hi_match << (8 * bq)) : 0u);
+    return;
+  }
   rowtab2[threadIdx.x] = make_uint2(a < 4 ? sp.mm4 + (sp.dlt << (8 * a)) : sp.n4, bq < 4 ? sp.mm4 + (sp.dlt << (8 * bq)) : sp.n4);
 }
 enum : uint32_t { SW16_NPAIR = 5u | (5u << 3) };
@@ -369,7 +451,7 @@ __global__ void __launch_bounds__(64) k_sw_full16(Batch b, DevIndex ix, MapPar p
   __shared__ uint2 rowtab2[64];
   const int lane = threadIdx.x, g = lane % G, grp = lane / G;
   const uint32_t ntask = list ? (uint32_t)nlong : min(*b.rc_count, ntask_cap), npair = (ntask + 1) / 2;
-  const Sw16Par sp = sw16_par(p);
+  const Sw16Par sp = sw16_par(p, G * C);
   sw16_rowtab2(rowtab2, sp);
   const uint32_t ngroups = gridDim.x * NG;
   unsigned long long cells = 0, ntasks_done = 0;
@@ -433,10 +515,10 @@ __global__ void __launch_bounds__(64) k_sw_full16(Batch b, DevIndex ix, MapPar p
     for (int cc = 0; cc < C; cc++) {
       const uint32_t j = (uint32_t)(g * C + cc);
       const uint32_t sa = j < qlen[0] ? (uint32_t)q[0][j] : 0x0cu, sb = j < qlen[1] ? 4u + (uint32_t)q[1][j] : 0x0cu;
-      sel[cc] = 0x0c000c00u | sa | (sb << 16);
+      sel[cc] = sp.fp ? (0x000c000cu | (sa << 8) | (sb << 24)) : (0x0c000c00u | sa | (sb << 16));      // half floats: the score byte is the high byte
     }
     __syncthreads();
-    const uint32_t bb = sw16_core<G, C>(win[grp], nstep, sel, g, sp, rowtab2);
+    const uint32_t bb = sp.fp ? sw16f_core<G, C>(win[grp], nstep, sel, g, sp, rowtab2) : sw16_core<G, C>(win[grp], nstep, sel, g, sp, rowtab2);
     if (g == 0) {
 #pragma unroll
       for (int u = 0; u < 2; u++) {
@@ -466,7 +548,7 @@ __global__ void __launch_bounds__(64) k_sw_full16_raw(const uint8_t *qcodes, con
   __shared__ uint2 rowtab2[64];
   const int lane = threadIdx.x, g = lane % G, grp = lane / G;
   const uint32_t npair = (ntask + 1) / 2;
-  const Sw16Par sp = sw16_par(p);
+  const Sw16Par sp = sw16_par(p, G * C);
   sw16_rowtab2(rowtab2, sp);
   const uint32_t ngroups = gridDim.x * NG;
   for (uint32_t t0 = blockIdx.x * NG; t0 < npair; t0 += ngroups) {
@@ -507,12 +589,12 @@ __global__ void __launch_bounds__(64) k_sw_full16_raw(const uint8_t *qcodes, con
         if (j < qlen[u] && qc >= 4) qn[u] = true;
         s2[u] = qc == 0x0cu ? 0x0cu : (uint32_t)(4 * u) + (qc & 3u);
       }
-      sel[cc] = 0x0c000c00u | s2[0] | (s2[1] << 16);
+      sel[cc] = sp.fp ? (0x000c000cu | (s2[0] << 8) | (s2[1] << 24)) : (0x0c000c00u | s2[0] | (s2[1] << 16));
     }
 #pragma unroll
     for (int u = 0; u < 2; u++) for (int o = G / 2; o > 0; o >>= 1) { const int other = __shfl_xor((int)qn[u], o); qn[u] = qn[u] || other != 0; }
     __syncthreads();
-    const uint32_t bb = sw16_core<G, C>(win[grp], nstep, sel, g, sp, rowtab2);
+    const uint32_t bb = sp.fp ? sw16f_core<G, C>(win[grp], nstep, sel, g, sp, rowtab2) : sw16_core<G, C>(win[grp], nstep, sel, g, sp, rowtab2);
     if (g == 0) {
 #pragma unroll
       for (int u = 0; u < 2; u++) {
