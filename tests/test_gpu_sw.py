@@ -71,6 +71,42 @@ def test_sw_full_kernel_matches_oracle(qlo, qhi, oracle_built):
         ol.lib().or_index_free(oix)
 
 
+@pytest.mark.parametrize("pen", [(2, -3, -5, -2), (5, -4, -6, -1), (1, -1, -2, -1), (3, -6, -8, -4),       # half-float form
+                                 (9, -7, -9, -3), (3, -9, -4, -3), (15, -14, -20, -10), (13, -2, -4, -3)],  # integer form (low byte / range)
+                         ids=lambda v: "m%d_x%d_g%d_e%d" % (v[0], -v[1], -v[2], -v[3]))
+def test_sw_packed_kernel_penalty_sets(pen, oracle_built):
+    """The packed K2a kernel picks its form from the penalties: half floats when match and mismatch are half floats with a
+    zero low byte and match x tile columns <= 2040, the integer form otherwise.  Both against the oracle."""
+    from smalt_amd import api
+    match, mismatch, gi, ge = pen
+    rng = np.random.default_rng(match * 1000 - mismatch * 10 - gi)
+    seqs = [bytes(rng.choice(list(b"ACGT"), size=4000).astype(np.uint8))]
+    oix = ol.build_index(seqs, ["s"], 11, 3)
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        pre = os.path.join(tmp, "x")
+        ol.lib().or_index_write(oix, pre.encode())
+        gix = api.Index.load(pre, 0)
+    mp = api.Mapper(gix, 16, 512)
+    par = gix.default_params()
+    par.match, par.mismatch, par.gap_init, par.gap_ext = match, mismatch, gi, ge
+    M = (C.c_int8 * 64)()
+    ol.lib().or_score_matrix(M, match, mismatch)
+    try:
+        for qlo, qhi in ((40, 64), (105, 152), (161, 256)):
+            qs, ws = _pairs(rng, 400, qlo, qhi, False)
+            got16 = mp.sw_full_batch(qs, ws, par, packed16=True)
+            got32 = mp.sw_full_batch(qs, ws, par)
+            for i, (q, w) in enumerate(zip(qs, ws)):
+                exp = ol.lib().or_sw_full(q, len(q), w, len(w), M, gi, ge)
+                assert got16[i] == exp, (i, len(q), len(w), got16[i], exp)
+                assert got32[i] == exp, (i, len(q), len(w), got32[i], exp)
+    finally:
+        mp.close()
+        gix.close()
+        ol.lib().or_index_free(oix)
+
+
 @pytest.mark.parametrize("qlo,qhi,ntask", [(513, 1024, 60), (1025, 2300, 40), (40, 300, 60)])
 def test_sw_strip_kernel_matches_oracle(qlo, qhi, ntask, oracle_built):
     """K2a beyond the register tiling: strips of 1024 read columns with the boundary column handed from strip to strip
