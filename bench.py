@@ -269,7 +269,7 @@ def main():
         line = {
             "metric": "mapped reads/sec (1Mx150bp vs 3Gbp ref)", "value": value, "unit": "mapped reads/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",      # K2a: packed half floats holding exact integer scores
             "config": {"workload": "configs[1]: %d x %d bp single-end reads per GPU vs %d x %.0f Mbp synthetic reference (15%% repeats), k=%d s=%d, best-only"
                        % (args.reads, args.read_len, nchr, args.chr_mbp, k, s),
                        "reads_per_gpu_per_step": args.reads, "sub_batch": sub, "mapped_fraction": mapped_all / (world * args.steps * args.reads),
