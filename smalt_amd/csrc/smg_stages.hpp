@@ -253,9 +253,11 @@ SMG_HD inline uint32_t stage_seed(const Batch &b, const DevIndex &ix, const MapP
         qm_clear(mk);
         uint32_t cover = 0;
         int last = -1;
+        const uint32_t smagic = div_magic(s);           // q0 % s without a division (exact for offsets below 2^20)
         for (uint32_t rk = 0; rk < nseeds; rk++) {
           const uint32_t q0 = x.qbr[rk];
-          if (q0 % (uint32_t)s != f) continue;
+          const uint32_t qd = smagic ? (uint32_t)(((uint64_t)q0 * smagic) >> 32) : q0;
+          if (q0 - qd * (uint32_t)s != f) continue;
           if (!(cover <= maxcover && (cover < mincover || rk <= nbud))) break;
           cover += qm_add(mk, q0, (uint32_t)k - 1);      // k-1 bases (hashhit.c:873)
           last = (int)rk;
