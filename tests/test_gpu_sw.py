@@ -136,3 +136,15 @@ def test_sw_strip_kernel_matches_oracle(qlo, qhi, ntask, oracle_built):
         mp.close()
         gix.close()
         ol.lib().or_index_free(oix)
+
+
+def test_packed_max3_orders_u16_bit_patterns_like_integers(tmp_path):
+    """The packed kernels use gfx950's v_pk_maximum3_f16 as an integer maximum of three on u16 bit patterns below 0x7C00
+    (tools/pk_max3_check.hip: 10^6 random triples incl. the half-float denormal range, bit for bit)."""
+    import os, shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "pk_max3_check")
+    subprocess.run([hipcc, "-w", "-O2", "--offload-arch=gfx950", "-o", exe, os.path.join(root, "tools", "pk_max3_check.hip")], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "bad 0 of" in out
