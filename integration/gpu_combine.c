@@ -23,11 +23,18 @@ typedef struct {
   int done, rv;
 } CombReq;
 
-static struct CombDev {
-  pthread_mutex_t mu; pthread_cond_t cv; int init;
-  CombReq *pending[COMB_MAXREQ]; int npending; int leader;
+/* one mapper (HIP stream) with its staging buffers; a device has COMB_NSLOT of them so that one batch is packed,
+ * copied and unpacked while another one runs */
+enum { COMB_NSLOT = 2 };
+struct CombSlot {
+  int busy;
   smaltgpu_mapper *mp; uint32_t cap_reads, cap_len;
   char *bases, *quals; uint64_t *off; size_t basecap;
+};
+static struct CombDev {
+  pthread_mutex_t mu; pthread_cond_t cv; int init;
+  CombReq *pending[COMB_MAXREQ]; int npending; int assembling;      /* assembling: a leader is collecting requests */
+  struct CombSlot slot[COMB_NSLOT];
 } g_dev[COMB_MAXDEV];
 static pthread_mutex_t g_init = PTHREAD_MUTEX_INITIALIZER;
 
@@ -42,8 +49,8 @@ static int grow(void **p, size_t *cap, size_t need, size_t elem)
   return 0;
 }
 
-/* one combined batch: reqs[0..nreq) on device d */
-static void run_batch(struct CombDev *d, const smaltgpu_index *ix, CombReq **reqs, int nreq)
+/* one combined batch: reqs[0..nreq) on mapper slot d */
+static void run_batch(struct CombSlot *d, const smaltgpu_index *ix, CombReq **reqs, int nreq)
 {
   uint32_t ntot = 0, maxlen = 1, r0;
   size_t nb = 0;
@@ -59,13 +66,14 @@ static void run_batch(struct CombDev *d, const smaltgpu_index *ix, CombReq **req
     uint32_t cr = d->cap_reads > 16384 ? d->cap_reads : 16384, cl = d->cap_len > 64 ? d->cap_len : 64;
     while (cr < ntot) cr *= 2;
     if (cl < maxlen) cl = (maxlen + 31u) & ~31u;
+    pthread_mutex_lock(&g_init);                         /* mapper creation reads the environment: one at a time */
     if (d->mp) smaltgpu_mapper_free(d->mp);
     d->mp = NULL;
-    setenv("SMALTGPU_CANDS_PER_READ", "1024", 0);        /* ranked candidates per read of the shared pool (default sizing is for large batches) */
     free(d->off);
     d->off = malloc(((size_t)cr + 1) * sizeof(uint64_t));
     if (!d->off || smaltgpu_mapper_create(&d->mp, ix, cr, cl)) rv = SMALTGPU_ENOMEM;
     else { d->cap_reads = cr; d->cap_len = cl; }
+    pthread_mutex_unlock(&g_init);
   }
   if (!rv && d->basecap < nb + 1) {
     free(d->bases); free(d->quals);
@@ -123,7 +131,10 @@ int gpuCombineSubmit(int dev, const smaltgpu_index *ix, const char *bases, const
   if (dev < 0 || dev >= COMB_MAXDEV || !n) return SMALTGPU_EARG;
   d = &g_dev[dev];
   pthread_mutex_lock(&g_init);
-  if (!d->init) { pthread_mutex_init(&d->mu, NULL); pthread_cond_init(&d->cv, NULL); d->init = 1; }
+  if (!d->init) {
+    pthread_mutex_init(&d->mu, NULL); pthread_cond_init(&d->cv, NULL); d->init = 1;
+    setenv("SMALTGPU_CANDS_PER_READ", "1024", 0);        /* ranked candidates per read of the shared pools (default sizing is for large batches) */
+  }
   pthread_mutex_unlock(&g_init);
   req.bases = bases; req.quals = quals; req.off = off; req.n = n; req.par = par; req.out = out; req.done = 0; req.rv = 0;
   pthread_mutex_lock(&d->mu);
@@ -131,11 +142,13 @@ int gpuCombineSubmit(int dev, const smaltgpu_index *ix, const char *bases, const
   d->pending[d->npending++] = &req;
   pthread_cond_broadcast(&d->cv);
   while (!req.done) {
-    if (!d->leader) {
+    int sl = -1, u;
+    if (!d->assembling && d->npending > 0) for (u = 0; u < COMB_NSLOT; u++) if (!d->slot[u].busy) { sl = u; break; }     /* (a waiting thread may lead a batch of others) */
+    if (sl >= 0) {
       CombReq *take[COMB_MAXREQ];
       int ntake = 0, i, rounds;
       uint32_t reads = 0;
-      d->leader = 1;
+      d->assembling = 1; d->slot[sl].busy = 1;
       for (rounds = 0; rounds < 8; rounds++) {              /* let the other workers arrive: up to 8 x 250 us while requests keep coming */
         struct timespec ts;
         const int before = d->npending;
@@ -152,11 +165,13 @@ int gpuCombineSubmit(int dev, const smaltgpu_index *ix, const char *bases, const
       }
       memmove(d->pending, d->pending + ntake, (size_t)(d->npending - ntake) * sizeof(d->pending[0]));
       d->npending -= ntake;
+      d->assembling = 0;                                     /* the next leader may collect while this batch runs */
+      pthread_cond_broadcast(&d->cv);
       pthread_mutex_unlock(&d->mu);
-      run_batch(d, ix, take, ntake);
+      if (ntake) run_batch(&d->slot[sl], ix, take, ntake);
       pthread_mutex_lock(&d->mu);
       for (i = 0; i < ntake; i++) take[i]->done = 1;
-      d->leader = 0;
+      d->slot[sl].busy = 0;
       pthread_cond_broadcast(&d->cv);
     } else pthread_cond_wait(&d->cv, &d->mu);
   }
