@@ -25,7 +25,8 @@ typedef struct {
 
 /* one mapper (HIP stream) with its staging buffers; a device has COMB_NSLOT of them so that one batch is packed,
  * copied and unpacked while another one runs */
-enum { COMB_NSLOT = 2 };
+enum { COMB_NSLOT = 4 };                          /* capacity; SMALTGPU_COMBINE_SLOTS (default 2) of them are used */
+static int g_nslot = 2;
 struct CombSlot {
   int busy;
   smaltgpu_mapper *mp; uint32_t cap_reads, cap_len;
@@ -134,6 +135,7 @@ int gpuCombineSubmit(int dev, const smaltgpu_index *ix, const char *bases, const
   if (!d->init) {
     pthread_mutex_init(&d->mu, NULL); pthread_cond_init(&d->cv, NULL); d->init = 1;
     setenv("SMALTGPU_CANDS_PER_READ", "1024", 0);        /* ranked candidates per read of the shared pools (default sizing is for large batches) */
+    if (getenv("SMALTGPU_COMBINE_SLOTS")) { const int v = atoi(getenv("SMALTGPU_COMBINE_SLOTS")); if (v >= 1 && v <= COMB_NSLOT) g_nslot = v; }
   }
   pthread_mutex_unlock(&g_init);
   req.bases = bases; req.quals = quals; req.off = off; req.n = n; req.par = par; req.out = out; req.done = 0; req.rv = 0;
@@ -143,7 +145,7 @@ int gpuCombineSubmit(int dev, const smaltgpu_index *ix, const char *bases, const
   pthread_cond_broadcast(&d->cv);
   while (!req.done) {
     int sl = -1, u;
-    if (!d->assembling && d->npending > 0) for (u = 0; u < COMB_NSLOT; u++) if (!d->slot[u].busy) { sl = u; break; }     /* (a waiting thread may lead a batch of others) */
+    if (!d->assembling && d->npending > 0) for (u = 0; u < g_nslot; u++) if (!d->slot[u].busy) { sl = u; break; }     /* (a waiting thread may lead a batch of others) */
     if (sl >= 0) {
       CombReq *take[COMB_MAXREQ];
       int ntake = 0, i, rounds;
