@@ -73,5 +73,14 @@ static int smaltgpu_threadsSetTask(uint8_t task_typ, short n_threads, THREAD_INI
                                    THREAD_CLEANF *cleanf, THREAD_CHECKF *checkf, THREAD_CMPF *cmpf, size_t argsz)
 {
   if (task_typ == THRTASK_PROC && !getenv("SMALTGPU_PER_READ")) procf = processArgBlockGpu;     /* SMALTGPU_PER_READ: keep one rmapSingle per read */
+  if (task_typ == THRTASK_ARGBUF && !getenv("SMALTGPU_PER_READ") && initargp) {
+    /* The reference sizes a block at 32 reads per worker thread (smalt.c:466).  The GPU path wants enough reads in flight
+     * for two combined batches whatever the thread count: blocks of at least 1024 reads (SMALTGPU_BLOCK_READS overrides).
+     * The block size changes nothing in what is computed for a read. */
+    SmaltMapConst *mc = (SmaltMapConst *)initargp;
+    int want = getenv("SMALTGPU_BLOCK_READS") ? atoi(getenv("SMALTGPU_BLOCK_READS")) : 1024;
+    if (want > 16384) want = 16384;
+    if (mc->threadblksz < want) mc->threadblksz = (short)want;
+  }
   return threadsSetTask(task_typ, n_threads, initf, initargp, procf, cleanf, checkf, cmpf, argsz);
 }
