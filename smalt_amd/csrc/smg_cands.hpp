@@ -75,8 +75,10 @@ SMG_HD inline bool seed_break(uint64_t a, uint64_t b, int k, int s) {
 }
 
 // calcSegmentBoundaries (segment.c:635-668) from the compact arrays
+// x / s for offsets below 2^20 (magic = div_magic(s): a multiplication instead of a division)
+SMG_HD inline uint32_t div_s(uint32_t x, uint32_t magic) { return magic ? (uint32_t)(((uint64_t)x * magic) >> 32) : x; }
 template <class IT>
-SMG_HD inline void segm_bounds(const StrandWork<IT> &w, uint32_t m, int k, int s, bool is_reverse, uint32_t *qs, uint32_t *qe,
+SMG_HD inline void segm_bounds(const StrandWork<IT> &w, uint32_t m, int k, uint32_t mg /* div_magic(s) */, bool is_reverse, uint32_t *qs, uint32_t *qe,
                                uint32_t *rs, uint32_t *re) {
   const uint32_t sa = w.segm_first[m], sb = sa + w.segm_nseed[m] - 1;
   const uint64_t ka = w.dat[w.seed_first[sa]], kb = w.dat[w.seed_first[sb]];
@@ -84,27 +86,27 @@ SMG_HD inline void segm_bounds(const StrandWork<IT> &w, uint32_t m, int k, int s
   *qs = qa;
   *qe = qb + lb - 1;
   if (is_reverse) {
-    *rs = (uint32_t)((key_diag(kb) - qb / (uint32_t)s) & SOFFSMASK);
-    *rs -= (lb - (uint32_t)k) / (uint32_t)s;
-    *re = (uint32_t)((key_diag(ka) - qa / (uint32_t)s) & SOFFSMASK);
+    *rs = (uint32_t)((key_diag(kb) - div_s(qb, mg)) & SOFFSMASK);
+    *rs -= div_s(lb - (uint32_t)k, mg);
+    *re = (uint32_t)((key_diag(ka) - div_s(qa, mg)) & SOFFSMASK);
   } else {
-    *rs = (uint32_t)((key_diag(ka) + qa / (uint32_t)s) & SOFFSMASK);
-    *re = (uint32_t)((key_diag(kb) + qb / (uint32_t)s) & SOFFSMASK);
-    *re += (lb - (uint32_t)k) / (uint32_t)s;
+    *rs = (uint32_t)((key_diag(ka) + div_s(qa, mg)) & SOFFSMASK);
+    *re = (uint32_t)((key_diag(kb) + div_s(qb, mg)) & SOFFSMASK);
+    *re += div_s(lb - (uint32_t)k, mg);
   }
 }
 
 // derriveSEGCAND (segment.c:929-1059) over segments [m0, m0 + nseg)
 template <class IT>
-SMG_HD inline int derive_cand_c(SegCand &c, const StrandWork<IT> &w, uint32_t m0, int nseg, int k, int s, uint32_t cover,
+SMG_HD inline int derive_cand_c(SegCand &c, const StrandWork<IT> &w, uint32_t m0, int nseg, int k, uint32_t mg /* div_magic(s) */, uint32_t cover,
                                 uint32_t mincover_noindel, uint32_t hregix, bool is_reverse, int32_t seqidx) {
   const uint64_t offbit = 1ull << (HALFBIT + 1);
-  segm_bounds(w, m0, k, s, is_reverse, &c.qs, &c.qe, &c.rs, &c.re);
+  segm_bounds(w, m0, k, mg, is_reverse, &c.qs, &c.qe, &c.rs, &c.re);
   int64_t shift_min = (int64_t)key_diag(w.dat[w.seed_first[w.segm_first[m0]]]), shift_2mm = shift_min, shift_start, shift_last = shift_min;
   uint32_t maxcover = w.segm_cover[m0], qs, qe, rs, re;
   for (int n = 1; n < nseg; n++) {
     const uint32_t m = m0 + (uint32_t)n;
-    segm_bounds(w, m, k, s, is_reverse, &qs, &qe, &rs, &re);
+    segm_bounds(w, m, k, mg, is_reverse, &qs, &qe, &rs, &re);
     shift_last = (int64_t)key_diag(w.dat[w.seed_first[w.segm_first[m]]]);
     if (w.segm_cover[m] > maxcover) { shift_2mm = shift_last; maxcover = w.segm_cover[m]; }
     if (qs < c.qs) c.qs = qs;
@@ -113,8 +115,8 @@ SMG_HD inline int derive_cand_c(SegCand &c, const StrandWork<IT> &w, uint32_t m0
     if (re > c.re) c.re = re;
   }
   uint8_t flag = 0;
-  if (is_reverse) { flag |= CANDFLG_REVERSE; shift_start = ((int64_t)c.rs) + (int64_t)((c.qe - (uint32_t)k + 1) / (uint32_t)s); }
-  else shift_start = (int64_t)((((uint64_t)c.rs) | offbit) - (uint64_t)(c.qs / (uint32_t)s));
+  if (is_reverse) { flag |= CANDFLG_REVERSE; shift_start = ((int64_t)c.rs) + (int64_t)div_s(c.qe - (uint32_t)k + 1, mg); }
+  else shift_start = (int64_t)((((uint64_t)c.rs) | offbit) - (uint64_t)div_s(c.qs, mg));
   const uint64_t shift_range = (uint64_t)(shift_last - shift_min);
   const int64_t diff_shift = shift_min - shift_start;
   if (shift_range > 32767 || diff_shift < -32768 || diff_shift > 32767) return -1;
@@ -331,6 +333,7 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
   // candidates in segment order: one lane per candidate derives the record (derriveSEGCAND) and writes it once
   uint32_t nc = *ncand_io;
   bool ovf = false;
+  const uint32_t smg = div_magic(s);
   uint32_t pthr = 0;                             // lower bound of the final cover threshold (segment.c:1700-1730)
   if (lw.prune_on) { pthr = lw.prune_mcbm > mx ? 0 : mx - lw.prune_mcbm; if (pthr > mx2) pthr = mx2; }
   SMG_PAR_CHUNKS(base, nsegm) {
@@ -344,7 +347,7 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
       const int32_t seqidx = seqbyseq ? (int32_t)(key_grp(w.dat[w.seed_first[w.segm_first[m]]]) & ((1u << KEY_SEQBITS) - 1)) : -1;
       SegCand c;
       const uint32_t ccover = LONG ? lw.ccov[m] : (uint32_t)w.cflag[m];
-      if (derive_cand_c(c, w, m, (int)(uint32_t)w.reg_num[m], k, s, ccover, mincover, reg_base + lo, is_reverse, seqidx)) err = SMG_ERR_ASSERT;
+      if (derive_cand_c(c, w, m, (int)(uint32_t)w.reg_num[m], k, smg, ccover, mincover, reg_base + lo, is_reverse, seqidx)) err = SMG_ERR_ASSERT;
       if (slot < candcap) { cand[slot] = c; if (!LONG) cover8[slot] = w.cflag[m]; } else ovf = true;     // covers again as a byte array: the S6 filter reads only these
     }
   }
