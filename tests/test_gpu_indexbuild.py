@@ -86,3 +86,14 @@ def test_mapping_through_a_built_image_equals_mapping_through_its_files(oracle_b
     assert out[0][0] == out[1][0]
     assert out[0][1] == out[1][1]
     assert sum(1 for r in out[0][0] if r) > 300
+
+
+def test_index_build_rejects_what_the_reference_rejects():
+    """A sequence shorter than the word length (hashidx.c:499) and word lengths the index types do not cover."""
+    from smalt_amd import api
+    with pytest.raises(api.SmaltGpuError):
+        api.Index.build([b"ACGTACGTACGTACGTACGTACGT" * 50, b"ACGTACG"], ["a", "b"], 13, 6, 0)
+    with pytest.raises(api.SmaltGpuError):
+        api.Index.build([b"ACGT" * 5000], ["a"], 22, 6, 0)
+    ix = api.Index.build([b"ACGT" * 5000], ["a"], 13, 6, 0)       # and a loaded handle cannot be saved, only a built one
+    ix.close()
