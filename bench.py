@@ -195,11 +195,10 @@ def main():
 
     def one_step(collect):
         mapped = total_res = 0
-        pending = []                      # (mapper, n) whose kernels are enqueued and whose results have not been fetched
 
         def fetch(mp, n):
             nonlocal mapped, total_res
-            out = mp.fetch_results()
+            out = mp.fetch_end()
             st = np.ctypeslib.as_array(C.cast(out.stat, C.POINTER(C.c_uint32)), shape=(n, 8))
             mapped += int((st[:, 7] > 0).sum())
             total_res += int(out.res_off[n])
@@ -209,15 +208,20 @@ def main():
                     ms_acc[kk] = ms_acc.get(kk, 0.0) + v
                 for i in range(32):
                     work_acc[i] += wk[i]
+        state = {}                        # mapper -> reads of its batch in flight (kernels enqueued, results not yet fetched)
         for bi, b0 in enumerate(range(0, args.reads, sub)):
             n = min(sub, args.reads - b0)
             mp = mappers[bi % len(mappers)]
-            if len(pending) == len(mappers):          # this mapper still holds the results of its previous sub-batch
-                fetch(*pending.pop(0))
+            prev = state.pop(mp, None)
+            if prev is not None:
+                mp.fetch_begin()                      # waits for the mapper's previous sub-batch, enqueues the copies of its results
             mp.map_batch_device(reads_ascii.data_ptr() + b0 * args.read_len, 0, offs.data_ptr(), n, n * args.read_len, par)
-            pending.append((mp, n))
-        while pending:
-            fetch(*pending.pop(0))
+            state[mp] = n
+            if prev is not None:
+                fetch(mp, prev)                       # results put in read order on the host while the device runs the new sub-batch
+        for mp, n in list(state.items()):
+            mp.fetch_begin()
+            fetch(mp, n)
         return mapped, total_res
 
     import ctypes as C

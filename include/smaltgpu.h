@@ -136,6 +136,11 @@ int smaltgpu_map_batch_device(smaltgpu_mapper *m, const uint8_t *d_bases, const 
                               const uint64_t *d_read_off, uint32_t nreads, uint64_t total_bases,
                               const smaltgpu_params *par);
 int smaltgpu_fetch_results(smaltgpu_mapper *m, smaltgpu_batch_out *out);
+/* The same in two steps, so that the device does not wait for the host between batches: _begin waits for the batch and
+ * enqueues the copies of its results; the next smaltgpu_map_batch_device may follow at once; _end hands the results out
+ * (valid until the next _begin on this mapper). */
+int smaltgpu_fetch_begin(smaltgpu_mapper *m);
+int smaltgpu_fetch_end(smaltgpu_mapper *m, smaltgpu_batch_out *out);
 int smaltgpu_synchronize(smaltgpu_mapper *m);
 
 /* Per-kernel device time (ms, HIP events on the mapper's stream) and work counters of the last

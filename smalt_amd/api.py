@@ -251,6 +251,15 @@ class Mapper:
         _check(lib().smaltgpu_fetch_results(self.h, C.byref(out)))
         return out
 
+    def fetch_begin(self):
+        """Wait for the enqueued batch and start copying its results; the next map_batch_device may follow at once."""
+        _check(lib().smaltgpu_fetch_begin(self.h))
+
+    def fetch_end(self):
+        out = BatchOut()
+        _check(lib().smaltgpu_fetch_end(self.h, C.byref(out)))
+        return out
+
     def timers(self):
         ms = (C.c_double * 32)()
         wk = (C.c_uint64 * 32)()

@@ -243,9 +243,29 @@ struct smaltgpu_mapper {
   uint8_t *align_scr2 = nullptr; size_t align_bytes2 = 0; uint32_t align_slots2 = 0; uint64_t dircap2 = 0;   // second K3 pass: few slots with full-size direction matrices
   uint32_t wincap = 0, rescap_slot = 0, dstrcap_slot = 0; uint64_t dircap = 0;
   // host mirrors
-  std::vector<ReadStat> h_stat;
-  std::vector<Result> h_res;
-  std::vector<uint8_t> h_dstr;
+  // results come back through pinned host memory: the copies are asynchronous, so the next batch can be launched
+  // behind them (smaltgpu_fetch_begin / _end)
+  template <class T> struct Pinned {
+    T *p = nullptr; size_t cap = 0;
+    int ensure(size_t n) {
+      if (n <= cap) return 0;
+      size_t c = cap ? cap : 1024;
+      while (c < n) c += c / 2 + 1;
+      T *q = nullptr;
+      if (hipHostMalloc((void **)&q, c * sizeof(T), hipHostMallocDefault) != hipSuccess) return -1;
+      if (p) (void)hipHostFree(p);
+      p = q; cap = c;
+      return 0;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    T *data() { return p; }
+    T &operator[](size_t i) { return p[i]; }
+  };
+  Pinned<ReadStat> h_stat;
+  Pinned<Result> h_res;
+  Pinned<uint8_t> h_dstr;
+  hipEvent_t ev_fetch = nullptr;
+  uint32_t fetch_n = 0; uint64_t fetch_nres = 0; bool fetch_open = false;
   std::vector<uint64_t> h_res_off;
   std::vector<smaltgpu_result> o_res;
   std::vector<smaltgpu_readstat> o_stat;
@@ -411,6 +431,8 @@ extern "C" void smaltgpu_mapper_free(smaltgpu_mapper *m) {
                 m->b.stat, m->b.rcpool, m->b.long_list, m->b.strip_list, m->strip_bnd, m->strip_win, m->b.respool, m->b.dstrpool, m->d_counters, m->seed_scr, m->cand_scr, m->cand_scr2, m->cand_scr_dbg,
                 m->sw_rows, m->align_scr, m->align_scr2};
   for (void *p : ps) if (p) (void)hipFree(p);
+  m->h_stat.release(); m->h_res.release(); m->h_dstr.release();
+  if (m->ev_fetch) (void)hipEventDestroy(m->ev_fetch);
   for (int i = 0; i <= T_NUM; i++) if (m->ev[i]) (void)hipEventDestroy(m->ev[i]);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
@@ -508,25 +530,42 @@ extern "C" int smaltgpu_map_batch_device(smaltgpu_mapper *m, const uint8_t *d_ba
   return run_pipeline(m, d_bases, d_quals, d_read_off, nreads, par);
 }
 
-extern "C" int smaltgpu_fetch_results(smaltgpu_mapper *m, smaltgpu_batch_out *out) {
-  if (!m || !out) return fail(SMALTGPU_EARG, "null argument");
+// Results in two steps so that a caller can keep the device busy: _begin waits for the batch, reads the pool counters and
+// enqueues the copies to pinned host memory; the next batch may be launched right behind them (same stream: the copies
+// finish first); _end waits for the copies and puts the results in read order.
+extern "C" int smaltgpu_fetch_begin(smaltgpu_mapper *m) {
+  if (!m) return fail(SMALTGPU_EARG, "null argument");
   HIPCHK(hipSetDevice(m->device));
   const uint32_t n = m->last_n;
   uint8_t ctr[512];
+  if (!m->ev_fetch) HIPCHK(hipEventCreate(&m->ev_fetch));
+  if (m->h_stat.ensure(n ? n : 1)) return fail(SMALTGPU_ENOMEM, "pinned host memory");
   HIPCHK(hipMemcpyAsync(ctr, m->d_counters, 512, hipMemcpyDeviceToHost, m->stream));
-  m->h_stat.resize(n ? n : 1);
-  if (n) HIPCHK(hipMemcpyAsync(m->h_stat.data(), m->b.stat, (size_t)n * sizeof(ReadStat), hipMemcpyDeviceToHost, m->stream));
   HIPCHK(hipStreamSynchronize(m->stream));
   const uint32_t rc_count = *(uint32_t *)(ctr + 0);
   const uint64_t nres = *(unsigned long long *)(ctr + 8), ndstr = *(unsigned long long *)(ctr + 16);
   memcpy(m->work, ctr + 64, sizeof(m->work));
   for (int i = 0; i < T_NUM; i++) { float f = 0; (void)hipEventElapsedTime(&f, m->ev[i], m->ev[i + 1]); m->ms[i] = f; }
+  m->fetch_open = false;
   if (rc_count > m->b.rccap) return fail(SMALTGPU_ECAP, "candidate pool overflow (%u > %u): use a smaller batch or SMALTGPU_CANDS_PER_READ", rc_count, m->b.rccap);
   if (nres > m->b.rescap || ndstr > m->b.dstrcap) return fail(SMALTGPU_ECAP, "result pool overflow");
-  m->h_res.resize(nres ? nres : 1);
-  m->h_dstr.resize(ndstr ? ndstr : 1);
-  if (nres) HIPCHK(hipMemcpy(m->h_res.data(), m->b.respool, nres * sizeof(Result), hipMemcpyDeviceToHost));
-  if (ndstr) HIPCHK(hipMemcpy(m->h_dstr.data(), m->b.dstrpool, ndstr, hipMemcpyDeviceToHost));
+  if (m->h_res.ensure(nres ? nres : 1) || m->h_dstr.ensure(ndstr ? ndstr : 1)) return fail(SMALTGPU_ENOMEM, "pinned host memory");
+  if (n) HIPCHK(hipMemcpyAsync(m->h_stat.data(), m->b.stat, (size_t)n * sizeof(ReadStat), hipMemcpyDeviceToHost, m->stream));
+  if (nres) HIPCHK(hipMemcpyAsync(m->h_res.data(), m->b.respool, nres * sizeof(Result), hipMemcpyDeviceToHost, m->stream));
+  if (ndstr) HIPCHK(hipMemcpyAsync(m->h_dstr.data(), m->b.dstrpool, ndstr, hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipEventRecord(m->ev_fetch, m->stream));
+  m->fetch_n = n; m->fetch_nres = nres; m->fetch_open = true;
+  return SMALTGPU_OK;
+}
+
+extern "C" int smaltgpu_fetch_end(smaltgpu_mapper *m, smaltgpu_batch_out *out) {
+  if (!m || !out) return fail(SMALTGPU_EARG, "null argument");
+  if (!m->fetch_open) return fail(SMALTGPU_EARG, "smaltgpu_fetch_begin must precede smaltgpu_fetch_end");
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipEventSynchronize(m->ev_fetch));
+  m->fetch_open = false;
+  const uint32_t n = m->fetch_n;
+  const uint64_t nres = m->fetch_nres;
   // per-read order: results of read i are contiguous in the pool but reads finish in any order;
   // re-pack in read order so that res_off is monotone
   m->h_res_off.assign((size_t)n + 1, 0);
@@ -553,6 +592,13 @@ extern "C" int smaltgpu_fetch_results(smaltgpu_mapper *m, smaltgpu_batch_out *ou
   out->nreads = n; out->res_off = m->h_res_off.data(); out->res = m->o_res.data(); out->diffstr = m->h_dstr.data(); out->stat = m->o_stat.data();
   if (first_err) return fail(first_err, "%u of %u reads hit a device-side limit (-5) or assertion (-6); first: read %u code %d (see stat[].errcode)", nerr, n, first_err_read, first_err);
   return SMALTGPU_OK;
+}
+
+extern "C" int smaltgpu_fetch_results(smaltgpu_mapper *m, smaltgpu_batch_out *out) {
+  if (!m || !out) return fail(SMALTGPU_EARG, "null argument");
+  const int rv = smaltgpu_fetch_begin(m);
+  if (rv) return rv;
+  return smaltgpu_fetch_end(m, out);
 }
 
 extern "C" int smaltgpu_map_batch(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
