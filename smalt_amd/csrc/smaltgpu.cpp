@@ -356,10 +356,21 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
     m->cg.segcap = m->cg.hcap / 2;
     m->cg.candcap = m->cg.hcap;                         // every hit can be a candidate of its own (mincover = k)
     { const char *e = getenv("SMALTGPU_CANDS_WINDOW"); m->cg.window = e ? (uint32_t)atoi(e) : 0; }   // test hook (tests/test_gpu_large.py)
-    { const char *e = getenv("SMALTGPU_CANDS_LDS_HITS"); m->cg.lds_hits = e ? (uint32_t)atoi(e) : (uint32_t)CANDS_LDS_HITS; }   // tuning hook
+    m->cg.tab = m->qmax + 8 < (uint32_t)CANDS_TAB ? m->qmax + 8 : (uint32_t)CANDS_TAB;    // a read has fewer seeds than bases
+    {
+      // Hits of the LDS working set: as many as leave eight workgroups per CU (160 KB / 8 = 20 KB each, less a margin for
+      // the allocation granularity) beside the per-list tables and the LDS copy of the sequence table -- more hits per
+      // window mean fewer windows, fewer resident workgroups cost more (measured: 704-712 best, 736 = seven workgroups
+      // 10 % slower for 150-base reads and 24 sequences).  SMALTGPU_CANDS_LDS_HITS overrides.
+      const size_t seqb = (d.nseq > 0 && d.nseq < 512) ? (((size_t)d.nseq + 1) * 4 + 15) & ~(size_t)15 : 0;
+      const size_t fixed = 64 /* guard */ + seqb + (size_t)5 * m->cg.tab * 4 + 64 + 15 + 256 /* margin */;
+      uint32_t w = fixed + 23 * 256 < 20480 ? (uint32_t)((20480 - fixed) / 23) & ~7u : 256u;
+      if (w < (uint32_t)CANDS_LDS_HITS / 2) w = CANDS_LDS_HITS;            // many sequences: the table does not leave room, accept fewer workgroups
+      const char *e = getenv("SMALTGPU_CANDS_LDS_HITS");
+      m->cg.lds_hits = e ? (uint32_t)atoi(e) : w;
+    }
     if (m->cg.lds_hits < 256) m->cg.lds_hits = 256;
     if (m->cg.lds_hits > 2048) m->cg.lds_hits = 2048;
-    m->cg.tab = m->qmax + 8 < (uint32_t)CANDS_TAB ? m->qmax + 8 : (uint32_t)CANDS_TAB;    // a read has fewer seeds than bases
     m->cg.slot_bytes = m->cand_bytes = cand_slot_bytes(m->cg, m->qmax, d.s);
     memset(&m->cg2, 0, sizeof(m->cg2));
     if (m->cand_bytes > (64ull << 20)) {
