@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--reads", type=int, default=1000000)
     ap.add_argument("--cpu-reads", type=int, default=100000)
     ap.add_argument("--threads", type=int, default=16)
-    ap.add_argument("--gpu-threads", type=int, default=0, help="worker threads of the bound program (0: same as --threads)")
+    ap.add_argument("--gpu-threads", type=int, default=32, help="worker threads of the bound program (0: same as --threads); about twice the cores: most of them wait for their batch")
     ap.add_argument("--nchr", type=int, default=24)
     ap.add_argument("--chr-mbp", type=float, default=125.0)
     ap.add_argument("--read-len", type=int, default=150)
