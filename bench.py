@@ -6,9 +6,12 @@ score pass -> banded traceback) over one batch of synthetic reads that is alread
 HBM.  Default workload = BASELINE.json configs[1]: 1 M x 150 bp single-end Illumina-shape reads
 vs a 3 Gbp synthetic reference (24 x 125 Mbp, 15 % repeat content), k=13 s=6.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); rank 0 builds the index and
-broadcasts the image over xGMI; every rank then maps its own shard of reads (weak scaling, no
-data-path collective).
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  `python bench.py --gpus N` starts
+the N ranks itself (before anything touches HIP); under `torch.distributed.run` it takes the ranks it
+is given.  Rank 0 builds the index with the library's own builder and broadcasts the image over xGMI;
+the ranks then pull sub-batches of the job's reads (BASELINE.json configs[3]: 20 M reads on 8 GPUs =
+2.5 M per GPU) from one shared cursor -- the analogue of the reference's workers pulling read blocks
+from one queue (threads.c:548) -- with no data-path collective (weak scaling: the job grows with N).
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
 """
@@ -28,6 +31,7 @@ sys.path.insert(0, ROOT)
 VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12     # lane-ops/s: 256 CU x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md); a packed 16-bit
                                                   # instruction issues every 4 cycles for 64 lanes x 2 halves = the same 32 cell-ops/clk/SIMD
 HBM_PEAK_GBS = 8000.0
+OPS_PER_CELL_SURVEY = 12.0                        # scalar integer ops per Gotoh cell (1 add, 5 max, 3 sub/add, 1 compare, 2 select/move)
 OPS_PER_CELL = 8.6                                # VALU ops per Gotoh cell of the packed kernel: 8.6 instructions per cell pair
                                                   # (perm, add, max3, add, 2 x (add, max3), 0.6 for the running maximum), each counting as 2 cell-ops
 
@@ -39,14 +43,53 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nchr", type=int, default=24)
     ap.add_argument("--chr-mbp", type=float, default=125.0)
-    ap.add_argument("--reads", type=int, default=1_000_000)
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU and step (default: 1 M at N = 1 = configs[1]; 2.5 M at N > 1 = configs[3]'s 20 M / 8)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--sub-batch", type=int, default=262144)
     ap.add_argument("--streams", type=int, default=1, help="mappers (HIP streams) that take the sub-batches in turn: kernels of consecutive sub-batches overlap")
+    ap.add_argument("--static-shards", action="store_true", help="N > 1: contiguous shard per rank instead of the shared sub-batch cursor")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-buffers", action="store_true", help="also time smaltgpu_map_batch on pageable host buffers (PCIe-inclusive rate, extra field)")
+    ap.add_argument("--no-host-buffers", action="store_true", help="skip the extra PCIe-inclusive measurement of smaltgpu_map_batch on pageable host buffers")
     ap.add_argument("--cpu-sample", type=int, default=150000)
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) from a parent that has not
+    touched HIP (no torch import yet) and leave with their status.  Rank 0 prints the JSON line."""
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            st = p.poll()
+            if st is None:
+                continue
+            live.remove(p)
+            if st != 0 and rc == 0:
+                rc = st
+                for q in live:            # a rank died: the others would wait in a collective for ever
+                    q.terminate()
+    return rc
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(args, ref_pack, idx, pos, sop, names, k, s, reads_ascii, nreads, rlen, gix=None):
@@ -57,7 +100,14 @@ def cpu_baseline(args, ref_pack, idx, pos, sop, names, k, s, reads_ascii, nreads
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get('SMALT_BENCH_CPU_THREADS', '16'))))   # the GPU box's CPU share per GPU
+    try:                                                     # a container's CPU quota counts too (cgroup v2: "<quota> <period>" or "max")
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    host_cores = cores                                       # every core this process may run on (the box's share per GPU)
+    cores = max(1, int(os.environ.get('SMALT_BENCH_CPU_THREADS', cores)))
     from smalt_amd import indexfile
     n2 = min(args.cpu_sample, nreads)
     n1 = max(n2 // 10, 1000)
@@ -91,8 +141,8 @@ def cpu_baseline(args, ref_pack, idx, pos, sop, names, k, s, reads_ascii, nreads
             mapped = len({ln.split()[1] for ln in open(os.path.join(tmp, "o.cig")) if ln.startswith("cigar:")})
             dt = max(t2 - t1, 1e-6)      # the index load (same in both runs) cancels
             rate = (n2 - n1) / dt * (mapped / n2)
-            return dict(value=rate, unit="mapped reads/s", cores=cores, kind="reference",
-                        sample="smalt map -n %d on the first %d vs %d reads of the bench batch (slope: index load cancels), same index files; %.1f s + %.1f s wall"
+            return dict(value=rate, unit="mapped reads/s", cores=cores, host_cores=host_cores, cpu_model=cpu_model(), kind="reference",
+                        sample="smalt map -n %d (all cores this process may use) on the first %d vs %d reads of the bench batch (slope: index load cancels), same index files; %.1f s + %.1f s wall"
                         % (cores, n1, n2, t1, t2))
         # port: the oracle's C restatement, single thread
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -112,8 +162,20 @@ def cpu_baseline(args, ref_pack, idx, pos, sop, names, k, s, reads_ascii, nreads
                     sample="oracle C restatement, 1 thread, first %d reads of the bench batch, %.1f s" % (n, dt))
 
 
+class _DevArray:
+    """A device array of the library seen through __cuda_array_interface__, so that torch.distributed can broadcast the
+    index image the library built without a copy."""
+
+    def __init__(self, ptr, n, typestr="<i4"):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))            # before torch / HIP are touched in this process
+    import ctypes as C
+
     import torch
     import torch.distributed as dist
     from smalt_amd import api, gpuindex, shard
@@ -121,13 +183,33 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()           # does not initialise HIP
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # nccl = RCCL over xGMI; SMALT_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1 path
-        dist.init_process_group(backend=os.environ.get("SMALT_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        # nccl = RCCL over xGMI, one rank per GPU.  With fewer GPUs than ranks (rehearsal on a one-GPU box) the ranks share
+        # devices and RCCL cannot be used: gloo carries the same collectives.  SMALT_BENCH_BACKEND overrides.
+        backend = os.environ.get("SMALT_BENCH_BACKEND", "nccl" if ndev >= world else "gloo")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if os.environ.get("SMALT_BENCH_DRYRUN"):   # tests/test_shard_gloo.py: launcher, rendezvous and the shared cursor without a device
+        dealer = shard.BatchDealer(23, static=args.static_shards)
+        dealer.start("dry")
+        got = []
+        while True:
+            j = dealer.next()
+            if j is None:
+                break
+            got.append(j)
+        parts = shard.gather_in_rank_order(got)
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "dry_run": True, "backend": backend, "dealt": parts}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    local = local % max(1, torch.cuda.device_count())
+    local = local % max(1, ndev)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     k, s = 13, 6
@@ -136,64 +218,80 @@ def main():
     sop = np.arange(nchr + 1, dtype=np.int64) * chrlen
     names = ["chr%d" % (i + 1) for i in range(nchr)]
     tot = int(sop[-1])
+    per_gpu = args.reads or (1_000_000 if world == 1 else 2_500_000)      # configs[1]; configs[3]: 20 M reads / 8 GPUs
+    job_reads = per_gpu * world
 
-    # ---- setup (untimed): reference + index image in HBM; rank 0 builds, RCCL broadcast ----
+    # ---- setup (untimed): reference + index image in HBM.  Rank 0 builds the index with the library's builder
+    # (smaltgpu_index_build_device) and broadcasts the image (RCCL over xGMI for N > 1) ----
     t0 = time.time()
-    image = {}
-    # small references (4^k > 2 * bases / s) get the collision-type index: every rank builds it from the broadcast
-    # reference with the library's own builder (smaltgpu_index_build_device); the default 3 Gbp reference gets the perfect
-    # type and its image is broadcast as a whole
-    native_build = 4 ** k > 2 * (tot // s)
+    image, meta, gix0, build_ms = {}, None, None, 0.0
     if rank == 0:
         ref = gpuindex.make_reference_gpu(nchr, chrlen, 20261004, dev)
-        if native_build:
-            image = {"ref": ref}
-        else:
-            packed = gpuindex.pack_reference(ref)
-            idx, pos = gpuindex.build_perfect_index(ref, sop, k, s)
-            image = {"idx": idx, "pos": pos, "packed": packed, "ref": ref}
-    image, bcast_s = shard.broadcast_image(image, dev, 0, order=("ref",) if native_build else ("idx", "pos", "packed", "ref"))     # RCCL over xGMI for N > 1
-    ref = image["ref"]
-    idx, pos, packed = (None, None, None) if native_build else (image["idx"], image["pos"], image["packed"])
-    bcast_ms = bcast_s * 1e3
-    gix = None
-    if native_build:
         lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
         ascii_ref = lut[ref.long()]
-        gix = api.Index.build_device(ascii_ref.data_ptr(), [int(x) for x in sop], names, k, s, local)
+        gix0 = api.Index.build_device(ascii_ref.data_ptr(), [int(x) for x in sop], names, k, s, local)
+        build_ms = gix0.build_ms
         del ascii_ref
-    # reads of this rank (weak scaling: every rank maps args.reads reads of its own)
-    torch.cuda.synchronize()
-    t_idx = time.time() - t0
-    reads_ascii, _ = gpuindex.make_reads_gpu(ref, sop, args.reads, args.read_len, 777 + rank)
-    del ref
-    torch.cuda.synchronize()
-    setup_s = time.time() - t0
+        if world > 1:
+            d0 = gix0.info()
+            nkeys = 1 << (2 * k if d0.typ == 0 else d0.nbits_key)
+            image = {"idx": torch.as_tensor(_DevArray(d0.idx, nkeys + 1), device=dev), "pos": torch.as_tensor(_DevArray(d0.pos, d0.npos), device=dev),
+                     "packed": torch.as_tensor(_DevArray(d0.packed, tot // 10 + 1), device=dev), "ref": ref}
+            if d0.typ != 0:
+                image["wordidx"] = torch.as_tensor(_DevArray(d0.wordidx, d0.nwords + 1), device=dev)
+                image["posidx"] = torch.as_tensor(_DevArray(d0.posidx, d0.nwords + 1), device=dev)
+            meta = [d0.typ, d0.nbits_key, d0.nbits_lo, d0.npos, d0.nwords]
+    bcast_ms = 0.0
+    if world > 1:
+        ml = [meta]
+        dist.broadcast_object_list(ml, 0)
+        meta = ml[0]
+        order = ("idx", "pos", "packed", "ref") + (("wordidx", "posidx") if meta[0] != 0 else ())
+        image, bcast_s = shard.broadcast_image(image, dev, 0, order=order)
+        bcast_ms = bcast_s * 1e3
+        ref = image["ref"]
     if rank == 0:
-        print("[bench] setup: reference+index %.1f s, reads %.1f s" % (t_idx, setup_s - t_idx), file=sys.stderr, flush=True)
-
-    if gix is None:
+        gix = gix0
+    else:                                       # the other ranks adopt the broadcast arrays (kept alive by `image`)
         desc = api.IndexDesc()
-        desc.k, desc.s, desc.typ, desc.nbits_key, desc.nbits_lo = k, s, 0, 2 * k, 0
-        desc.npos, desc.nwords = int(pos.numel()), 0
-        desc.idx, desc.pos, desc.packed = idx.data_ptr(), pos.data_ptr(), packed.data_ptr()
-        desc.wordidx = desc.posidx = None
+        desc.k, desc.s, desc.typ, desc.nbits_key, desc.nbits_lo, desc.npos, desc.nwords = k, s, meta[0], meta[1], meta[2], meta[3], meta[4]
+        desc.idx, desc.pos, desc.packed = image["idx"].data_ptr(), image["pos"].data_ptr(), image["packed"].data_ptr()
+        desc.wordidx = image["wordidx"].data_ptr() if meta[0] != 0 else None
+        desc.posidx = image["posidx"].data_ptr() if meta[0] != 0 else None
         desc.nseq = nchr
         sop_u64 = np.ascontiguousarray(sop.astype(np.uint64))
         desc.sop = sop_u64.ctypes.data
         desc.on_device = 1
         gix = api.Index.from_desc(desc, local)
+    torch.cuda.synchronize()
+    t_idx = time.time() - t0
+    # Reads of the whole job on every rank (3 GB for 20 M reads), generated in chunks of one GPU's share: any rank can
+    # then take any sub-batch from the shared cursor.  Chunk 0 is the N = 1 workload.
+    if args.static_shards:
+        chunks = {rank: gpuindex.make_reads_gpu(ref, sop, per_gpu, args.read_len, 777 + rank)[0]}
+    else:
+        chunks = {c: gpuindex.make_reads_gpu(ref, sop, per_gpu, args.read_len, 777 + c)[0] for c in range(world)}
+    del ref
+    torch.cuda.synchronize()
+    setup_s = time.time() - t0
+    if rank == 0:
+        print("[bench] setup: reference+index %.1f s (index construction on the device %.1f ms), reads %.1f s" % (t_idx, build_ms, setup_s - t_idx), file=sys.stderr, flush=True)
+
     par = gix.default_params()
-    sub = min(args.sub_batch, args.reads)
+    sub = min(args.sub_batch, per_gpu)
     os.environ.setdefault("SMALTGPU_CANDS_PER_READ", "768")
     mappers = [api.Mapper(gix, sub, args.read_len) for _ in range(max(1, args.streams))]
     mapper = mappers[0]
     offs = torch.arange(sub + 1, dtype=torch.int64, device=dev) * args.read_len
     torch.cuda.synchronize()
+    nsub_chunk = (per_gpu + sub - 1) // sub
+    # sub-batch j of the job = sub-batch j % nsub_chunk of chunk j // nsub_chunk; static shards: the rank's own chunk
+    dealer = shard.BatchDealer(nsub_chunk * world, static=args.static_shards)
 
     ms_acc, work_acc = {}, [0] * 32
+    mine = {"reads": 0, "launches": 0}
 
-    def one_step(collect):
+    def one_step(collect, tag):
         mapped = total_res = 0
 
         def fetch(mp, n):
@@ -208,14 +306,23 @@ def main():
                     ms_acc[kk] = ms_acc.get(kk, 0.0) + v
                 for i in range(32):
                     work_acc[i] += wk[i]
+                mine["reads"] += n
+                mine["launches"] += 1
         state = {}                        # mapper -> reads of its batch in flight (kernels enqueued, results not yet fetched)
-        for bi, b0 in enumerate(range(0, args.reads, sub)):
-            n = min(sub, args.reads - b0)
+        dealer.start(tag)
+        bi = 0
+        while True:
+            j = dealer.next()
+            if j is None:
+                break
+            c, b0 = j // nsub_chunk, (j % nsub_chunk) * sub
+            n = min(sub, per_gpu - b0)
             mp = mappers[bi % len(mappers)]
+            bi += 1
             prev = state.pop(mp, None)
             if prev is not None:
                 mp.fetch_begin()                      # waits for the mapper's previous sub-batch, enqueues the copies of its results
-            mp.map_batch_device(reads_ascii.data_ptr() + b0 * args.read_len, 0, offs.data_ptr(), n, n * args.read_len, par)
+            mp.map_batch_device(chunks[c].data_ptr() + b0 * args.read_len, 0, offs.data_ptr(), n, n * args.read_len, par)
             state[mp] = n
             if prev is not None:
                 fetch(mp, prev)                       # results put in read order on the host while the device runs the new sub-batch
@@ -224,35 +331,38 @@ def main():
             fetch(mp, n)
         return mapped, total_res
 
-    import ctypes as C
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for w in range(args.warmup):
         tw = time.time()
-        one_step(False)
+        one_step(False, "w%d" % w)
         if rank == 0:
             print("[bench] warmup step %.2f s" % (time.time() - tw), file=sys.stderr, flush=True)
     barrier()
     t1 = time.time()
     mapped = 0
-    for _ in range(args.steps):
-        m_, _r = one_step(True)
+    for st_ in range(args.steps):
+        m_, _r = one_step(True, "s%d" % st_)
         mapped += m_
     barrier()
     dt = time.time() - t1
-    dt, (mapped_all,) = shard.reduce_step(dt, [mapped], dev)      # max over ranks, whole-job count
+    if world == 1:
+        mapped_all, reads_min, reads_max = mapped, mine["reads"], mine["reads"]
+    else:
+        dt, (mapped_all, reads_min, reads_max) = _reduce(shard, dist, torch, dt, mapped, mine["reads"], dev)
 
     if rank == 0:
         value = mapped_all / dt
-        nlaunch = args.steps * ((args.reads + sub - 1) // sub)
+        nlaunch = max(1, mine["launches"])            # rank 0's own launches: the kernel figures below are rank 0's
+        my_reads = max(1, mine["reads"])
         dom = max(ms_acc, key=lambda kk: ms_acc[kk])
         cells = work_acc[2]
         sw_ms = ms_acc.get("sw_full", 0.0)
-        sw_tops = cells * OPS_PER_CELL / (sw_ms * 1e-3) / 1e12 if sw_ms > 0 else 0.0
+        tcups = cells / (sw_ms * 1e-3) / 1e12 if sw_ms > 0 else 0.0
+        sw_tops = tcups * OPS_PER_CELL
         seed_bytes = work_acc[0] * 8 + work_acc[1] * 12
         seed_ms = ms_acc.get("seed", 0.0) + ms_acc.get("cands", 0.0)
         seed_gbs = seed_bytes / (seed_ms * 1e-3) / 1e9 if seed_ms > 0 else 0.0
@@ -264,20 +374,31 @@ def main():
             traffic_seed = sum(pt["kernels"][kk]["fetch"] + pt["kernels"][kk]["write"] for kk in ("seed", "cands")) * sc
         except Exception:
             pass
+        # Two units for the same time: `frac_issue` counts the VALU instructions the kernel issues per cell (8.6 per cell
+        # pair, two cell-ops each; verified in the gfx950 ISA) against the measured issue peak -- the fraction of the machine
+        # in use; `frac_survey` counts SURVEY 8(d)'s 12 scalar ops per Gotoh cell against the same peak and exceeds 1 because
+        # v_pk_maximum3 does two of those ops (and two cells) per instruction.  `frac` is the issue figure.
         roof_sw = dict(kernel="k_sw_full16", bound="valu", achieved=sw_tops, peak=VALU_PEAK_TOPS, unit="TOP/s",
-                       frac=sw_tops / VALU_PEAK_TOPS, traffic=traffic_sw, gcups=cells / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else 0.0,
-                       avg_launch_ms=sw_ms / nlaunch, cells_per_launch=cells / nlaunch)
+                       frac=sw_tops / VALU_PEAK_TOPS, frac_issue=sw_tops / VALU_PEAK_TOPS, ops_per_cell_issue=OPS_PER_CELL,
+                       frac_survey=tcups * OPS_PER_CELL_SURVEY / VALU_PEAK_TOPS, ops_per_cell_survey=OPS_PER_CELL_SURVEY,
+                       peak_note="256 CU x 4 SIMD x 32 lane-ops/clk x 2.4 GHz; packed 16-bit, max3 and perm issue at half rate with two halves each (profiles/r02_valu_rate.txt)",
+                       traffic=traffic_sw, gcups=tcups * 1e3, avg_launch_ms=sw_ms / nlaunch, cells_per_launch=cells / nlaunch)
         roof_seed = dict(kernel="k_seed+k_cands", bound="hbm", achieved=seed_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
                          frac=seed_gbs / HBM_PEAK_GBS, traffic=traffic_seed, avg_launch_ms=seed_ms / nlaunch,
                          bytes_per_launch=seed_bytes / nlaunch)
+        wl = ("configs[1]: %d x %d bp single-end reads" % (per_gpu, args.read_len)) if world == 1 else \
+             ("configs[3]: %d x %d bp single-end reads on %d GPUs (%d per GPU)" % (job_reads, args.read_len, world, per_gpu))
         line = {
             "metric": "mapped reads/sec (1Mx150bp vs 3Gbp ref)", "value": value, "unit": "mapped reads/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",      # K2a: packed half floats holding exact integer scores
-            "config": {"workload": "configs[1]: %d x %d bp single-end reads per GPU vs %d x %.0f Mbp synthetic reference (15%% repeats), k=%d s=%d, best-only"
-                       % (args.reads, args.read_len, nchr, args.chr_mbp, k, s),
-                       "reads_per_gpu_per_step": args.reads, "sub_batch": sub, "mapped_fraction": mapped_all / (world * args.steps * args.reads),
-                       "reads_per_s_total": world * args.steps * args.reads / dt, "setup_s": setup_s, "index_broadcast_ms": bcast_ms,
+            "config": {"workload": "%s vs %d x %.0f Mbp synthetic reference (15%% repeats), k=%d s=%d, best-only" % (wl, nchr, args.chr_mbp, k, s),
+                       "reads_per_gpu_per_step": per_gpu, "job_reads_per_step": job_reads, "sub_batch": sub,
+                       "mapped_fraction": mapped_all / (args.steps * job_reads),
+                       "reads_per_s_total": args.steps * job_reads / dt, "setup_s": setup_s, "index_build_ms": build_ms,
+                       "index_broadcast_ms": bcast_ms, "backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
+                       "dealing": "static shards" if args.static_shards or world == 1 else "shared sub-batch cursor (c10d store)",
+                       "reads_taken_min_max_per_rank": [reads_min / args.steps, reads_max / args.steps],
                        "parallelism": "read-shard x%d" % world, "streams": len(mappers)},
             "roofline": roof_sw if dom in ("sw_full",) else roof_seed,
             "roofline_sw": roof_sw, "roofline_seed": roof_seed,
@@ -288,30 +409,37 @@ def main():
             "cands_phase_ticks": sum(work_acc[8:17]),
             "cands_windows": {"hits_in_windowed_strands": work_acc[20], "window_gather_share": round(work_acc[21] / max(1, sum(work_acc[8:17])), 4),
                               "table_build_share": round(work_acc[19] / max(1, sum(work_acc[8:17])), 4), "hbm_fallback_strands": work_acc[22]},
-            "cands_per_read": work_acc[5] / max(1, world * args.steps * args.reads), "kept_per_read": work_acc[6] / max(1, world * args.steps * args.reads),
-            "long_window_tasks_per_read": work_acc[17] / max(1, world * args.steps * args.reads), "ranked_per_read": work_acc[3] / max(1, world * args.steps * args.reads), "scored_in_reference_order_per_read": work_acc[4] / max(1, world * args.steps * args.reads),
-            "hits_per_read": work_acc[1] / max(1, world * args.steps * args.reads),
+            "cands_per_read": work_acc[5] / my_reads, "kept_per_read": work_acc[6] / my_reads,
+            "long_window_tasks_per_read": work_acc[17] / my_reads, "ranked_per_read": work_acc[3] / my_reads, "scored_in_reference_order_per_read": work_acc[4] / my_reads,
+            "hits_per_read": work_acc[1] / my_reads,
         }
-        if args.host_buffers:       # the boundary's host-buffer entry point: H2D of the reads + D2H of the results inside the timing
-            hb = reads_ascii[:sub * args.read_len].cpu().numpy()
+        if not args.no_host_buffers:       # the boundary's host-buffer entry point: H2D of the reads + D2H of the results inside the timing
+            hb = chunks[0][:sub * args.read_len].cpu().numpy()
             ho = (np.arange(sub + 1, dtype=np.uint64) * np.uint64(args.read_len))
             mapper.map_batch_raw(hb, ho, None, par)
             th = time.time()
             mapper.map_batch_raw(hb, ho, None, par)
-            line["host_buffers"] = {"reads_per_s": sub / (time.time() - th), "reads": sub, "note": "PCIe-inclusive, not `value`"}
+            line["host_buffers"] = {"reads_per_s": sub / (time.time() - th), "reads": sub, "note": "smaltgpu_map_batch on pageable host buffers, PCIe-inclusive, one batch at a time; not `value`"}
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
             try:
-                line["cpu_baseline"] = cpu_baseline(args, None if native_build else packed.cpu().numpy(), None if native_build else idx.cpu().numpy(),
-                                                    None if native_build else pos.cpu().numpy(), sop, names, k, s,
-                                                    reads_ascii.cpu().numpy(), args.reads, args.read_len, gix)
+                line["cpu_baseline"] = cpu_baseline(args, None, None, None, sop, names, k, s, chunks[0].cpu().numpy(), per_gpu, args.read_len, gix)
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 line["cpu_baseline"] = dict(value=None, unit="mapped reads/s", cores=0, kind="reference", sample="failed: %r" % (e,))
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     for mp_ in mappers:
         mp_.close()
     gix.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def _reduce(shard, dist, torch, dt, mapped, my_reads, dev):
+    """max step time over ranks, whole-job mapped count, and the spread of reads the ranks took from the cursor"""
+    dt, (mapped_all,) = shard.reduce_step(dt, [mapped], dev)
+    t = torch.tensor([float(my_reads), -float(my_reads)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return dt, (mapped_all, -float(t[1].item()), float(t[0].item()))
 
 
 if __name__ == "__main__":

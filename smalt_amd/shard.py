@@ -84,3 +84,40 @@ def gather_in_rank_order(obj):
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, obj)
     return out
+
+
+class BatchDealer:
+    """One cursor over the sub-batches of a job, shared by all ranks: a rank that finishes early takes the next sub-batch
+    instead of idling behind a repeat-rich shard.  This is the reference's scheme -- its worker threads pull read blocks
+    from one FIFO (threads.c:548 tprocf) -- with the c10d key-value store of the process group as the queue head (an
+    atomic add on the host side; no collective, nothing on the data path).  Without a process group it is a plain local
+    counter.  `static=True` deals contiguous shards instead (shard_bounds), e.g. when the ranks hold different reads."""
+
+    def __init__(self, nbatches: int, static: bool = False):
+        import torch.distributed as dist
+        self.n = int(nbatches)
+        self.static = static
+        self.rank, self.world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+        self.store = None
+        if self.world > 1 and not static:
+            from torch.distributed import distributed_c10d as c10d
+            self.store = dist.PrefixStore("smalt_deal", c10d._get_default_store())
+        self.key = None
+        self.local = 0
+        self.hi = 0
+
+    def start(self, tag: str) -> None:
+        """Begin a pass over the job; `tag` must be the same on all ranks and unique per pass."""
+        self.key = "pass/%s" % tag
+        if self.store is None:
+            self.local, self.hi = shard_bounds(self.n, self.rank, self.world) if self.world > 1 else (0, self.n)
+
+    def next(self):
+        """Index of the next sub-batch for this rank, or None when the job is dealt out."""
+        if self.store is None:
+            if self.local >= self.hi:
+                return None
+            self.local += 1
+            return self.local - 1
+        i = self.store.add(self.key, 1) - 1
+        return i if i < self.n else None

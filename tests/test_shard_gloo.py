@@ -110,3 +110,26 @@ def test_two_rank_sharded_mapping_matches_single_process(oracle_built, tmp_path)
         p.join(300)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert ret.get(timeout=5) == "ok"
+
+
+def test_bench_starts_its_own_ranks_and_deals_sub_batches():
+    """`python bench.py --gpus 2` (no launcher) must itself produce two ranks; the shared cursor deals every sub-batch
+    exactly once.  Dry run: stops before the device is needed."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, SMALT_BENCH_DRYRUN="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    for extra in ([], ["--static-shards"]):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + extra, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads(out.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 2 and line["backend"] == "gloo"
+        a, b = line["dealt"]
+        assert sorted(a + b) == list(range(23)) and a and b
+        if extra:
+            assert a == list(range(12)) and b == list(range(12, 23))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")], env=env, capture_output=True, text=True, timeout=300)
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["dealt"] == [list(range(23))]
