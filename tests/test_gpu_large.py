@@ -245,3 +245,36 @@ def test_edge_batches(oracle_built, tmp_path):
     finally:
         mp.close()
         gix.close()
+
+
+def test_8kbp_reads_match_oracle(oracle_built, tmp_path):
+    """BASELINE configs[4] at its real read length: 8 kbp sources with 3/5/4 % substitutions/insertions/deletions
+    (PacBio shape), k=20 s=13, both strands, one exact copy (narrow bands: K2b) -- the 8-strip K2a kernel, K3 strips of
+    >= 1024 columns and the two-pass candidate / direction-matrix slots, against the oracle read by read."""
+    from smalt_amd import api, synth
+    ch = synth.make_reference(3, 700_000, seed=71, repeat_frac=0.1, n_fam=3, cons_len=400, divergence=0.05)
+    seqs = [synth.codes_to_ascii(c) for c in ch]
+    reads, _ = synth.make_long_reads(ch, 7, 8000, seed=72, sub=0.03, ins=0.05, dele=0.04)
+    rb = [synth.codes_to_ascii(r) for r in reads]
+    rb.append(seqs[1][300_000:308_000])                    # error-free 8 kbp read
+    assert min(len(r) for r in rb) > 7800
+    oix0 = ol.build_index(seqs, ["c%d" % i for i in range(3)], 20, 13)
+    pre = str(tmp_path / "l8k")
+    assert ol.lib().or_index_write(oix0, pre.encode()) == 0
+    oix = ol.lib().or_index_read(pre.encode())
+    exp = _oracle_map_all(oix, rb, ol.default_params(oix))
+    gix = api.Index.load(pre, 0)
+    mp = api.Mapper(gix, len(rb), max(len(r) for r in rb))
+    try:
+        res, stats = mp.map_batch(rb, [b"5" * len(r) for r in rb], gix.default_params())
+        ms, _ = mp.timers()
+        print("8 kbp kernel ms:", {k_: round(v, 2) for k_, v in ms.items()})
+    finally:
+        mp.close()
+        gix.close()
+    for i in range(len(rb)):
+        assert stats[i]["err"] == 0
+        assert res[i], i
+        assert res[i] == exp[i][0], i
+        for kk, v in exp[i][1].items():
+            assert stats[i][kk] == v, (i, kk)
