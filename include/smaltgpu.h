@@ -22,7 +22,8 @@ enum {
   SMALTGPU_EFILE = -2,      /* cannot read .smi/.sma (ERRCODE_NOFILE / FILEFORM analogue) */
   SMALTGPU_EARG = -3,       /* bad argument (ERRCODE_ARGRANGE analogue) */
   SMALTGPU_ENOMEM = -4,     /* host or device allocation failed (ERRCODE_NOMEM) */
-  SMALTGPU_ECAP = -5,       /* a per-batch work pool overflowed; retry with a smaller batch */
+  SMALTGPU_ECAP = -5,       /* a work pool overflowed: smaltgpu_map_batch recovers by itself (reads re-mapped in smaller batches);
+                             * from smaltgpu_fetch_* / in stat[].errcode it marks the reads to map again */
   SMALTGPU_EINTERNAL = -6   /* device-side assertion (ERRCODE_ASSERT analogue) */
 };
 
@@ -99,6 +100,11 @@ typedef struct smaltgpu_batch_out {
 /* ---- index (replaces hashTableRead hashidx.c:1257 + seqSetReadBinFil sequence.c:2521) ---- */
 int smaltgpu_index_load(smaltgpu_index **out, const char *prefix, int device);
 int smaltgpu_index_create(smaltgpu_index **out, const smaltgpu_index_desc *desc, int device);
+/* A copy of the image on another device of the node, device to device (hipMemcpyPeer: xGMI), instead of a second load from
+ * disk: the reference's worker threads share one read-only HashTable/SeqSet (threads.c:793-985, rmap.h:83); with one image
+ * per GPU the others are filled from the first.  (One process per GPU: broadcast the arrays of smaltgpu_index_info with
+ * RCCL and adopt them with smaltgpu_index_create, as bench.py does.) */
+int smaltgpu_index_clone(smaltgpu_index **out, const smaltgpu_index *src, int device);
 void smaltgpu_index_free(smaltgpu_index *ix);
 int smaltgpu_index_info(const smaltgpu_index *ix, smaltgpu_index_desc *desc_out); /* device pointers */
 void smaltgpu_params_default(smaltgpu_params *p, const smaltgpu_index *ix);
@@ -119,6 +125,17 @@ int smaltgpu_index_save(const smaltgpu_index *ix, const char *prefix);
 /* ---- mapper (replaces rmapCreate rmap.c:1511 / rmapDelete :1597) ---- */
 int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_index *ix, uint32_t max_batch_reads,
                            uint32_t max_read_len);
+/* Same with sizing options (0 = default): the RMap's buffers grow on demand (array.c), the mapper's pools are sized once.
+ * cands_per_read: ranked candidates per read of the batch-wide pool (default 640 for large batches; the depth cut of
+ * segment.c:1745-1775 leaves ~270 on a human-size reference, at most 2048).  slot_budget_gb: HBM for the scratch slots of
+ * the persistent kernels (default 64) -- lower it when several mappers share a device.  A batch that overflows a pool is
+ * not an error: smaltgpu_map_batch re-maps the reads that did not fit in smaller batches. */
+typedef struct smaltgpu_mapper_opts {
+  uint32_t cands_per_read;
+  uint32_t slot_budget_gb;
+} smaltgpu_mapper_opts;
+int smaltgpu_mapper_create_ex(smaltgpu_mapper **out, const smaltgpu_index *ix, uint32_t max_batch_reads,
+                              uint32_t max_read_len, const smaltgpu_mapper_opts *opts);
 void smaltgpu_mapper_free(smaltgpu_mapper *m);
 
 /* Map a block of reads (the unit processArgBlock smalt.c:1221 hands to a worker).  `bases`:

@@ -6,6 +6,7 @@
  * of the C ABI; nothing of the reference is needed here. */
 #include <pthread.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -21,22 +22,39 @@ typedef struct {
   const smaltgpu_params *par;
   GpuCombOut *out;
   int done, rv;
+  char err[256];                /* smaltgpu_last_error() is per thread: the leader copies its message to every request */
 } CombReq;
+
+/* tuning switches, read from the environment ONCE (pthread_once) before any batch: worker threads never call setenv, and
+ * getenv only happens here */
+static struct { uint32_t combine_reads; int nslot; } g_cfg = { COMB_MAXREADS, 2 };
+static pthread_once_t g_cfg_once = PTHREAD_ONCE_INIT;
+static void read_cfg(void)
+{
+  const char *e;
+  if ((e = getenv("SMALTGPU_COMBINE_READS")) && atoi(e) > 0) g_cfg.combine_reads = (uint32_t)atoi(e);
+  if ((e = getenv("SMALTGPU_COMBINE_SLOTS")) && atoi(e) >= 1 && atoi(e) <= 4) g_cfg.nslot = atoi(e);
+}
 
 /* one mapper (HIP stream) with its staging buffers; a device has COMB_NSLOT of them so that one batch is packed,
  * copied and unpacked while another one runs */
 enum { COMB_NSLOT = 4 };                          /* capacity; SMALTGPU_COMBINE_SLOTS (default 2) of them are used */
-static int g_nslot = 2;
+#define g_nslot (g_cfg.nslot)
 struct CombSlot {
   int busy;
   smaltgpu_mapper *mp; uint32_t cap_reads, cap_len;
   char *bases, *quals; uint64_t *off; size_t basecap;
 };
-static struct CombDev {
+/* ONE queue of pending worker blocks for all devices -- the reference's workers pull blocks from one FIFO (threads.c:548);
+ * here whichever device has a free mapper slot takes the next cohort, so a device that got repeat-rich reads does not
+ * hold the others up (no static assignment of threads to devices). */
+static struct CombQueue {
   pthread_mutex_t mu; pthread_cond_t cv; int init;
   CombReq *pending[COMB_MAXREQ]; int npending; int assembling;      /* assembling: a leader is collecting requests */
-  struct CombSlot slot[COMB_NSLOT];
-} g_dev[COMB_MAXDEV];
+  int ndev; const smaltgpu_index *ix[COMB_MAXDEV];
+  struct CombSlot slot[COMB_MAXDEV][COMB_NSLOT];
+  unsigned long batches[COMB_MAXDEV];                                /* combined batches run per device (diagnostic, SMALTGPU_COMBINE_STATS) */
+} g_q;
 static pthread_mutex_t g_init = PTHREAD_MUTEX_INITIALIZER;
 
 static int grow(void **p, size_t *cap, size_t need, size_t elem)
@@ -67,12 +85,13 @@ static void run_batch(struct CombSlot *d, const smaltgpu_index *ix, CombReq **re
     uint32_t cr = d->cap_reads > 16384 ? d->cap_reads : 16384, cl = d->cap_len > 64 ? d->cap_len : 64;
     while (cr < ntot) cr *= 2;
     if (cl < maxlen) cl = (maxlen + 31u) & ~31u;
-    pthread_mutex_lock(&g_init);                         /* mapper creation reads the environment: one at a time */
+    smaltgpu_mapper_opts opts = { 1024, 0 };             /* ranked candidates per read of the shared pools (the default sizing is for large batches) */
+    pthread_mutex_lock(&g_init);                         /* one mapper at a time */
     if (d->mp) smaltgpu_mapper_free(d->mp);
     d->mp = NULL;
     free(d->off);
     d->off = malloc(((size_t)cr + 1) * sizeof(uint64_t));
-    if (!d->off || smaltgpu_mapper_create(&d->mp, ix, cr, cl)) rv = SMALTGPU_ENOMEM;
+    if (!d->off || smaltgpu_mapper_create_ex(&d->mp, ix, cr, cl, &opts)) rv = SMALTGPU_ENOMEM;
     else { d->cap_reads = cr; d->cap_len = cl; }
     pthread_mutex_unlock(&g_init);
   }
@@ -95,7 +114,11 @@ static void run_batch(struct CombSlot *d, const smaltgpu_index *ix, CombReq **re
     }
     d->off[k] = pos;
     rv = smaltgpu_map_batch(d->mp, (const uint8_t *)d->bases, has_qual ? (const uint8_t *)d->quals : NULL, d->off, ntot, reqs[0]->par, &o);
+    /* pool overflows are recovered inside the library; what can remain is a read that fails on its own (stat[].errcode):
+     * the batch is complete for every other read, so hand the slices out and let the owner of that read report it */
+    if ((rv == SMALTGPU_ECAP || rv == SMALTGPU_EINTERNAL) && o.nreads == ntot) rv = 0;
   }
+  if (rv) for (i = 0; i < nreq; i++) { strncpy(reqs[i]->err, smaltgpu_last_error(), sizeof(reqs[i]->err) - 1); reqs[i]->err[sizeof(reqs[i]->err) - 1] = 0; }
   for (i = 0, r0 = 0; i < nreq; i++) {                    /* every request gets its own copy of its slice */
     CombReq *q = reqs[i];
     GpuCombOut *w = q->out;
@@ -124,33 +147,37 @@ static void run_batch(struct CombSlot *d, const smaltgpu_index *ix, CombReq **re
   }
 }
 
-int gpuCombineSubmit(int dev, const smaltgpu_index *ix, const char *bases, const char *quals, const uint64_t *off, uint32_t n,
-                     const smaltgpu_params *par, GpuCombOut *out)
+int gpuCombineSubmit(int ndev, const smaltgpu_index *const *ixs, const char *bases, const char *quals, const uint64_t *off, uint32_t n,
+                     const smaltgpu_params *par, GpuCombOut *out, char *errbuf, size_t errcap)
 {
-  struct CombDev *d;
+  struct CombQueue *d = &g_q;
   CombReq req;
-  if (dev < 0 || dev >= COMB_MAXDEV || !n) return SMALTGPU_EARG;
-  d = &g_dev[dev];
+  if (ndev < 1 || ndev > COMB_MAXDEV || !ixs || !n) return SMALTGPU_EARG;
+  pthread_once(&g_cfg_once, read_cfg);
   pthread_mutex_lock(&g_init);
   if (!d->init) {
-    pthread_mutex_init(&d->mu, NULL); pthread_cond_init(&d->cv, NULL); d->init = 1;
-    setenv("SMALTGPU_CANDS_PER_READ", "1024", 0);        /* ranked candidates per read of the shared pools (default sizing is for large batches) */
-    if (getenv("SMALTGPU_COMBINE_SLOTS")) { const int v = atoi(getenv("SMALTGPU_COMBINE_SLOTS")); if (v >= 1 && v <= COMB_NSLOT) g_nslot = v; }
+    int i;
+    pthread_mutex_init(&d->mu, NULL); pthread_cond_init(&d->cv, NULL);
+    d->ndev = ndev;
+    for (i = 0; i < ndev; i++) d->ix[i] = ixs[i];
+    d->init = 1;
   }
   pthread_mutex_unlock(&g_init);
-  req.bases = bases; req.quals = quals; req.off = off; req.n = n; req.par = par; req.out = out; req.done = 0; req.rv = 0;
+  req.bases = bases; req.quals = quals; req.off = off; req.n = n; req.par = par; req.out = out; req.done = 0; req.rv = 0; req.err[0] = 0;
   pthread_mutex_lock(&d->mu);
   while (d->npending >= COMB_MAXREQ) pthread_cond_wait(&d->cv, &d->mu);
   d->pending[d->npending++] = &req;
   pthread_cond_broadcast(&d->cv);
   while (!req.done) {
-    int sl = -1, u;
-    if (!d->assembling && d->npending > 0) for (u = 0; u < g_nslot; u++) if (!d->slot[u].busy) { sl = u; break; }     /* (a waiting thread may lead a batch of others) */
+    int sl = -1, dv = -1, u, v;
+    /* (a waiting thread may lead a batch of others)  first slot of every device before the second slot of any */
+    if (!d->assembling && d->npending > 0)
+      for (u = 0; u < g_nslot && sl < 0; u++) for (v = 0; v < d->ndev; v++) if (!d->slot[v][u].busy) { sl = u; dv = v; break; }
     if (sl >= 0) {
       CombReq *take[COMB_MAXREQ];
       int ntake = 0, i, rounds;
       uint32_t reads = 0;
-      d->assembling = 1; d->slot[sl].busy = 1;
+      d->assembling = 1; d->slot[dv][sl].busy = 1;
       for (rounds = 0; rounds < 8; rounds++) {              /* let the other workers arrive: up to 8 x 250 us while requests keep coming */
         struct timespec ts;
         const int before = d->npending;
@@ -160,7 +187,7 @@ int gpuCombineSubmit(int dev, const smaltgpu_index *ix, const char *bases, const
         (void)pthread_cond_timedwait(&d->cv, &d->mu, &ts);
         if (d->npending == before) break;
       }
-      const uint32_t maxreads = getenv("SMALTGPU_COMBINE_READS") ? (uint32_t)atoi(getenv("SMALTGPU_COMBINE_READS")) : (uint32_t)COMB_MAXREADS;
+      const uint32_t maxreads = g_cfg.combine_reads;
       for (i = 0; i < d->npending; i++) {
         if (ntake && reads + d->pending[i]->n > maxreads) break;
         reads += d->pending[i]->n; take[ntake++] = d->pending[i];
@@ -170,13 +197,19 @@ int gpuCombineSubmit(int dev, const smaltgpu_index *ix, const char *bases, const
       d->assembling = 0;                                     /* the next leader may collect while this batch runs */
       pthread_cond_broadcast(&d->cv);
       pthread_mutex_unlock(&d->mu);
-      if (ntake) run_batch(&d->slot[sl], ix, take, ntake);
+      if (ntake) run_batch(&d->slot[dv][sl], d->ix[dv], take, ntake);
       pthread_mutex_lock(&d->mu);
       for (i = 0; i < ntake; i++) take[i]->done = 1;
-      d->slot[sl].busy = 0;
+      if (ntake) d->batches[dv]++;
+      d->slot[dv][sl].busy = 0;
       pthread_cond_broadcast(&d->cv);
     } else pthread_cond_wait(&d->cv, &d->mu);
   }
   pthread_mutex_unlock(&d->mu);
+  if (errbuf && errcap > 64 && !req.rv && getenv("SMALTGPU_COMBINE_STATS")) {    /* diagnostic: batches per device so far */
+    int i, w = 0;
+    for (i = 0; i < d->ndev && w + 24 < (int)errcap; i++) w += snprintf(errbuf + w, errcap - (size_t)w, "%sdev%d=%lu", i ? " " : "", i, d->batches[i]);
+  }
+  if (req.rv && errbuf && errcap) { strncpy(errbuf, req.err, errcap - 1); errbuf[errcap - 1] = 0; }
   return req.rv;
 }

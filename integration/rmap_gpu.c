@@ -32,7 +32,9 @@ enum { GPU_MAXMAPPERS = 256 };
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 enum { GPU_MAXDEV = 16 };
 static smaltgpu_index *g_ixdev[GPU_MAXDEV];      /* one index image per device, shared by the mappers on it */
-static int g_ndev = 0;
+static int g_ndev = 0, g_nphys = 0;              /* index images (logical devices) and GPUs present */
+static int g_combine = 1;                        /* SMALTGPU_NO_COMBINE unset */
+static const char *g_prefix = NULL;              /* SMALTGPU_INDEX_PREFIX */
 #define g_ix (g_ixdev[0])
 static struct {
   const RMap *rmp; smaltgpu_mapper *mp; uint32_t maxlen, maxreads;
@@ -42,6 +44,19 @@ static struct {
 } g_map[GPU_MAXMAPPERS];
 static int g_nmap = 0;
 
+/* the environment is read once, before any mapper exists; worker threads never call setenv */
+static pthread_once_t g_once = PTHREAD_ONCE_INIT;
+static void gpuReadConfig(void)
+{
+  const char *e = getenv("SMALTGPU_NDEV");       /* worker threads are dealt round-robin to the devices (SMALTGPU_NDEV limits them) */
+  g_combine = !getenv("SMALTGPU_NO_COMBINE");
+  g_prefix = getenv("SMALTGPU_INDEX_PREFIX");
+  g_nphys = g_ndev = smaltgpu_device_count();
+  if (e && atoi(e) > 0) g_ndev = atoi(e);        /* more than there are GPUs: images share devices (rehearsal of the N-device path on one GPU) */
+  if (g_ndev > GPU_MAXDEV) g_ndev = GPU_MAXDEV;
+  if (g_nphys < 1) g_ndev = 0;
+}
+
 static int gpuMapperFor(const RMap *rmp, uint32_t rlen);
 static int gpuMapperForBatch(const RMap *rmp, uint32_t rlen, uint32_t nreads, size_t nbases, int need_mapper);
 
@@ -50,19 +65,18 @@ static int gpuMapperFor(const RMap *rmp, uint32_t rlen) { return gpuMapperForBat
 static int gpuMapperForBatch(const RMap *rmp, uint32_t rlen, uint32_t nreads, size_t nbases, int need_mapper)
 {
   int i, slot = -1;
+  pthread_once(&g_once, gpuReadConfig);
   pthread_mutex_lock(&g_lock);
-  if (!g_ndev) {                    /* worker threads are dealt round-robin to the devices (SMALTGPU_NDEV limits them) */
-    const char *e = getenv("SMALTGPU_NDEV");
-    g_ndev = smaltgpu_device_count();
-    if (e && atoi(e) > 0 && atoi(e) < g_ndev) g_ndev = atoi(e);
-    if (g_ndev > GPU_MAXDEV) g_ndev = GPU_MAXDEV;
-    if (g_ndev < 1) { g_ndev = 0; pthread_mutex_unlock(&g_lock); return -1; }
-  }
+  if (g_ndev < 1) { pthread_mutex_unlock(&g_lock); return -1; }
   for (i = 0; i < g_nmap; i++) if (g_map[i].rmp == rmp) { slot = i; break; }
   if (slot < 0 && g_nmap < GPU_MAXMAPPERS) { slot = g_nmap++; memset(&g_map[slot], 0, sizeof(g_map[slot])); g_map[slot].rmp = rmp; }
-  if (slot >= 0 && !g_ixdev[slot % g_ndev]) {
-    const char *prefix = getenv("SMALTGPU_INDEX_PREFIX");
-    if (!prefix || smaltgpu_index_load(&g_ixdev[slot % g_ndev], prefix, slot % g_ndev)) { pthread_mutex_unlock(&g_lock); return -1; }
+  if (slot >= 0 && !g_ixdev[0]) {
+    /* the index files are read ONCE, into the first GPU; the other images are copied from it device to device
+     * (smaltgpu_index_clone: hipMemcpyPeer over xGMI) -- the workers of the reference share one read-only index */
+    int dv;
+    if (!g_prefix || smaltgpu_index_load(&g_ixdev[0], g_prefix, 0)) { pthread_mutex_unlock(&g_lock); return -1; }
+    for (dv = 1; dv < g_ndev; dv++)
+      if (smaltgpu_index_clone(&g_ixdev[dv], g_ixdev[0], dv % g_nphys)) { pthread_mutex_unlock(&g_lock); return -1; }
   }
   pthread_mutex_unlock(&g_lock);
   if (slot < 0) return -1;
@@ -78,11 +92,11 @@ static int gpuMapperForBatch(const RMap *rmp, uint32_t rlen, uint32_t nreads, si
   } else if (!g_map[slot].mp || g_map[slot].maxlen < rlen || g_map[slot].maxreads < nreads) {
     uint32_t cap = g_map[slot].maxlen > 64 ? g_map[slot].maxlen : 64, rcap = g_map[slot].maxreads > 1 ? g_map[slot].maxreads : 1;
     if (cap < rlen) cap = (rlen + 31u) & ~31u;                /* scratch is sized by the longest read */
-    setenv("SMALTGPU_SLOT_BUDGET_GB", "6", 0);            /* one mapper per worker thread shares the device */
+    smaltgpu_mapper_opts opts = { 0, 6 };                 /* one mapper per worker thread shares the device: 6 GB of scratch slots each */
     while (rcap < nreads) rcap *= 2;
     if (g_map[slot].mp) smaltgpu_mapper_free(g_map[slot].mp);
     g_map[slot].mp = NULL;
-    if (smaltgpu_mapper_create(&g_map[slot].mp, g_ixdev[slot % g_ndev], rcap, cap)) return -1;
+    if (smaltgpu_mapper_create_ex(&g_map[slot].mp, g_ixdev[slot % g_ndev], rcap, cap, &opts)) return -1;
     g_map[slot].maxlen = cap; g_map[slot].maxreads = rcap;
     free(g_map[slot].off);
     if (!(g_map[slot].off = malloc(((size_t)rcap + 1) * sizeof(uint64_t)))) return -1;
@@ -167,7 +181,8 @@ int rmapGpuBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, int n, int 
   short mismatchscor, gapinitscor, gapextscor, matchscor;
   smaltgpu_params par;
   for (i = 0; i < n; i++) { (void)seqFastqGetConstSequence(reads[i], &rlen, &cod); tot += rlen; if (rlen > maxlen) maxlen = rlen; }
-  const int combine = !getenv("SMALTGPU_NO_COMBINE");       /* default: blocks of all worker threads form one GPU batch */
+  pthread_once(&g_once, gpuReadConfig);
+  const int combine = g_combine;                             /* default: blocks of all worker threads form one GPU batch */
   if ((slot = gpuMapperForBatch(rmp, maxlen, (uint32_t)n, tot, !combine)) < 0) { fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error()); ERRMSGNO(errmsgp, ERRCODE_FAILURE); }
   for (i = 0, tot = 0; i < n; i++) {
     const char *seqp = seqFastqGetConstSequence(reads[i], &rlen, &cod);
@@ -190,17 +205,22 @@ int rmapGpuBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, int n, int 
   g_map[slot].nbatch = 0;
   g_map[slot].use_comb = combine;
   if (combine) {
-    if (gpuCombineSubmit(slot % g_ndev, g_ixdev[slot % g_ndev], g_map[slot].bases, has_qual ? g_map[slot].quals : NULL, g_map[slot].off,
-                         (uint32_t)n, &par, &g_map[slot].comb)) {
-      fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error());
+    char emsg[256] = "";
+    if (gpuCombineSubmit(g_ndev, (const smaltgpu_index *const *)g_ixdev, g_map[slot].bases, has_qual ? g_map[slot].quals : NULL, g_map[slot].off,
+                         (uint32_t)n, &par, &g_map[slot].comb, emsg, sizeof(emsg))) {
+      fprintf(stderr, "smaltgpu: %s\n", emsg);
       ERRMSGNO(errmsgp, ERRCODE_FAILURE);
     }
     g_map[slot].out.nreads = (uint32_t)n; g_map[slot].out.res_off = g_map[slot].comb.res_off; g_map[slot].out.res = g_map[slot].comb.res;
     g_map[slot].out.diffstr = g_map[slot].comb.dstr; g_map[slot].out.stat = g_map[slot].comb.stat;
-  } else if (smaltgpu_map_batch(g_map[slot].mp, (const uint8_t *)g_map[slot].bases, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
-                         g_map[slot].off, (uint32_t)n, &par, &g_map[slot].out)) {
-    fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error());
-    ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+  } else {
+    const int rv = smaltgpu_map_batch(g_map[slot].mp, (const uint8_t *)g_map[slot].bases, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
+                                      g_map[slot].off, (uint32_t)n, &par, &g_map[slot].out);
+    /* a read that fails on its own leaves its code in stat[].errcode; rmapGpuFinish reports it for that read */
+    if (rv && !((rv == SMALTGPU_ECAP || rv == SMALTGPU_EINTERNAL) && g_map[slot].out.nreads == (uint32_t)n)) {
+      fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error());
+      ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+    }
   }
   g_map[slot].nbatch = n;
   return ERRCODE_SUCCESS;

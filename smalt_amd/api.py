@@ -50,6 +50,10 @@ class ReadStat(C.Structure):
                 ("errcode", C.c_int32), ("nres", C.c_uint32)]
 
 
+class MapperOpts(C.Structure):
+    _fields_ = [("cands_per_read", C.c_uint32), ("slot_budget_gb", C.c_uint32)]
+
+
 class BatchOut(C.Structure):
     _fields_ = [("nreads", C.c_uint32), ("res_off", C.POINTER(C.c_uint64)), ("res", C.POINTER(Result)),
                 ("diffstr", C.POINTER(C.c_uint8)), ("stat", C.POINTER(ReadStat))]
@@ -82,6 +86,8 @@ def lib():
         L.smaltgpu_index_info.argtypes = [C.c_void_p, C.POINTER(IndexDesc)]
         L.smaltgpu_params_default.argtypes = [C.POINTER(Params), C.c_void_p]
         L.smaltgpu_mapper_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32, C.c_uint32]
+        L.smaltgpu_mapper_create_ex.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(MapperOpts)]
+        L.smaltgpu_index_clone.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
         L.smaltgpu_mapper_free.argtypes = [C.c_void_p]
         L.smaltgpu_map_batch.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint32,
                                          C.POINTER(Params), C.POINTER(BatchOut)]
@@ -159,6 +165,12 @@ class Index:
         ix.build_ms = float(ms.value)
         return ix
 
+    def clone(self, device: int) -> "Index":
+        """A second image on `device`, copied device to device (xGMI) from this one."""
+        h = C.c_void_p()
+        _check(lib().smaltgpu_index_clone(C.byref(h), self.h, device))
+        return Index(h)
+
     def save(self, prefix: str) -> None:
         """Write <prefix>.sma / <prefix>.smi, byte-compatible with the reference's index files."""
         _check(lib().smaltgpu_index_save(self.h, prefix.encode()))
@@ -182,10 +194,11 @@ class Index:
 class Mapper:
     """Work buffers + stream for one host thread (the analogue of an RMap, rmap.h:83)."""
 
-    def __init__(self, index: Index, max_batch_reads: int, max_read_len: int):
+    def __init__(self, index: Index, max_batch_reads: int, max_read_len: int, cands_per_read: int = 0, slot_budget_gb: int = 0):
         self.index = index
         self.h = C.c_void_p()
-        _check(lib().smaltgpu_mapper_create(C.byref(self.h), index.h, max_batch_reads, max_read_len))
+        opts = MapperOpts(cands_per_read, slot_budget_gb)
+        _check(lib().smaltgpu_mapper_create_ex(C.byref(self.h), index.h, max_batch_reads, max_read_len, C.byref(opts)))
 
     def close(self):
         if self.h:

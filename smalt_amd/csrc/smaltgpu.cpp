@@ -62,7 +62,9 @@ static int upload(smaltgpu_index *ix, const T *host, size_t n, const T **dev) {
 
 extern "C" int smaltgpu_index_create(smaltgpu_index **out, const smaltgpu_index_desc *ds, int device) {
   if (!out || !ds || !ds->idx || !ds->pos || !ds->sop || !ds->packed) return fail(SMALTGPU_EARG, "null argument");
-  if (ds->k < 1 || ds->k > 21 || ds->s < 1 || ds->nseq < 1 || ds->nseq >= (1 << KEY_SEQBITS))
+  // Any number of sequences: only the sequence-by-sequence mode packs a sequence number into the hit sort key (KEY_SEQBITS),
+  // and that mode is limited to fewer than 512 sequences as in the reference (smalt.c:599; check_par).
+  if (ds->k < 1 || ds->k > 21 || ds->s < 1 || ds->nseq < 1 || ds->nseq > 0x7ffffffeLL)
     return fail(SMALTGPU_EARG, "unsupported index geometry (k=%d s=%d nseq=%lld)", ds->k, ds->s, (long long)ds->nseq);
   HIPCHK(hipSetDevice(device));
   smaltgpu_index *ix = new smaltgpu_index();
@@ -106,11 +108,49 @@ extern "C" int smaltgpu_index_load(smaltgpu_index **out, const char *prefix, int
   return smaltgpu_index_create(out, &ds, device);
 }
 
+// A second image of an index on another device, copied device to device (xGMI between the GPUs of a node) instead of being
+// read from disk and uploaded again: the reference's worker threads share ONE read-only index (threads.c:793-985, rmapCreate
+// receives the same HashTable/SeqSet pointers); with one image per GPU the images are filled from the first one.
+extern "C" int smaltgpu_index_clone(smaltgpu_index **out, const smaltgpu_index *src, int device) {
+  if (!out || !src) return fail(SMALTGPU_EARG, "null argument");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(SMALTGPU_EARG, "no device %d", device);
+  const DevIndex &d = src->d;
+  const uint32_t *sp[5] = {d.idx, d.pos, d.typ != IDX_PERFECT ? d.wordidx : nullptr, d.typ != IDX_PERFECT ? d.posidx : nullptr, d.packed};
+  const size_t sn[5] = {(size_t)d.nkeys + 1, (size_t)d.npos, (size_t)d.nwords + 1, (size_t)d.nwords + 1, (size_t)(d.totlen / 10 + 1)};
+  uint32_t *dp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  HIPCHK(hipSetDevice(device));
+  if (device != src->device) {                     // direct access between the two GPUs (ignored when already enabled or not available: the copy is then staged by the runtime)
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) { const hipError_t e = hipDeviceEnablePeerAccess(src->device, 0); if (e != hipSuccess) (void)hipGetLastError(); }
+  }
+  int rv = 0;
+  for (int i = 0; i < 5 && !rv; i++) {
+    if (!sp[i]) continue;
+    if (hipMalloc((void **)&dp[i], (sn[i] ? sn[i] : 1) * 4) != hipSuccess) { rv = fail(SMALTGPU_ENOMEM, "device memory for the index copy"); break; }
+    if (sn[i] && hipMemcpyPeer(dp[i], device, sp[i], src->device, sn[i] * 4) != hipSuccess) rv = fail(SMALTGPU_ENODEV, "device-to-device copy of the index failed");
+  }
+  smaltgpu_index *ix = nullptr;
+  if (!rv) {
+    smaltgpu_index_desc ds;
+    memset(&ds, 0, sizeof(ds));
+    ds.k = d.k; ds.s = d.s; ds.typ = d.typ; ds.nbits_key = d.nbits_key; ds.nbits_lo = d.nbits_lo; ds.npos = d.npos; ds.nwords = d.nwords;
+    ds.idx = dp[0]; ds.pos = dp[1]; ds.wordidx = dp[2]; ds.posidx = dp[3]; ds.packed = dp[4]; ds.nseq = d.nseq; ds.sop = src->sop.data(); ds.on_device = 1;
+    rv = smaltgpu_index_create(&ix, &ds, device);
+  }
+  if (rv) { for (uint32_t *p : dp) if (p) (void)hipFree(p); return rv; }
+  for (uint32_t *p : dp) if (p && ix->nbufs < 8) ix->bufs[ix->nbufs++] = p;      // adopted: freed with the index
+  ix->names = src->names; ix->maxpos = src->maxpos; ix->built = src->built;
+  *out = ix;
+  return SMALTGPU_OK;
+}
+
 // ---- index construction on the device (smg_indexbuild.hip) ----
 extern "C" int smaltgpu_index_build_device(smaltgpu_index **out, int device, const uint8_t *d_bases, const uint64_t *seq_off, const char *const *names,
                                            int64_t nseq, int32_t k, int32_t s, float *build_ms) {
   if (!out || !d_bases || !seq_off || !names) return fail(SMALTGPU_EARG, "null argument");
-  if (k < 1 || k > 21 || s < 1 || nseq < 1 || nseq >= (1 << KEY_SEQBITS)) return fail(SMALTGPU_EARG, "unsupported index geometry (k=%d s=%d nseq=%lld)", k, s, (long long)nseq);
+  if (k < 1 || k > 21 || s < 1 || nseq < 1 || nseq > 0x7ffffffeLL) return fail(SMALTGPU_EARG, "unsupported index geometry (k=%d s=%d nseq=%lld)", k, s, (long long)nseq);
   for (int64_t i = 0; i < nseq; i++) if (seq_off[i + 1] - seq_off[i] > 0x7fffffffull) return fail(SMALTGPU_EARG, "sequence %lld is longer than 2^31-1 bases (hashidx.c:592)", (long long)i);
   HIPCHK(hipSetDevice(device));
   BuiltIndex b;
@@ -125,6 +165,9 @@ extern "C" int smaltgpu_index_build_device(smaltgpu_index **out, int device, con
   if (rv) { (void)hipFree(b.idx); (void)hipFree(b.pos); (void)hipFree(b.wordidx); (void)hipFree(b.posidx); (void)hipFree(b.packed); return rv; }
   void *own[5] = {b.idx, b.pos, b.wordidx, b.posidx, b.packed};      // adopted: freed with the index
   for (void *p : own) if (p && ix->nbufs < 8) ix->bufs[ix->nbufs++] = p;
+  // The reference's reader takes only 2 * nwords + 1 of the collision words (hashidx.c:1257; smg_indexfile.hpp), so a loaded
+  // index runs with posidx[nwords] == 0; the built image must behave the same.  smaltgpu_index_save writes npos there.
+  if (b.typ != IDX_PERFECT && b.posidx) HIPCHK(hipMemset(b.posidx + b.nwords, 0, 4));
   ix->maxpos = b.maxpos; ix->built = true;
   for (int64_t i = 0; i < nseq; i++) ix->names.emplace_back(names[i] ? names[i] : "");
   if (build_ms) *build_ms = b.build_ms;
@@ -182,7 +225,7 @@ extern "C" int smaltgpu_index_save(const smaltgpu_index *ix, const char *prefix)
   fp = fopen((std::string(prefix) + ".smi").c_str(), "wb");
   if (!fp) return fail(SMALTGPU_EFILE, "cannot write %s.smi", prefix);
   ok = container(fp, totsiz, 2, 3, g) && put_dev(fp, d.idx, (size_t)d.nkeys + 1) && put_dev(fp, d.pos, d.npos);
-  if (ok && d.typ != IDX_PERFECT) ok = put_dev(fp, d.wordidx, (size_t)d.nwords + 1) && put_dev(fp, d.posidx, (size_t)d.nwords + 1);
+  if (ok && d.typ != IDX_PERFECT) ok = put_dev(fp, d.wordidx, (size_t)d.nwords + 1) && put_dev(fp, d.posidx, (size_t)d.nwords) && fwrite(&d.npos, 4, 1, fp) == 1;   // posidx[nwords] = npos in the file (hashidx.c:989)
   ok = (fclose(fp) == 0) && ok;
   if (!ok) return fail(SMALTGPU_EFILE, "short write to %s.smi", prefix);
   return SMALTGPU_OK;
@@ -242,6 +285,7 @@ struct smaltgpu_mapper {
   uint8_t *align_scr = nullptr; size_t align_bytes = 0; uint32_t align_slots = 0;
   uint8_t *align_scr2 = nullptr; size_t align_bytes2 = 0; uint32_t align_slots2 = 0; uint64_t dircap2 = 0;   // second K3 pass: few slots with full-size direction matrices
   uint32_t wincap = 0, rescap_slot = 0, dstrcap_slot = 0; uint64_t dircap = 0;
+  uint32_t rescap_slot2 = 0, dstrcap_slot2 = 0;       // result slots of the second K3 pass (reads with more alignments than a first-pass slot holds)
   // host mirrors
   // results come back through pinned host memory: the copies are asynchronous, so the next batch can be launched
   // behind them (smaltgpu_fetch_begin / _end)
@@ -265,7 +309,9 @@ struct smaltgpu_mapper {
   Pinned<Result> h_res;
   Pinned<uint8_t> h_dstr;
   hipEvent_t ev_fetch = nullptr;
-  uint32_t fetch_n = 0; uint64_t fetch_nres = 0; bool fetch_open = false;
+  uint32_t fetch_n = 0; uint64_t fetch_nres = 0; bool fetch_open = false, pool_overflow = false;
+  // smaltgpu_map_batch after a pool overflow: results of the whole batch assembled from several device batches
+  std::vector<smaltgpu_result> fin_res; std::vector<uint8_t> fin_dstr; std::vector<smaltgpu_readstat> fin_stat; std::vector<uint64_t> fin_off;
   std::vector<uint64_t> h_res_off;
   std::vector<smaltgpu_result> o_res;
   std::vector<smaltgpu_readstat> o_stat;
@@ -274,6 +320,7 @@ struct smaltgpu_mapper {
   MapPar last_par;
   bool have_host_off = false;
   int debug = 0;
+  uint64_t remap_batches = 0;               // device batches smaltgpu_map_batch ran to recover from pool overflows (diagnostic)
   hipEvent_t ev[T_NUM + 1] = {nullptr};
   double ms[T_NUM] = {0};
   unsigned long long work[WK_NWORK] = {0};
@@ -288,7 +335,13 @@ static int dalloc(T **p, size_t n) {
 static uint32_t next_pow2(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
 
 extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_index *ix, uint32_t max_batch_reads, uint32_t max_read_len) {
+  return smaltgpu_mapper_create_ex(out, ix, max_batch_reads, max_read_len, nullptr);
+}
+
+extern "C" int smaltgpu_mapper_create_ex(smaltgpu_mapper **out, const smaltgpu_index *ix, uint32_t max_batch_reads, uint32_t max_read_len,
+                                         const smaltgpu_mapper_opts *opts) {
   if (!out || !ix || !max_batch_reads || !max_read_len) return fail(SMALTGPU_EARG, "bad argument");
+  const uint32_t opt_cands = opts ? opts->cands_per_read : 0, opt_budget = opts ? opts->slot_budget_gb : 0;
   if (max_read_len >= (1u << KEY_QBITS)) return fail(SMALTGPU_EARG, "reads longer than %u bases are not supported", (1u << KEY_QBITS) - 1);
   HIPCHK(hipSetDevice(ix->device));
   smaltgpu_mapper *m = new smaltgpu_mapper();
@@ -310,12 +363,14 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
   DA(b.qmask, 2 * (size_t)max_batch_reads * m->qmax);
   DA(b.ch, max_batch_reads); DA(b.ctl, max_batch_reads); DA(b.stat, max_batch_reads);
   {
-    const char *e = getenv("SMALTGPU_CANDS_PER_READ");
-    uint64_t per = e ? strtoull(e, nullptr, 10) : 640;      // ranked candidates per read: the depth cut leaves 270 on average at 3 Gbp, at most 2048
+    const char *e = getenv("SMALTGPU_CANDS_PER_READ");        // the environment overrides the caller's option (test hook)
+    const bool sized = e || opt_cands;
+    uint64_t per = e ? strtoull(e, nullptr, 10) : (opt_cands ? opt_cands : 640);      // ranked candidates per read: the depth cut leaves 270 on average at 3 Gbp, at most 2048
     if (per < 8) per = 8;
     if (per > 2048) per = 2048;
     uint64_t cap = (uint64_t)max_batch_reads * per;
-    if (max_batch_reads <= 4096 && !e) cap = (uint64_t)max_batch_reads * 2048;
+    if (max_batch_reads <= 4096 && !sized) cap = (uint64_t)max_batch_reads * 2048;
+    if (cap < (uint64_t)MAXIMUM_DEPTH) cap = MAXIMUM_DEPTH;      // one read alone always fits: smaltgpu_map_batch re-maps the reads of an overflowing batch in smaller batches
     if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
     b.rccap = (uint32_t)cap;
   }
@@ -328,7 +383,9 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
   b.rescap = (uint64_t)max_batch_reads * 8 + 4096;
   DA(b.respool, b.rescap);
   b.dstrcap = b.rescap * (uint64_t)(m->qmax / 4 + 48);
+  if (b.dstrcap > 0xFFFFFFF0ull) b.dstrcap = 0xFFFFFFF0ull;    // smaltgpu_result.stroffs is 32 bits wide: a batch that needs more reports SMALTGPU_ECAP and is re-mapped in parts
   DA(b.dstrpool, b.dstrcap);
+  DA(b.align_retry, max_batch_reads);
   DA(m->d_counters, 512);
   if (!rv) {
     b.rc_count = (uint32_t *)(m->d_counters + 0);
@@ -336,6 +393,7 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
     b.dstr_count = (unsigned long long *)(m->d_counters + 16);
     b.err_flag = (int32_t *)(m->d_counters + 24);
     b.next_item = (uint32_t *)(m->d_counters + 32);
+    b.align_retry_n = (uint32_t *)(m->d_counters + 56);
     b.work = (unsigned long long *)(m->d_counters + 64);
   }
   // scratch geometry -------------------------------------------------------------------
@@ -388,7 +446,8 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
       } else { memset(&m->cg2, 0, sizeof(m->cg2)); m->cand_bytes2 = 0; }
     }
     uint64_t budget = 64ull << 30;     // of 288 GB: more slots than resident workgroups lets the hardware balance uneven reads
-    if (const char *e = getenv("SMALTGPU_SLOT_BUDGET_GB")) { const long g = atol(e); if (g > 0) budget = (uint64_t)g << 30; }   // many mappers on one device
+    if (opt_budget) budget = (uint64_t)opt_budget << 30;              // many mappers on one device
+    if (const char *e = getenv("SMALTGPU_SLOT_BUDGET_GB")) { const long g = atol(e); if (g > 0) budget = (uint64_t)g << 30; }
     uint64_t slots = budget / m->cand_bytes;
     if (slots > 2048) slots = 2048;                     // LDS admits 4 workgroups per CU: 1024 run at a time
     if (slots < 64) slots = 64;
@@ -406,6 +465,9 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
     DA(m->strip_win, (size_t)m->strip_grid * m->wincap * 2);      // code pairs of the packed strip kernel
     m->dircap = (uint64_t)(m->qmax + 64) * (m->wincap + 8);
     m->rescap_slot = 512; m->dstrcap_slot = 512 * (m->qmax / 4 + 48);
+    // second pass: a few slots that hold the alignments of any read (up to MAXIMUM_DEPTH candidates, each of which may split)
+    m->rescap_slot2 = 2 * MAXIMUM_DEPTH; m->dstrcap_slot2 = m->rescap_slot2 * (m->qmax / 4 + 48);
+    m->dircap2 = m->dircap;
     if (m->dircap > (4ull << 20)) {
       // Long reads: a full direction matrix (read x window) is 10-300 MB, a band rarely needs a tenth of it.  The many
       // slots of the first pass hold a sixteenth; a read whose band does not fit is deferred to a second pass over a
@@ -413,14 +475,15 @@ extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_inde
       m->dircap2 = m->dircap;
       m->dircap = m->dircap / 16 > (4ull << 20) ? m->dircap / 16 : (4ull << 20);
       if (const char *e = getenv("SMALTGPU_ALIGN_DIRCAP")) { const long v = atol(e); if (v >= 4096 && (uint64_t)v < m->dircap2) m->dircap = (uint64_t)v; }   // test hook
-      m->align_bytes2 = align_scratch_bytes(m->qmax, m->wincap, m->dircap2, m->rescap_slot, m->dstrcap_slot);
-      m->align_slots2 = max_batch_reads < 16 ? max_batch_reads : 16;
-      DA(m->align_scr2, m->align_bytes2 * m->align_slots2);
     }
+    m->align_bytes2 = align_scratch_bytes(m->qmax, m->wincap, m->dircap2, m->rescap_slot2, m->dstrcap_slot2);
+    m->align_slots2 = max_batch_reads < 16 ? max_batch_reads : 16;
+    DA(m->align_scr2, m->align_bytes2 * m->align_slots2);
     m->align_bytes = align_scratch_bytes(m->qmax, m->wincap, m->dircap, m->rescap_slot, m->dstrcap_slot);
     uint64_t budget = 8ull << 30;
     if (m->align_bytes * 512 > budget) budget = m->align_bytes * 512;      // long reads: direction matrices of 10-300 MB per slot
     if (budget > (48ull << 30)) budget = 48ull << 30;
+    if (opt_budget && ((uint64_t)opt_budget << 30) < budget) budget = (uint64_t)opt_budget << 30;
     if (const char *e = getenv("SMALTGPU_SLOT_BUDGET_GB")) { const uint64_t g = (uint64_t)atol(e) << 30; if (g > 0 && g < budget) budget = g; }
     uint64_t slots = budget / m->align_bytes;
     if (slots > 8192) slots = 8192;
@@ -439,7 +502,7 @@ extern "C" void smaltgpu_mapper_free(smaltgpu_mapper *m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   void *ps[] = {m->d_bases, m->d_quals, m->d_codes, m->d_codes_rc, m->d_off, m->b.hi, m->b.seeds, m->b.qmask, m->b.ch, m->b.ctl,
-                m->b.stat, m->b.rcpool, m->b.long_list, m->b.strip_list, m->strip_bnd, m->strip_win, m->b.respool, m->b.dstrpool, m->d_counters, m->seed_scr, m->cand_scr, m->cand_scr2, m->cand_scr_dbg,
+                m->b.stat, m->b.align_retry, m->b.rcpool, m->b.long_list, m->b.strip_list, m->strip_bnd, m->strip_win, m->b.respool, m->b.dstrpool, m->d_counters, m->seed_scr, m->cand_scr, m->cand_scr2, m->cand_scr_dbg,
                 m->sw_rows, m->align_scr, m->align_scr2};
   for (void *p : ps) if (p) (void)hipFree(p);
   m->h_stat.release(); m->h_res.release(); m->h_dstr.release();
@@ -517,8 +580,8 @@ static int run_pipeline(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_
   HIPCHK(hipEventRecord(m->ev[T_REPLAY], s));
   if (!rv) rv = launch_replay(s, b, d, p);
   HIPCHK(hipEventRecord(m->ev[T_ALIGN], s));
-  if (!rv) rv = launch_align(s, b, d, p, m->align_scr, m->align_bytes, m->align_slots, m->wincap, m->dircap, m->rescap_slot, m->dstrcap_slot, m->align_scr2 ? 1 : 0);
-  if (!rv && m->align_scr2) rv = launch_align(s, b, d, p, m->align_scr2, m->align_bytes2, m->align_slots2, m->wincap, m->dircap2, m->rescap_slot, m->dstrcap_slot, 2);
+  if (!rv) rv = launch_align(s, b, d, p, m->align_scr, m->align_bytes, m->align_slots, m->wincap, m->dircap, m->rescap_slot, m->dstrcap_slot, 1);
+  if (!rv) rv = launch_align(s, b, d, p, m->align_scr2, m->align_bytes2, m->align_slots2, m->wincap, m->dircap2, m->rescap_slot2, m->dstrcap_slot2, 2);
   HIPCHK(hipEventRecord(m->ev[T_NUM], s));
   if (rv) return fail(SMALTGPU_ENODEV, "kernel launch failed: %s", hipGetErrorString((hipError_t)rv));
   return SMALTGPU_OK;
@@ -558,14 +621,16 @@ extern "C" int smaltgpu_fetch_begin(smaltgpu_mapper *m) {
   memcpy(m->work, ctr + 64, sizeof(m->work));
   for (int i = 0; i < T_NUM; i++) { float f = 0; (void)hipEventElapsedTime(&f, m->ev[i], m->ev[i + 1]); m->ms[i] = f; }
   m->fetch_open = false;
-  if (rc_count > m->b.rccap) return fail(SMALTGPU_ECAP, "candidate pool overflow (%u > %u): use a smaller batch or SMALTGPU_CANDS_PER_READ", rc_count, m->b.rccap);
-  if (nres > m->b.rescap || ndstr > m->b.dstrcap) return fail(SMALTGPU_ECAP, "result pool overflow");
-  if (m->h_res.ensure(nres ? nres : 1) || m->h_dstr.ensure(ndstr ? ndstr : 1)) return fail(SMALTGPU_ENOMEM, "pinned host memory");
+  // A pool that overflowed leaves SMALTGPU_ECAP in the stat of every read that did not fit (their results are dropped on the
+  // device); all other reads are complete.  smaltgpu_fetch_end reports the code, smaltgpu_map_batch re-maps those reads.
+  m->pool_overflow = rc_count > m->b.rccap || nres > m->b.rescap || ndstr > m->b.dstrcap;
+  const uint64_t nres_c = nres < m->b.rescap ? nres : m->b.rescap, ndstr_c = ndstr < m->b.dstrcap ? ndstr : m->b.dstrcap;
+  if (m->h_res.ensure(nres_c ? nres_c : 1) || m->h_dstr.ensure(ndstr_c ? ndstr_c : 1)) return fail(SMALTGPU_ENOMEM, "pinned host memory");
   if (n) HIPCHK(hipMemcpyAsync(m->h_stat.data(), m->b.stat, (size_t)n * sizeof(ReadStat), hipMemcpyDeviceToHost, m->stream));
-  if (nres) HIPCHK(hipMemcpyAsync(m->h_res.data(), m->b.respool, nres * sizeof(Result), hipMemcpyDeviceToHost, m->stream));
-  if (ndstr) HIPCHK(hipMemcpyAsync(m->h_dstr.data(), m->b.dstrpool, ndstr, hipMemcpyDeviceToHost, m->stream));
+  if (nres_c) HIPCHK(hipMemcpyAsync(m->h_res.data(), m->b.respool, nres_c * sizeof(Result), hipMemcpyDeviceToHost, m->stream));
+  if (ndstr_c) HIPCHK(hipMemcpyAsync(m->h_dstr.data(), m->b.dstrpool, ndstr_c, hipMemcpyDeviceToHost, m->stream));
   HIPCHK(hipEventRecord(m->ev_fetch, m->stream));
-  m->fetch_n = n; m->fetch_nres = nres; m->fetch_open = true;
+  m->fetch_n = n; m->fetch_nres = nres_c; m->fetch_open = true;
   return SMALTGPU_OK;
 }
 
@@ -601,7 +666,8 @@ extern "C" int smaltgpu_fetch_end(smaltgpu_mapper *m, smaltgpu_batch_out *out) {
   }
   m->h_res_off[n] = w;
   out->nreads = n; out->res_off = m->h_res_off.data(); out->res = m->o_res.data(); out->diffstr = m->h_dstr.data(); out->stat = m->o_stat.data();
-  if (first_err) return fail(first_err, "%u of %u reads hit a device-side limit (-5) or assertion (-6); first: read %u code %d (see stat[].errcode)", nerr, n, first_err_read, first_err);
+  if (first_err) return fail(first_err, "%u of %u reads hit a device-side limit (-5%s) or assertion (-6); first: read %u code %d (see stat[].errcode)", nerr, n,
+                             m->pool_overflow ? ": a batch-wide work pool overflowed" : "", first_err_read, first_err);
   return SMALTGPU_OK;
 }
 
@@ -612,14 +678,10 @@ extern "C" int smaltgpu_fetch_results(smaltgpu_mapper *m, smaltgpu_batch_out *ou
   return smaltgpu_fetch_end(m, out);
 }
 
-extern "C" int smaltgpu_map_batch(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
-                                   const smaltgpu_params *par, smaltgpu_batch_out *out) {
-  if (!m || !bases || !read_off || !par || !out) return fail(SMALTGPU_EARG, "null argument");
-  if (nreads > m->max_reads) return fail(SMALTGPU_EARG, "batch of %u reads exceeds the mapper's capacity %u", nreads, m->max_reads);
+// one device batch over reads in host memory: bases/quals + read_off[0..n]
+static int map_range(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
+                     const smaltgpu_params *par, smaltgpu_batch_out *out) {
   const uint64_t total = read_off[nreads] - read_off[0];
-  if (total > m->max_bases) return fail(SMALTGPU_EARG, "batch exceeds the mapper's base capacity");
-  int rv = check_par(m, par);
-  if (rv) return rv;
   m->h_off.resize((size_t)nreads + 1);
   for (uint32_t i = 0; i <= nreads; i++) {
     m->h_off[i] = read_off[i] - read_off[0];
@@ -629,10 +691,108 @@ extern "C" int smaltgpu_map_batch(smaltgpu_mapper *m, const uint8_t *bases, cons
   HIPCHK(hipMemcpyAsync(m->d_bases, bases + read_off[0], total, hipMemcpyHostToDevice, m->stream));
   if (quals) HIPCHK(hipMemcpyAsync(m->d_quals, quals + read_off[0], total, hipMemcpyHostToDevice, m->stream));
   HIPCHK(hipMemcpyAsync(m->d_off, m->h_off.data(), ((size_t)nreads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
-  rv = run_pipeline(m, m->d_bases, quals ? m->d_quals : nullptr, m->d_off, nreads, par);
+  const int rv = run_pipeline(m, m->d_bases, quals ? m->d_quals : nullptr, m->d_off, nreads, par);
   m->have_host_off = true;
   if (rv) return rv;
   return smaltgpu_fetch_results(m, out);
+}
+
+// The work pools of a mapper (ranked candidates, results, DiffStr bytes) are sized for the average read of a large batch;
+// the reference's buffers grow without bound instead (array.c).  When a batch overflows a pool, the reads that did not
+// fit (stat[].errcode == SMALTGPU_ECAP; every other read is complete) are mapped again in smaller batches -- all of them
+// together, in halves when none of them fitted -- down to a single read, for which the pools hold the reference's
+// maximum of candidates.  Results are per read, so the outcome equals that of one unlimited batch.
+static int remap_overflowed(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
+                            const smaltgpu_params *par, smaltgpu_batch_out *out) {
+  struct Part { std::vector<smaltgpu_result> res; std::vector<uint8_t> dstr; };
+  std::vector<smaltgpu_readstat> stat(out->stat, out->stat + nreads);
+  std::vector<uint64_t> off0(out->res_off, out->res_off + nreads + 1);
+  std::vector<smaltgpu_result> res0(out->res, out->res + off0[nreads]);
+  size_t nd0 = 0;
+  for (const smaltgpu_result &r : res0) if ((size_t)r.stroffs + r.strlen > nd0) nd0 = (size_t)r.stroffs + r.strlen;
+  std::vector<uint8_t> dstr0(out->diffstr, out->diffstr + nd0);
+  std::vector<Part> part(nreads);
+  std::vector<std::vector<uint32_t>> todo(1);
+  for (uint32_t i = 0; i < nreads; i++) if (stat[i].errcode == SMALTGPU_ECAP) todo[0].push_back(i);
+  std::vector<uint8_t> sb, sq;
+  std::vector<uint64_t> so;
+  uint32_t npermanent = 0, nbatches = 0;
+  while (!todo.empty()) {
+    std::vector<uint32_t> L;
+    L.swap(todo.back());
+    todo.pop_back();
+    if (L.empty()) continue;
+    sb.clear(); sq.clear(); so.assign(1, 0);
+    for (uint32_t i : L) {
+      sb.insert(sb.end(), bases + read_off[i], bases + read_off[i + 1]);
+      if (quals) sq.insert(sq.end(), quals + read_off[i], quals + read_off[i + 1]);
+      so.push_back(sb.size());
+    }
+    if (sb.empty()) sb.push_back(0);
+    smaltgpu_batch_out o;
+    const int rv = map_range(m, sb.data(), quals ? sq.data() : nullptr, so.data(), (uint32_t)L.size(), par, &o);
+    nbatches++;
+    if (rv && !((rv == SMALTGPU_ECAP || rv == SMALTGPU_EINTERNAL) && o.nreads == L.size())) return rv;
+    std::vector<uint32_t> failed;
+    for (size_t t = 0; t < L.size(); t++) {
+      const uint32_t i = L[t];
+      if (o.stat[t].errcode == SMALTGPU_ECAP) { failed.push_back(i); continue; }
+      stat[i] = o.stat[t];
+      Part &p = part[i];
+      p.res.assign(o.res + o.res_off[t], o.res + o.res_off[t + 1]);
+      for (smaltgpu_result &r : p.res) {
+        const uint32_t at = (uint32_t)p.dstr.size();
+        p.dstr.insert(p.dstr.end(), o.diffstr + r.stroffs, o.diffstr + r.stroffs + r.strlen);
+        r.stroffs = at;
+      }
+    }
+    if (failed.empty()) continue;
+    if (failed.size() < L.size()) todo.push_back(failed);
+    else if (L.size() == 1) npermanent++;                       // alone and still over a limit: the read keeps its error code
+    else {
+      todo.emplace_back(L.begin() + (ptrdiff_t)(L.size() / 2), L.end());
+      todo.emplace_back(L.begin(), L.begin() + (ptrdiff_t)(L.size() / 2));
+    }
+  }
+  // assemble in read order
+  m->fin_res.clear(); m->fin_dstr.clear(); m->fin_off.assign((size_t)nreads + 1, 0); m->fin_stat = stat;
+  int first_err = 0;
+  for (uint32_t i = 0; i < nreads; i++) {
+    m->fin_off[i] = m->fin_res.size();
+    const smaltgpu_result *rp = part[i].res.empty() ? res0.data() + off0[i] : part[i].res.data();
+    const size_t nr = part[i].res.empty() ? (size_t)(off0[i + 1] - off0[i]) : part[i].res.size();
+    const uint8_t *dp = part[i].res.empty() ? dstr0.data() : part[i].dstr.data();
+    if (stat[i].errcode && !first_err) first_err = stat[i].errcode;
+    for (size_t j = 0; j < nr; j++) {
+      smaltgpu_result r = rp[j];
+      if (m->fin_dstr.size() + r.strlen > 0xFFFFFFF0ull) return fail(SMALTGPU_ECAP, "alignment strings of the batch exceed 4 GB: use smaller batches");
+      const uint32_t at = (uint32_t)m->fin_dstr.size();
+      m->fin_dstr.insert(m->fin_dstr.end(), dp + r.stroffs, dp + r.stroffs + r.strlen);
+      r.stroffs = at;
+      m->fin_res.push_back(r);
+    }
+  }
+  m->fin_off[nreads] = m->fin_res.size();
+  if (m->fin_res.empty()) m->fin_res.resize(1);
+  if (m->fin_dstr.empty()) m->fin_dstr.resize(1);
+  out->nreads = nreads; out->res_off = m->fin_off.data(); out->res = m->fin_res.data(); out->diffstr = m->fin_dstr.data(); out->stat = m->fin_stat.data();
+  m->remap_batches += nbatches;
+  if (first_err) return fail(first_err, "%u of %u reads exceed a device-side limit even alone or failed an assertion (see stat[].errcode)", npermanent, nreads);
+  return SMALTGPU_OK;
+}
+
+extern "C" int smaltgpu_map_batch(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
+                                   const smaltgpu_params *par, smaltgpu_batch_out *out) {
+  if (!m || !bases || !read_off || !par || !out) return fail(SMALTGPU_EARG, "null argument");
+  if (nreads > m->max_reads) return fail(SMALTGPU_EARG, "batch of %u reads exceeds the mapper's capacity %u", nreads, m->max_reads);
+  const uint64_t total = read_off[nreads] - read_off[0];
+  if (total > m->max_bases) return fail(SMALTGPU_EARG, "batch exceeds the mapper's base capacity");
+  int rv = check_par(m, par);
+  if (rv) return rv;
+  out->nreads = 0;
+  rv = map_range(m, bases, quals, read_off, nreads, par, out);
+  if (rv == SMALTGPU_ECAP && out->nreads == nreads && nreads > 0 && !m->debug) return remap_overflowed(m, bases, quals, read_off, nreads, par, out);
+  return rv;
 }
 
 extern "C" int smaltgpu_timers(const smaltgpu_mapper *m, double *ms, uint64_t *work, int n) {

@@ -122,6 +122,14 @@ __global__ void __launch_bounds__(64) k_align(Batch b, DevIndex ix, MapPar p, ui
   x.ring = WIDE ? (void *)strip_ring : nullptr;
   __shared__ uint32_t qslot;
   uint32_t *cursor = b.next_item + (pass == 2 ? 3 : 2);
+  if (pass == 2) {                        // only the reads the first pass deferred (usually none: the launch ends at once)
+    const uint32_t n = *b.align_retry_n;
+    for (uint32_t i = next_item(cursor, &qslot); i < n; i = next_item(cursor, &qslot)) {
+      stage_align<WIDE>(b, ix, p, b.align_retry[i], x);
+      __syncthreads();
+    }
+    return;
+  }
   for (uint32_t r = next_item(cursor, &qslot); r < b.nreads; r = next_item(cursor, &qslot)) {
     stage_align<WIDE>(b, ix, p, r, x);
     __syncthreads();

@@ -38,7 +38,8 @@ struct Batch {                          // one block of reads resident in HBM
   Result *respool; uint64_t rescap; unsigned long long *res_count;
   uint8_t *dstrpool; uint64_t dstrcap; unsigned long long *dstr_count;
   int32_t *err_flag;                    // batch-wide first error
-  uint32_t *next_item;                  // [4] work-queue cursors of the persistent kernels (seed, cands, align)
+  uint32_t *next_item;                  // [5] work-queue cursors of the persistent kernels (seed, cands, align, align pass 2, cands pass 2)
+  uint32_t *align_retry, *align_retry_n; // reads the first K3 pass deferred to the second one (SMG_ERR_RETRY), and how many
   unsigned long long *work;             // [WK_NWORK] work counters (WK_*), one atomic per workgroup
 };
 enum : int { WK_LOOKUPS = 0, WK_HITS = 1, WK_CELLS_FULL = 2, WK_TASKS_FULL = 3, WK_CELLS_BAND = 4, WK_NCAND = 5, WK_NKEPT = 6,
@@ -1142,7 +1143,7 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
   const int gi = -p.gap_init, ge = -p.gap_ext;
 
   unsigned long long aph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (x.pass == 2 && st.err != SMG_ERR_RETRY) return;       // wave-uniform: the first pass finished this read
+  if (x.pass == 2 && st.err != SMG_ERR_RETRY) return;       // wave-uniform: the first pass finished this read (the kernel walks the retry list)
   SMG_LANE0 {
     x.state[S_MINSW] = ctl.min_swatscor; x.state[S_SWMAX] = 0; x.state[S_SW2ND] = 0;
     x.state[S_NRES] = 0; x.state[S_NDSTR] = 0; x.state[S_ERR] = ch.err; x.state[S_SP] = 0; x.state[S_NALI] = 0;
@@ -1299,7 +1300,7 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
           if (!err && !(qs + minscorlen > qe + 1)) {
             // addALIMETAtoRsltSet (alignment.c:1277): forward DiffStr appended to the scratch string pool
             const int nali = x.state[S_NALI];
-            if ((uint32_t)(res_first + nali) >= x.rescap || (uint32_t)(x.state[S_NDSTR] + dn + 2) > x.dstrcap) err = SMG_ERR_CAP;
+            if ((uint32_t)(res_first + nali) >= x.rescap || (uint32_t)(x.state[S_NDSTR] + dn + 2) > x.dstrcap) err = x.pass == 1 ? SMG_ERR_RETRY : SMG_ERR_CAP;   // the second pass has large result slots
             else {
               Result &a = x.res[res_first + nali];
               a.swatscor = max_scor; a.q_start = (uint32_t)qs; a.q_end = (uint32_t)qe; a.s_start = (uint64_t)rs; a.s_end = (uint64_t)re;
@@ -1382,6 +1383,7 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
     st.dstr_off = atomic_add_u64(b.dstr_count, st.err ? 0 : nd);
     if (st.res_off + st.nres > b.rescap || st.dstr_off + nd > b.dstrcap) { st.err = SMG_ERR_CAP; st.nres = 0; }
     if (st.err && st.err != SMG_ERR_RETRY) atomic_add_u32((uint32_t *)b.err_flag, 1u);
+    if (st.err == SMG_ERR_RETRY && b.align_retry) b.align_retry[atomic_add_u32(b.align_retry_n, 1u)] = r;
     x.state[S_NRES] = (int32_t)st.nres; x.state[S_NDSTR] = st.err ? 0 : (int32_t)nd;
   }
   SMG_SYNC();

@@ -46,6 +46,7 @@ def _data(tmp, nchr, chrlen, nreads, rlen, seed, with_n=False):
     (13, 6, 2, 250_000, 100, ["-f", "cigar", "-n", "8", "-O", "-r", "-1", "-x", "-c", "30"]),   # blocks of 256 reads, exhaustive, absolute cover threshold
     (13, 6, 700, 1_500, 100, ["-f", "sam", "-n", "2", "-O", "-r", "-1"]),   # >= 512 reference sequences: concatenated mode (hashCollectHitsUsingCutoff, assignSequenceIndex)
     (11, 4, 600, 2_000, 120, ["-f", "cigar", "-d", "-1"]),                   # concatenated mode, all alignments
+    (13, 6, 3000, 400, 100, ["-f", "sam", "-n", "2", "-O", "-r", "-1"]),    # a contig set: 3000 reference sequences (no limit on their number in concatenated mode)
 ])
 def test_smalt_map_prints_the_same(k, s, nchr, chrlen, rlen, opts, tmp_path):
     tmp = str(tmp_path)
@@ -58,7 +59,10 @@ def test_smalt_map_prints_the_same(k, s, nchr, chrlen, rlen, opts, tmp_path):
     a = [ln for ln in open(out_ref).read().split("\n") if not ln.startswith("@PG")]
     assert sum(1 for ln in a if ln and not ln.startswith("@")) >= 1000
     # batched binding (the worker maps a block of reads per GPU batch) and per-read binding (rmapSingle, one read per call)
-    for extra in ({}, {"SMALTGPU_PER_READ": "1"}):
+    # ... with pools of 8 ranked candidates per read (overflow: the library re-maps in smaller batches) and with two index
+    # images / mapper sets fed from one queue (SMALTGPU_NDEV=2; on a one-GPU box both on the same device, the second image a
+    # device-to-device copy of the first)
+    for extra in ({}, {"SMALTGPU_PER_READ": "1"}, {"SMALTGPU_CANDS_PER_READ": "8"}, {"SMALTGPU_NDEV": "2", "SMALTGPU_COMBINE_READS": "256"}):
         r = subprocess.run([SMALT_GPU, "map"] + opts + ["-o", out_gpu, pre, fq], capture_output=True, env=dict(env, **extra))
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         b = [ln for ln in open(out_gpu).read().split("\n") if not ln.startswith("@PG")]
