@@ -210,6 +210,59 @@ OrIndex *or_index_build(int nseq, const char *const *seqs, const uint32_t *lens,
   return ix;
 }
 
+/* The on-the-fly index of rmapPair's rescue round (rmap.c:495-517 setupFineHashTable -> hashTableSetUp with an interval
+ * set, hashidx.c:549-575 doAllWordsInSeqSet): perfect type, k = 5, s = 1 (rmap.c:91-92; hashTableCreate rmap.c:1543),
+ * over the windows [lo, hi] of sequences sx only.  Serials are global (calcKtupOffs, hashidx.c:325: (sop[sx] + lo) / s) and
+ * ascending per key because the intervals are pruned (sorted, disjoint).  The packed reference, offsets and names are
+ * SHARED with `main` (the returned index must be freed with or_index_free_fine before `main`). */
+OrIndex *or_index_build_fine(const OrIndex *main, int niv, const int64_t *sx, const uint32_t *lo, const uint32_t *hi, int k, int s)
+{
+  OrIndex *ix = calloc(1, sizeof(OrIndex));
+  BuildCtx ctx;
+  uint8_t *codes = NULL;
+  size_t n, a, cap = 0;
+  uint32_t j, tuplectr = 0;
+  int i;
+  *ix = *main;
+  ix->k = k; ix->s = s; ix->typ = OR_IDX_PERFECT; ix->nbits_key = 2*k; ix->nbits_lo = 0;
+  ix->nkeys = ((uint32_t) 1) << ix->nbits_key;
+  ix->nwords = 0; ix->wordidx = ix->posidx = NULL; ix->idx = ix->pos = NULL;
+  memset(&ctx, 0, sizeof(ctx));
+  ctx.ix = ix;
+  for (ctx.pass = 0; ctx.pass < 2; ctx.pass++) {
+    if (ctx.pass == 1) { ctx.rec = malloc((ctx.n + 1)*sizeof(KmerRec)); ctx.n = 0; }
+    for (i = 0; i < niv; i++) {
+      const uint64_t g = main->sop[sx[i]] + lo[i];
+      const uint32_t sl = hi[i] - lo[i] + 1;
+      int offs;
+      tuplectr = (uint32_t) (g/(uint64_t) s);
+      offs = (int) (g - (uint64_t) tuplectr*(uint64_t) s);
+      if (sl < (uint32_t) k) continue;                                  /* hashidx.c:561-563 */
+      if (sl + 1 > cap) { cap = sl + 1024; codes = realloc(codes, cap); }
+      or_index_fetch(main, g, sl, codes);
+      scan_kmers(codes, sl, k, s, &tuplectr, &offs, build_visit, &ctx);
+    }
+  }
+  free(codes);
+  n = ctx.n;
+  ix->npos = (uint32_t) n;
+  ix->maxpos = (tuplectr > 0)? tuplectr - 1: 0;
+  qsort(ctx.rec, n, sizeof(KmerRec), cmp_rec);
+  ix->pos = malloc((n + 1)*sizeof(uint32_t));
+  for (a = 0; a < n; a++) ix->pos[a] = ctx.rec[a].pos;
+  ix->idx = calloc((size_t) ix->nkeys + 2, sizeof(uint32_t));
+  for (a = 0; a < n; a++) ix->idx[ctx.rec[a].key + 1]++;
+  for (j = 0; j < ix->nkeys; j++) ix->idx[j+1] += ix->idx[j];
+  free(ctx.rec);
+  return ix;
+}
+
+void or_index_free_fine(OrIndex *ix)
+{
+  if (!ix) return;
+  free(ix->idx); free(ix->pos); free(ix);
+}
+
 void or_index_free(OrIndex *ix)
 {
   if (!ix) return;

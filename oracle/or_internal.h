@@ -50,6 +50,9 @@ struct OrMap {
   uint64_t **hl_keep; int *hl_keep_n; int hl_keep_cnt;
   int keep_hitlists;
   OrParams par;
+  /* interval restriction of the current call (rmapPair); niv < 0: none */
+  int prevmax[2];            /* running score maxima of the ResultSet the next call appends to (0, 0: a blank set) */
+  int niv, niv_next; const int64_t *iv_sx; const uint32_t *iv_lo, *iv_hi;
 };
 
 /* or_seed.c */

@@ -3,6 +3,8 @@
  * alignRMAPCANDFull :790 -> resultSetAddFromAli results.c:1852) on top of the stage
  * functions in or_seed.c / or_segment.c / or_align.c, and the stage dump in the line format
  * of oracle/refdump (DUMPFORMAT.md). */
+#define _GNU_SOURCE
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <limits.h>
@@ -17,6 +19,7 @@ OrMap *or_map_create(const OrIndex *ix)
   or_hitinfo_init(&m->hi[0], ix->s);
   or_hitinfo_init(&m->hi[1], ix->s);
   m->keep_hitlists = 1;
+  m->niv = m->niv_next = -1;
   return m;
 }
 
@@ -71,6 +74,21 @@ static int collect_hits(OrMap *m, OrHitInfo *hi, uint32_t n_hit_max, uint32_t n_
     keep_hitlist(m);
     or_seglst_fill(&m->sl, n_ktup_min, &m->hl, ix);
     rv = or_segcands_add_fast(&m->sc, m->qmaskbuf, &m->sl, ix, cover_min, -1);
+  }
+  return rv;
+}
+
+/* collectHitsFromInterVal, rmap.c:438-492: one hit list per interval, all seeds (use_short_hitinfo = 0) */
+static int collect_hits_intervals(OrMap *m, OrHitInfo *hi, uint32_t n_hit_max, uint32_t n_ktup_min, uint32_t cover_min)
+{
+  const OrIndex *ix = m->ix;
+  int i, rv = OR_OK;
+  for (i = 0; i < m->niv; i++) {
+    const uint64_t offs = ix->sop[m->iv_sx[i]];
+    or_collect_hits_segment(&m->hl, hi, ix, offs + m->iv_lo[i], offs + m->iv_hi[i] + 1, n_hit_max, 0);
+    keep_hitlist(m);
+    or_seglst_fill(&m->sl, n_ktup_min, &m->hl, ix);
+    if ((rv = or_segcands_add_fast(&m->sc, m->qmaskbuf, &m->sl, ix, cover_min, (int32_t) m->iv_sx[i]))) break;
   }
   return rv;
 }
@@ -177,6 +195,7 @@ static void add_results(OrMap *m, const OrAli *a, int nres, uint64_t soffs, uint
         else if (rp->swatscor < m->swmax) m->sw2nd = rp->swatscor;
       }
       rp->reverse = is_reverse;
+      rp->cand_first = (i == 0);
     } else {
       arrlen--;
     }
@@ -237,8 +256,13 @@ static int map_single_read(OrMap *m)
 
   /* fillRMAPBUFF, rmap.c:1153-1226 */
   or_segcands_blank(&m->sc);
+  if (m->niv >= 0) {                                   /* filtered (rmap.c:1177-1198) */
+    if ((rv = collect_hits_intervals(m, &m->hi[0], (uint32_t) p->ncut, min_ktup, min_cover))) return rv;
+    if ((rv = collect_hits_intervals(m, &m->hi[1], (uint32_t) p->ncut, min_ktup, min_cover))) return rv;
+  } else {
   if ((rv = collect_hits(m, &m->hi[0], (uint32_t) p->ncut, min_ktup, min_cover, (p->flags & OR_FLG_SEQBYSEQ) != 0))) return rv;
   if ((rv = collect_hits(m, &m->hi[1], (uint32_t) p->ncut, min_ktup, min_cover, (p->flags & OR_FLG_SEQBYSEQ) != 0))) return rv;
+  }
 
   if ((rv = or_segcands_stats(&m->sc, ix, mincov_below_max, &m->hi[0], &m->hi[1], (uint32_t) p->target_depth,
                               (uint32_t) p->max_depth, (p->flags & OR_FLG_SENSITIVE) != 0))) return rv;
@@ -271,6 +295,30 @@ static int map_single_read(OrMap *m)
   return align_cands(m, M, min_swatscor, scorlen_min, bandwidth_min);
 }
 
+int or_map_single_restricted(OrMap *m, const char *bases, const char *quals, uint32_t len, const OrParams *p,
+                             int niv, const int64_t *sx, const uint32_t *lo, const uint32_t *hi)
+{
+  int rv;
+  m->niv_next = niv; m->iv_sx = sx; m->iv_lo = lo; m->iv_hi = hi;
+  rv = or_map_single(m, bases, quals, len, p);
+  m->niv_next = -1;
+  return rv;
+}
+
+void or_map_set_prevmax(OrMap *m, int swmax, int sw2nd) { m->prevmax[0] = swmax; m->prevmax[1] = sw2nd; }
+
+/* calcTotalNumberOfHits, rmap.c:1076-1081 -> hashCalcHitInfoNumberOfHits, hashhit.c:1171-1197 */
+uint32_t or_map_hit_total(const OrMap *m, int ktuple_maxhit)
+{
+  uint32_t st, i, tot = 0;
+  const uint32_t cut = (ktuple_maxhit < 1)? 0: (uint32_t) ktuple_maxhit;
+  if (m->qlen < (uint32_t) m->ix->k) return 0;
+  for (st = 0; st < 2; st++)
+    for (i = 0; i < m->hi[st].n_seeds; i++)
+      if (!cut || m->hi[st].sortkey[i] <= cut) tot += m->hi[st].sortkey[i];
+  return tot;
+}
+
 /* rmapSingle, rmap.c:1648-1742 (RMAPFLG_SPLIT / secondary mapping not restated) */
 int or_map_single(OrMap *m, const char *bases, const char *quals, uint32_t len, const OrParams *p)
 {
@@ -278,7 +326,11 @@ int or_map_single(OrMap *m, const char *bases, const char *quals, uint32_t len, 
   uint32_t i;
   int rv;
   m->par = *p;
-  m->nres = 0; m->ndiff = 0; m->swmax = m->sw2nd = 0; m->ncand = 0;
+  m->niv = m->niv_next;
+  /* a call that appends to a ResultSet (rmapPair) continues that set's running score maxima: alignRMAPCANDFull raises its
+   * threshold to the set's second-best score (rmap.c:881-885), whatever call it came from */
+  m->nres = 0; m->ndiff = 0; m->swmax = m->prevmax[0]; m->sw2nd = m->prevmax[1]; m->ncand = 0;
+  m->prevmax[0] = m->prevmax[1] = 0;
   m->nseg = m->nseg_tot = m->nhit = m->nhit_tot = m->max1 = m->max2 = 0;
   m->th_bandwidth_min = m->th_min_swatscor = m->th_scorlen_min = 0;
   m->sc.ncand = 0; m->sc.n_sort = 0;
@@ -308,6 +360,19 @@ int or_map_single(OrMap *m, const char *bases, const char *quals, uint32_t len, 
   rv = map_single_read(m);
   m->err = rv;
   return rv;
+}
+
+long or_map_dump_str(const OrMap *m, unsigned long long readno, const char *name, int with_hitlists, char *buf, size_t cap)
+{
+  char *mem = NULL;
+  size_t len = 0;
+  FILE *fp = open_memstream(&mem, &len);
+  if (!fp) return -1;
+  or_map_dump(m, fp, readno, name, with_hitlists);
+  fclose(fp);
+  if (buf && cap) { size_t c = (len < cap - 1)? len: cap - 1; memcpy(buf, mem, c); buf[c] = 0; }
+  free(mem);
+  return (long) len;
 }
 
 const OrResult *or_map_results(const OrMap *m, int *n, const uint8_t **diffstr)

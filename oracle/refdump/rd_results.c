@@ -19,3 +19,32 @@ void rdDumpResults(FILE *fp, const ResultSet *rsp)
   fprintf(fp, "RX %u %d %d %d %d %u %u\n", (unsigned) n, rsp->swatscor_max, rsp->swatscor_2ndmax,
 	  rsp->n_ali_done, rsp->n_ali_tot, rsp->n_hits_used, rsp->n_hits_tot);
 }
+
+/* paired mode (rd_rmap.c): the results one mapSingleRead call added, and the running score maxima */
+unsigned rdResultNum(const ResultSet *rsp) { return (unsigned) ARRLEN(rsp->resr); }
+void rdScoreMaxGet(const ResultSet *rsp, int *mx, int *mx2) { *mx = rsp->swatscor_max; *mx2 = rsp->swatscor_2ndmax; }
+void rdScoreMaxSet(ResultSet *rsp, int mx, int mx2) { rsp->swatscor_max = mx; rsp->swatscor_2ndmax = mx2; }
+void rdScoreMaxUpdate(ResultSet *rsp, int scor) { UPDATE_SWATSCORMAX(rsp, scor); }
+
+static void printResult(FILE *fp, const char *tag, unsigned i, const Result *rp, const ResultSet *rsp)
+{
+  int j;
+  fprintf(fp, "%s %u %c %d %u %u %llu %llu %lld ", tag, i, (rp->status & RSLTFLAG_REVERSE)? 'R':'F', rp->swatscor, rp->q_start, rp->q_end,
+	  (unsigned long long) rp->s_start, (unsigned long long) rp->s_end, (long long) rp->sidx);
+  for (j=0; j<rp->strlen; j++) fprintf(fp, "%02x", (unsigned) rsp->diffstrp->dstrp[rp->stroffs + j]);
+  fputc('\n', fp);
+}
+
+void rdDumpLastResult(FILE *fp, const ResultSet *rsp)
+{
+  const size_t n = ARRLEN(rsp->resr);
+  if (n > 0) printResult(fp, "PL", (unsigned) (n - 1), rsp->resr + n - 1, rsp);
+}
+
+void rdDumpResultsFrom(FILE *fp, const ResultSet *rsp, unsigned first, int swmax, int sw2nd)
+{
+  size_t i, n = ARRLEN(rsp->resr);
+  for (i=first; i<n; i++) printResult(fp, "RS", (unsigned) (i - first), rsp->resr + i, rsp);
+  fprintf(fp, "RX %u %d %d %d %d %u %u\n", (unsigned) ((n > first)? n - first: 0), swmax, sw2nd,
+	  rsp->n_ali_done, rsp->n_ali_tot, rsp->n_hits_used, rsp->n_hits_tot);
+}

@@ -7,15 +7,95 @@
  *
  * usage: refdump [-m minscor] [-d scordiff] [-c mincover] [-q minbasq] [-H ncut]
  *                [-S match,mismatch,gapopen,gapext] [-x] <index_prefix> <reads.fq>
+ *        refdump -P <mates.fq> [-i maxins] [-j minins] [-l pe|mp|pp] ... <index_prefix> <reads.fq>
+ *
+ * Paired mode (-P) runs the reference's rmapPair (rmap.c:1744) pair by pair and prints one block per mapSingleRead call
+ * it makes (rare mate, interval-restricted mate, unrestricted re-map, restricted re-map over the on-the-fly k=5 index):
+ * the call's arguments (`MS`, `IV` lines; DUMPFORMAT.md) followed by the stage dump of that call.  The calls are
+ * intercepted without touching the reference's text: every call site in rmap.c passes `errmsgp` first while the
+ * definition's first parameter is `ErrMsg *errmsgp`, so a function-like macro that pastes its first token sends the
+ * definition to mapSingleRead_impl and the calls to our hook.
  */
-#include "rmap.c"
 #include <stdio.h>
 #include <string.h>
 #include <getopt.h>
+#include "rmap.h"
+#include "interval.h"
+typedef struct RMAPBUFF_ RMAPBUFF;
+typedef struct RMAPINFO_ RMAPINFO;
+typedef struct RMAPPROF_ RMAPPROF;
+static int rd_msr_hook(ErrMsg *errmsgp, RMAPBUFF *bufp, ResultSet *rssp, const RMAPINFO *rmrp, const RMAPPROF *rprofp,
+		       SeqFastq *readp, int ktuple_maxhit, uint32_t min_cover, int min_swatscor, int min_swatscor_below_max,
+		       short target_depth, short max_depth, RMAPFLG_t rmapflg, const HashTable *htp, const SeqSet *ssp,
+		       const SeqCodec *codecp, const InterVal *ivr);
+#define mapSingleRead(first, ...) MSR_##first, __VA_ARGS__)
+#define MSR_ErrMsg mapSingleRead_impl(ErrMsg
+#define MSR_errmsgp rd_msr_hook(errmsgp
+#include "rmap.c"
+#undef mapSingleRead
 
 extern void rdDumpHitInfo(FILE *fp, char strand, const HashHitInfo *hip);
 extern void rdDumpCands(FILE *fp, const SegAliCands *sacp);
 extern void rdDumpResults(FILE *fp, const ResultSet *rsp);
+extern void rdDumpResultsFrom(FILE *fp, const ResultSet *rsp, unsigned first, int swmax, int sw2nd);
+extern void rdDumpLastResult(FILE *fp, const ResultSet *rsp);
+extern unsigned rdResultNum(const ResultSet *rsp);
+extern void rdScoreMaxGet(const ResultSet *rsp, int *mx, int *mx2);
+extern void rdScoreMaxSet(ResultSet *rsp, int mx, int mx2);
+extern void rdScoreMaxUpdate(ResultSet *rsp, int scor);
+
+static void dumpStages(FILE *fp, const RMAPINFO *rmrp, const RMAPBUFF *bufp, uint32_t readlen, UCHAR ktup)
+{
+  uint32_t i, n;
+  if (readlen < ktup) return;
+  rdDumpHitInfo(fp, 'F', rmrp->hhiFp);
+  rdDumpHitInfo(fp, 'R', rmrp->hhiRp);
+  rdDumpCands(fp, bufp->sacp);
+  n = ARRLEN(bufp->candr);
+  for (i=0; i<n; i++) {
+    const RMAPCAND *cp = bufp->candr + i;
+    fprintf(fp, "RC %u %u %u %u %llu %llu %d %d %lld %d\n", i, (unsigned) cp->flags, cp->qs, cp->qe,
+	    (unsigned long long) cp->rs, (unsigned long long) cp->re, cp->band_l, cp->band_r,
+	    (long long) cp->sqidx, cp->swscor);
+  }
+}
+
+/* ---- paired mode: one block per mapSingleRead call of rmapPair ---- */
+static struct { int on; unsigned long long pairno; int callno; const SeqFastq *readp, *matep; const HashTable *htp; } g_pm;
+
+static int rd_msr_hook(ErrMsg *errmsgp, RMAPBUFF *bufp, ResultSet *rssp, const RMAPINFO *rmrp, const RMAPPROF *rprofp,
+		       SeqFastq *readp, int ktuple_maxhit, uint32_t min_cover, int min_swatscor, int min_swatscor_below_max,
+		       short target_depth, short max_depth, RMAPFLG_t rmapflg, const HashTable *htp, const SeqSet *ssp,
+		       const SeqCodec *codecp, const InterVal *ivr)
+{
+  int rv, mx, mx2;
+  unsigned nbefore;
+  uint32_t readlen;
+  if (!g_pm.on)
+    return mapSingleRead_impl(errmsgp, bufp, rssp, rmrp, rprofp, readp, ktuple_maxhit, min_cover, min_swatscor,
+			      min_swatscor_below_max, target_depth, max_depth, rmapflg, htp, ssp, codecp, ivr);
+  seqFastqGetConstSequence(readp, &readlen, NULL);
+  rdScoreMaxGet(rssp, &mx, &mx2);         /* the set's running score maxima before the call (UPDATE_SWATSCORMAX, results.c:1013) */
+  printf("MS %d mate=%d niv=%d fine=%d minscor=%d mincov=%u belowmax=%d flags=%u prevmax=%d,%d\n", g_pm.callno++, (readp == g_pm.matep)? 1: 0,
+	 (ivr)? interValNum(ivr): -1, (htp != g_pm.htp)? 1: 0, min_swatscor, min_cover, min_swatscor_below_max, (unsigned) rmapflg, mx, mx2);
+  if (ivr) {
+    int i, n = interValNum(ivr);
+    for (i=0; i<n; i++) {
+      SEQLEN_t lo, hi; SEQNUM_t sx;
+      interValGet(&lo, &hi, &sx, NULL, i, ivr);
+      printf("IV %lld %u %u\n", (long long) sx, (unsigned) lo, (unsigned) hi);
+    }
+  }
+  nbefore = rdResultNum(rssp);
+  if (nbefore > 0) rdDumpLastResult(stdout, rssp);       /* PL: a first new result equal to it is dropped (results.c:1906) */
+  rv = mapSingleRead_impl(errmsgp, bufp, rssp, rmrp, rprofp, readp, ktuple_maxhit, min_cover, min_swatscor,
+			  min_swatscor_below_max, target_depth, max_depth, rmapflg, htp, ssp, codecp, ivr);
+  rdScoreMaxGet(rssp, &mx, &mx2);
+  printf("READ %llu %s len=%u err=%d\n", g_pm.pairno, seqFastqGetSeqName(readp), readlen, rv);
+  dumpStages(stdout, rmrp, bufp, readlen, hashTableGetKtupLen(htp, NULL));
+  rdDumpResultsFrom(stdout, rssp, nbefore, mx, mx2);      /* RX: new results, the set's running maxima after the call */
+  return rv;
+}
 
 static void dumpHitLists(FILE *fp, RMap *rmp, int ncut, BOOL with_seqidx,
 			 const HashTable *htp, const SeqSet *ssp)
@@ -62,9 +142,18 @@ int main(int argc, char *argv[])
   ErrMsg *errmsgp = 0;
   UCHAR ktup, nskip;
   unsigned long long readno = 0;
+  const char *matefil = NULL;
+  int ins_min = 0, ins_max = 500;
+  RSLTPAIRLIB_t pairlib = RSLTPAIRLIB_PAIREDEND;
+  SeqIO *mfp = NULL;
+  SeqFastq *matep = NULL;
 
-  while ((c = getopt(argc, argv, "m:d:c:q:H:S:xn")) != -1) {
+  while ((c = getopt(argc, argv, "m:d:c:q:H:S:xnP:i:j:l:")) != -1) {
     switch (c) {
+    case 'P': matefil = optarg; break;
+    case 'i': ins_max = atoi(optarg); break;
+    case 'j': ins_min = atoi(optarg); break;
+    case 'l': pairlib = (!strcmp(optarg, "mp"))? RSLTPAIRLIB_MATEPAIR: ((!strcmp(optarg, "pp"))? RSLTPAIRLIB_SAMESTRAND: RSLTPAIRLIB_PAIREDEND); break;
     case 'm': minscor = atoi(optarg); break;
     case 'd': scordiff = atoi(optarg); break;
     case 'c': mincover = atof(optarg); break;
@@ -97,13 +186,19 @@ int main(int argc, char *argv[])
   smp = scoreCreateMatrix(codecp, penp);
   rfp = resultSetCreateFilter();
   resultSetFilterData(rfp, minscor, scordiff, 0.0);
+  if (matefil) rmapflg |= RMAPFLG_PAIRED;
   rmp = rmapCreate(htp, codecp, ssp, smp, rmapflg);
   readp = seqFastqCreate(0, SEQTYP_FASTQ);
+  if (matefil) {
+    matep = seqFastqCreate(0, SEQTYP_FASTQ);
+    mfp = seqIOopen(&errcode, (char *) matefil, SEQIO_READ, 0);
+    if (errcode) { fprintf(stderr, "cannot open mates (%d)\n", errcode); return 1; }
+  }
   sfp = seqIOopen(&errcode, argv[optind+1], SEQIO_READ, 0);
   if (errcode) { fprintf(stderr, "cannot open reads (%d)\n", errcode); return 1; }
 
   while (!seqIOstatus(sfp)) {
-    uint32_t readlen, covermin, i, n;
+    uint32_t readlen, covermin;
     if ((errcode = seqFastqRead(readp, sfp))) break;
     seqFastqEncode(readp, codecp);
     seqFastqGetConstSequence(readp, &readlen, NULL);
@@ -111,21 +206,26 @@ int main(int argc, char *argv[])
       covermin = (uint32_t) (mincover*readlen);
       if (covermin > readlen) covermin = readlen;
     } else covermin = (uint32_t) mincover;
+    if (matefil) {                      /* as processMapArgs, smalt.c:1131-1165 */
+      uint32_t matelen, covermin_mate = covermin;
+      RSLTPAIRFLG_t pairflg = 0;
+      if ((errcode = seqFastqRead(matep, mfp))) break;
+      seqFastqEncode(matep, codecp);
+      seqFastqGetConstSequence(matep, &matelen, NULL);
+      if (mincover < 1.01) { covermin_mate = (uint32_t) (mincover*matelen); if (covermin_mate > matelen) covermin_mate = matelen; }
+      printf("PAIR %llu %s %s len=%u,%u\n", readno, seqFastqGetSeqName(readp), seqFastqGetSeqName(matep), readlen, matelen);
+      g_pm.on = 1; g_pm.pairno = readno; g_pm.callno = 0; g_pm.readp = readp; g_pm.matep = matep; g_pm.htp = htp;
+      errcode = rmapPair(errmsgp, rmp, readp, matep, &pairflg, ins_min, ins_max, pairlib, ncut, covermin, covermin_mate,
+			 minscor, (UCHAR) minbasq, 512, 2048, (RMAPFLG_t) (rmapflg | RMAPFLG_PAIRED), smp, rfp, htp, ssp, codecp);
+      g_pm.on = 0;
+      printf("PE %llu err=%d pairflg=%u ncalls=%d\n", readno, errcode, (unsigned) pairflg, g_pm.callno);
+      readno++;
+      continue;
+    }
     errcode = rmapSingle(errmsgp, rmp, readp, ncut, covermin, minscor, scordiff,
 			 (UCHAR) minbasq, 512, 2048, rmapflg, smp, rfp, htp, ssp, codecp);
     printf("READ %llu %s len=%u err=%d\n", readno++, seqFastqGetSeqName(readp), readlen, errcode);
-    if (readlen >= ktup) {
-      rdDumpHitInfo(stdout, 'F', rmp->mrp->hhiFp);
-      rdDumpHitInfo(stdout, 'R', rmp->mrp->hhiRp);
-      rdDumpCands(stdout, rmp->bfp->sacp);
-      n = ARRLEN(rmp->bfp->candr);
-      for (i=0; i<n; i++) {
-	const RMAPCAND *cp = rmp->bfp->candr + i;
-	printf("RC %u %u %u %u %llu %llu %d %d %lld %d\n", i, (unsigned) cp->flags, cp->qs, cp->qe,
-	       (unsigned long long) cp->rs, (unsigned long long) cp->re, cp->band_l, cp->band_r,
-	       (long long) cp->sqidx, cp->swscor);
-      }
-    }
+    dumpStages(stdout, rmp->mrp, rmp->bfp, readlen, ktup);
     rdDumpResults(stdout, rmp->rsrp);
     if (with_hitlists && readlen >= ktup)
       dumpHitLists(stdout, rmp, ncut, (BOOL) ((rmapflg & RMAPFLG_SEQBYSEQ) != 0), htp, ssp);

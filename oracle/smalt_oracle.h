@@ -50,6 +50,10 @@ OrIndex *or_index_build(int nseq, const char *const *seqs, const uint32_t *lens,
 int or_index_write(const OrIndex *ix, const char *prefix);      /* <prefix>.sma + .smi */
 OrIndex *or_index_read(const char *prefix);
 void or_index_free(OrIndex *ix);
+/* the on-the-fly index of rmapPair's rescue round (rmap.c:495-517): perfect type over the interval windows only; shares the
+ * reference arrays of `main` */
+OrIndex *or_index_build_fine(const OrIndex *main, int niv, const int64_t *sx, const uint32_t *lo, const uint32_t *hi, int k, int s);
+void or_index_free_fine(OrIndex *ix);
 uint32_t or_index_lookup(const OrIndex *ix, uint64_t word, uint32_t *posidx); /* hashidx.c:1146 */
 uint32_t or_index_positions(const OrIndex *ix, uint32_t posidx, const uint32_t **posp); /* :1193 */
 void or_index_fetch(const OrIndex *ix, uint64_t start, uint32_t len, uint8_t *codes); /* 3-bit codes */
@@ -110,6 +114,7 @@ typedef struct OrResult {                                                   /* r
   uint64_t s_start, s_end;     /* 1-based in sequence sidx */
   int64_t sidx;
   int stroffs, strlen;         /* into OrMap.diffstr (strlen includes the terminating 0) */
+  int cand_first;              /* 1: first alignment of its candidate, i.e. of one resultSetAddFromAli call (results.c:1852) */
 } OrResult;
 
 typedef struct OrMap OrMap;
@@ -117,8 +122,21 @@ OrMap *or_map_create(const OrIndex *ix);
 void or_map_free(OrMap *m);
 /* bases: ASCII; quals: ASCII phred+33 or NULL.  Returns OR_OK (also for too-short reads). */
 int or_map_single(OrMap *m, const char *bases, const char *quals, uint32_t len, const OrParams *p);
+/* One mapSingleRead call of rmapPair with an interval set (rmap.c:1940-1954, :2010-2039): seeding restricted to the windows
+ * [lo, hi] (0-based, inclusive) of sequences sx (collectHitsFromInterVal, rmap.c:438-492), in the given order.  niv = 0 is
+ * a valid (empty) restriction.  With an index from or_index_build_fine and OR_FLG_NOSHRTINFO this is the rescue round. */
+int or_map_single_restricted(OrMap *m, const char *bases, const char *quals, uint32_t len, const OrParams *p,
+                             int niv, const int64_t *sx, const uint32_t *lo, const uint32_t *hi);
+/* The next call appends to a ResultSet whose running score maxima (UPDATE_SWATSCORMAX, results.c:1013) are these: the
+ * traceback pass raises its threshold to the set's second-best score (rmap.c:881-885).  or_map_stats then returns the
+ * maxima after the call. */
+void or_map_set_prevmax(OrMap *m, int swmax, int sw2nd);
+/* calcTotalNumberOfHits (rmap.c:1076) of the last read: what rmapPair compares to pick the mate it maps first */
+uint32_t or_map_hit_total(const OrMap *m, int ktuple_maxhit);
 /* print the stage state of the last read in the refdump line format */
 void or_map_dump(const OrMap *m, FILE *fp, unsigned long long readno, const char *name, int with_hitlists);
+/* the same into a buffer; returns the number of bytes needed (excluding the terminating 0) */
+long or_map_dump_str(const OrMap *m, unsigned long long readno, const char *name, int with_hitlists, char *buf, size_t cap);
 
 /* accessors for ctypes */
 const OrResult *or_map_results(const OrMap *m, int *n, const uint8_t **diffstr);

@@ -121,3 +121,38 @@ def write_fastq(path: str, reads, truth=None, qual: bytes = b"I", prefix: str = 
                 name += b"_%d_%d_%d" % tuple(int(x) for x in truth[i])
             s = r if isinstance(r, (bytes, bytearray)) else codes_to_ascii(r)
             f.write(b"@" + name + b"\n" + s + b"\n+\n" + qual * len(s) + b"\n")
+
+
+def make_pairs(chroms, n: int, length: int, seed: int = DEFAULT_SEED + 3, insert_mean: float = 300.0, insert_sd: float = 30.0,
+               sub_rate: float = 0.01, indel_read_frac: float = 0.02):
+    """Paired-end reads, FR orientation (BASELINE configs[2]): a fragment of length N(insert_mean,
+    insert_sd) is drawn from a random locus and strand; read 1 is its first `length` bases, read 2 the reverse complement
+    of its last `length` bases.  Returns (reads1, reads2, truth[n,4] = (chr, fragment start, strand, fragment length))."""
+    rng = np.random.default_rng(seed)
+    r1, r2 = [], []
+    truth = np.zeros((n, 4), dtype=np.int64)
+
+    def noisy(r):
+        r = r.copy()
+        if rng.random() < indel_read_frac and len(r) > 24:
+            p = int(rng.integers(10, len(r) - 10))
+            if rng.random() < 0.5:
+                r = np.concatenate([r[:p], r[p + 1:], rng.integers(0, 4, size=1, dtype=np.uint8)])
+            else:
+                r = np.concatenate([r[:p], rng.integers(0, 4, size=1, dtype=np.uint8), r[p:-1]])
+        mut = rng.random(len(r)) < sub_rate
+        return np.where(mut, (r + rng.integers(1, 4, size=len(r))) & 3, r).astype(np.uint8)
+
+    for i in range(n):
+        ci = int(rng.integers(0, len(chroms)))
+        c = chroms[ci]
+        flen = max(length, int(round(rng.normal(insert_mean, insert_sd))))
+        pos = int(rng.integers(0, len(c) - flen - 1))
+        frag = c[pos:pos + flen]
+        strand = int(rng.random() < 0.5)
+        if strand:
+            frag = revcomp_codes(frag)
+        r1.append(noisy(frag[:length]))
+        r2.append(noisy(revcomp_codes(frag[-length:])))
+        truth[i] = (ci, pos, strand, flen)
+    return r1, r2, truth

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Generate the committed PAIRED golden fixtures from the UNMODIFIED reference (BASELINE configs[2] shape in small).
+
+Runs only in the build container (needs /root/reference and `make -C oracle ref`).  For each seeded configuration it
+writes the inputs (FASTA, two FASTQ files) and the dump of `oracle/_ref/refdump -P`: the reference's own rmapPair
+(rmap.c:1744) run pair by pair, one block per mapSingleRead call it makes -- arguments (`MS`/`IV`/`PL` lines) and
+per-stage state (oracle/DUMPFORMAT.md).  The data are made so that every round of rmapPair occurs: repeat-rich references
+(second mate re-mapped without restriction, first mate re-mapped over the on-the-fly k=5 index), mates that do not map,
+mates shorter than k, reads with N, both orders of rare mate.  Fixtures are data only: inputs and expected outputs.
+"""
+import gzip
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from smalt_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+CONFIGS = [
+    dict(tag="gp_k13s6_pe", nchr=3, chrlen=200000, k=13, s=6, npairs=140, rlen=100, rep=0.35, div=0.03, opts="-i 500"),
+    dict(tag="gp_k11s3_mp", nchr=2, chrlen=150000, k=11, s=3, npairs=90, rlen=75, rep=0.3, div=0.02, opts="-i 450 -j 150 -l mp", ins=(300, 40)),
+    dict(tag="gp_k13s6_150", nchr=4, chrlen=150000, k=13, s=6, npairs=100, rlen=150, rep=0.4, div=0.05, opts="-i 500 -q 5", qualmix=True),
+]
+
+
+def make(cfg, tmp):
+    tag = cfg["tag"]
+    seed = int(hashlib.md5(tag.encode()).hexdigest()[:6], 16)
+    rng = np.random.default_rng(seed + 77)
+    ch = synth.make_reference(cfg["nchr"], cfg["chrlen"], seed=seed, repeat_frac=cfg["rep"], n_fam=2, cons_len=400, divergence=cfg["div"])
+    fa = os.path.join(tmp, tag + ".fa")
+    synth.write_fasta(fa, ch)
+    ins = cfg.get("ins", (300, 30))
+    r1, r2, _ = synth.make_pairs(ch, cfg["npairs"], cfg["rlen"], seed=seed + 1, insert_mean=ins[0], insert_sd=ins[1], sub_rate=0.02, indel_read_frac=0.2)
+    fqs = []
+    for which, reads in ((1, r1), (2, r2)):
+        fq = os.path.join(tmp, "%s_%d.fq" % (tag, which))
+        with open(fq, "wb") as f:
+            for i, r in enumerate(reads):
+                b = bytearray(synth.codes_to_ascii(r))
+                u = rng.random()
+                if u < 0.04:
+                    b = bytearray(synth.codes_to_ascii(rng.integers(0, 4, size=len(b), dtype=np.uint8)))     # a mate that maps nowhere
+                elif u < 0.07:
+                    b = b[:int(rng.integers(5, cfg["k"] + 3))]                                                  # around the word length
+                elif u < 0.12:
+                    b = b[:int(rng.integers(cfg["k"] + 8, len(b)))]
+                if rng.random() < 0.05 and len(b) > 4:
+                    b[int(rng.integers(0, len(b)))] = ord("N")
+                q = bytearray(b"I" * len(b))
+                if cfg.get("qualmix"):
+                    for j in range(len(b)):
+                        if rng.random() < 0.04:
+                            q[j] = 33 + int(rng.integers(0, 12))
+                f.write(b"@p%d/%d\n" % (i, which) + bytes(b) + b"\n+\n" + bytes(q) + b"\n")
+        fqs.append(fq)
+    pre = os.path.join(tmp, tag)
+    subprocess.run([os.path.join(REF, "smalt"), "index", "-k", str(cfg["k"]), "-s", str(cfg["s"]), pre, fa], check=True, capture_output=True)
+    dump = subprocess.run([os.path.join(REF, "refdump"), "-n", "-P", fqs[1]] + cfg["opts"].split() + [pre, fqs[0]], check=True, capture_output=True).stdout
+    for src, dst in ((fa, tag + ".fa.gz"), (fqs[0], tag + "_1.fq.gz"), (fqs[1], tag + "_2.fq.gz")):
+        with gzip.GzipFile(os.path.join(HERE, dst), "wb", mtime=0) as g:
+            g.write(open(src, "rb").read())
+    with gzip.GzipFile(os.path.join(HERE, tag + ".refdump.txt.gz"), "wb", mtime=0) as g:
+        g.write(dump)
+    text = dump.decode()
+    ncalls = text.count("\nMS ") + text.startswith("MS ")
+    return dict(tag=tag, k=cfg["k"], s=cfg["s"], opts=cfg["opts"], npairs=cfg["npairs"], calls=ncalls, restricted_calls=text.count(" fine=0") - text.count("niv=-1 fine=0"),
+                fine_calls=text.count(" fine=1"), dump_lines=dump.count(b"\n"))
+
+
+if __name__ == "__main__":
+    import tempfile
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        manifest = [make(c, tmp) for c in CONFIGS]
+    json.dump(manifest, open(os.path.join(HERE, "manifest_pairs.json"), "w"), indent=1)
+    for m in manifest:
+        print(m)

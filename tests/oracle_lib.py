@@ -5,6 +5,7 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ODIR = os.path.join(ROOT, "oracle")
+FLG_BEST, FLG_SEQBYSEQ, FLG_NOSHRTINFO, FLG_SENSITIVE = 0x02, 0x10, 0x20, 0x80     # rmap.h:53-65
 
 
 class OrIndex(C.Structure):
@@ -32,7 +33,7 @@ class OrCand(C.Structure):
 class OrResult(C.Structure):
     _fields_ = [("reverse", C.c_int), ("swatscor", C.c_int), ("q_start", C.c_uint32), ("q_end", C.c_uint32),
                 ("s_start", C.c_uint64), ("s_end", C.c_uint64), ("sidx", C.c_int64), ("stroffs", C.c_int),
-                ("strlen", C.c_int)]
+                ("strlen", C.c_int), ("cand_first", C.c_int)]
 
 
 class OrAli(C.Structure):
@@ -61,6 +62,16 @@ def lib():
         L.or_map_create.argtypes = [C.POINTER(OrIndex)]
         L.or_map_free.argtypes = [C.c_void_p]
         L.or_map_single.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint32, C.POINTER(OrParams)]
+        L.or_map_single_restricted.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint32, C.POINTER(OrParams), C.c_int,
+                                               C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.or_map_set_prevmax.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.or_map_hit_total.restype = C.c_uint32
+        L.or_map_hit_total.argtypes = [C.c_void_p, C.c_int]
+        L.or_map_dump_str.restype = C.c_long
+        L.or_map_dump_str.argtypes = [C.c_void_p, C.c_ulonglong, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
+        L.or_index_build_fine.restype = C.POINTER(OrIndex)
+        L.or_index_build_fine.argtypes = [C.POINTER(OrIndex), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int, C.c_int]
+        L.or_index_free_fine.argtypes = [C.POINTER(OrIndex)]
         L.or_map_results.restype = C.POINTER(OrResult)
         L.or_map_results.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_uint8))]
         L.or_map_cands.restype = C.POINTER(OrCand)
@@ -93,6 +104,16 @@ def build_index(seqs, names, k, s):
     return ix
 
 
+def build_fine_index(ix, intervals, k=5, s=1):
+    """The on-the-fly index of rmapPair's rescue round over the interval windows (rmap.c:495-517); free with
+    lib().or_index_free_fine BEFORE the main index."""
+    n = len(intervals)
+    sx = (C.c_int64 * max(1, n))(*[iv[0] for iv in intervals])
+    lo = (C.c_uint32 * max(1, n))(*[iv[1] for iv in intervals])
+    hi = (C.c_uint32 * max(1, n))(*[iv[2] for iv in intervals])
+    return lib().or_index_build_fine(ix, n, sx, lo, hi, k, s)
+
+
 def default_params(ix):
     p = OrParams()
     lib().or_params_default(C.byref(p), ix)
@@ -109,9 +130,20 @@ class Mapper:
             lib().or_map_free(self.m)
             self.m = None
 
-    def map(self, bases: bytes, quals, params):
-        """Returns list of dicts (raw result array of the read, reference order)."""
-        rv = lib().or_map_single(self.m, bases, quals, len(bases), C.byref(params))
+    def map(self, bases: bytes, quals, params, intervals=None, prevmax=None):
+        """Returns list of dicts (raw result array of the read, reference order).  intervals: list of (sx, lo, hi) =
+        one mapSingleRead call of rmapPair with seeding restricted to these windows (rmap.c:438-492); prevmax: running
+        score maxima of the ResultSet the call appends to."""
+        if prevmax is not None:
+            lib().or_map_set_prevmax(self.m, prevmax[0], prevmax[1])
+        if intervals is None:
+            rv = lib().or_map_single(self.m, bases, quals, len(bases), C.byref(params))
+        else:
+            n_iv = len(intervals)
+            sx = (C.c_int64 * max(1, n_iv))(*[iv[0] for iv in intervals])
+            lo = (C.c_uint32 * max(1, n_iv))(*[iv[1] for iv in intervals])
+            hi = (C.c_uint32 * max(1, n_iv))(*[iv[2] for iv in intervals])
+            rv = lib().or_map_single_restricted(self.m, bases, quals, len(bases), C.byref(params), n_iv, sx, lo, hi)
         n = C.c_int()
         dp = C.POINTER(C.c_uint8)()
         rp = lib().or_map_results(self.m, C.byref(n), C.byref(dp))
@@ -120,7 +152,17 @@ class Mapper:
             r = rp[i]
             out.append(dict(reverse=r.reverse, score=r.swatscor, q_start=r.q_start, q_end=r.q_end, s_start=r.s_start,
                             s_end=r.s_end, sidx=r.sidx, diffstr=bytes(dp[r.stroffs:r.stroffs + r.strlen])))
+        self.cand_first = [bool(rp[i].cand_first) for i in range(n.value)]
         return rv, out
+
+    def hit_total(self, ktuple_maxhit):
+        return int(lib().or_map_hit_total(self.m, ktuple_maxhit))
+
+    def dump(self, readno, name, with_hitlists=False):
+        n = lib().or_map_dump_str(self.m, readno, name.encode(), int(with_hitlists), None, 0)
+        buf = C.create_string_buffer(n + 1)
+        lib().or_map_dump_str(self.m, readno, name.encode(), int(with_hitlists), buf, n + 1)
+        return buf.value.decode()
 
     def stats(self):
         a = (C.c_int * 8)()

@@ -1,0 +1,116 @@
+"""Replay of the paired-mode reference dumps (`oracle/_ref/refdump -P`, oracle/DUMPFORMAT.md): the reference's rmapPair
+(rmap.c:1744) makes two to four mapSingleRead calls per pair -- rare mate, interval-restricted mate, unrestricted re-map,
+restricted re-map over the on-the-fly k=5 index -- and the dump records every call with its arguments (`MS`, `IV`, `PL`
+lines) and its stage state.  A mapper under test (the CPU oracle or the GPU library) is fed each call's arguments and must
+reproduce the call's block.
+
+What a call adds to a ResultSet that already holds alignments follows resultSetAddFromAli (results.c:1852-1942): the first
+new alignment is compared with the set's last one, and if it repeats it, it is dropped together with the other alignments
+of the same candidate (`append_rule`); the set's running score maxima go into the call (the traceback pass raises its
+threshold to the set's second-best score, rmap.c:881-885) and come out updated."""
+
+
+def parse(text):
+    pairs, cur, call = [], None, None
+    for ln in text.split("\n"):
+        if not ln:
+            continue
+        tag = ln.split(" ", 1)[0]
+        if tag == "PAIR":
+            f = ln.split()
+            cur = dict(no=int(f[1]), names=(f[2], f[3]), calls=[], pe=None)
+            pairs.append(cur)
+        elif tag == "MS":
+            kv = dict(x.split("=") for x in ln.split()[2:])
+            call = dict(mate=int(kv["mate"]), niv=int(kv["niv"]), fine=int(kv["fine"]), minscor=int(kv["minscor"]), mincov=int(kv["mincov"]),
+                        belowmax=int(kv["belowmax"]), flags=int(kv["flags"]), prevmax=tuple(int(x) for x in kv["prevmax"].split(",")),
+                        ivs=[], pl=None, lines=[], rs=[], rx=None, err=None)
+            cur["calls"].append(call)
+        elif tag == "IV":
+            f = ln.split()
+            call["ivs"].append((int(f[1]), int(f[2]), int(f[3])))
+        elif tag == "PL":
+            call["pl"] = result_of(ln)
+        elif tag == "PE":
+            cur["pe"] = ln
+            call = None
+        elif tag == "READ":
+            call["err"] = int(ln.rsplit("err=", 1)[1])
+            call["lines"].append(ln.rsplit(" err=", 1)[0])
+        elif tag == "RS":
+            call["rs"].append(result_of(ln))
+        elif tag == "RX":
+            call["rx"] = tuple(int(x) for x in ln.split()[1:])
+        else:
+            call["lines"].append(ln)
+    return pairs
+
+
+def result_of(ln):
+    f = ln.split()
+    return dict(reverse=1 if f[2] == "R" else 0, score=int(f[3]), q_start=int(f[4]), q_end=int(f[5]), s_start=int(f[6]), s_end=int(f[7]),
+                sidx=int(f[8]), diffstr=bytes.fromhex(f[9]) if len(f) > 9 else b"")
+
+
+def same_alignment(a, b):                   # isIdenticalResult, results.c:556-565
+    return all(a[k] == b[k] for k in ("s_start", "s_end", "q_start", "q_end", "score", "sidx"))
+
+
+def append_rule(results, cand_first, prev_last):
+    """Results of one call as they end up behind a non-empty set whose last alignment is prev_last."""
+    if prev_last is None or not results or not same_alignment(results[0], prev_last):
+        return list(results)
+    j = 1
+    while j < len(results) and not cand_first[j]:
+        j += 1
+    return list(results[j:])
+
+
+def stage_lines(dump_text):
+    """(stage lines without RS/RX, err stripped from the READ line) of one dump block"""
+    out = []
+    for ln in dump_text.split("\n"):
+        if not ln or ln[:2] in ("RS", "RX", "HL"):
+            continue
+        out.append(ln.rsplit(" err=", 1)[0] if ln.startswith("READ") else ln)
+    return out
+
+
+def check_call(call, produced_lines, results, cand_first, stats):
+    """stats: (swmax, sw2nd, nseg, nseg_tot, nhit, nhit_tot) of the produced call, which was given call["prevmax"]"""
+    exp = call["lines"]
+    for i, (x, y) in enumerate(zip(produced_lines, exp)):
+        assert x == y, ("stage line %d" % i, x, y)
+    assert len(produced_lines) == len(exp), (len(produced_lines), len(exp))
+    got = append_rule(results, cand_first, call["pl"])
+    assert len(got) == len(call["rs"]), (len(got), len(call["rs"]))
+    for a, b in zip(got, call["rs"]):
+        assert a == b, (a, b)
+    assert (len(got),) + tuple(stats[0:6]) == call["rx"], ((len(got),) + tuple(stats[0:6]), call["rx"])
+
+
+def load_fixture(entry, tmpdir):
+    """-> dict(prefix (index files written by the oracle), reads1, reads2 [(name, seq, qual)], pairs (parsed dump), min_basq)"""
+    import gzip
+    import os
+
+    import golden_util as gu
+    import oracle_lib as ol
+    tag = entry["tag"]
+    paths = {}
+    for ext in ("fa", "_1.fq", "_2.fq"):
+        p = os.path.join(str(tmpdir), tag + (ext if ext[0] == "_" else "." + ext))
+        with gzip.open(os.path.join(gu.GOLD, tag + (ext if ext[0] == "_" else "." + ext) + ".gz"), "rb") as g, open(p, "wb") as f:
+            f.write(g.read())
+        paths[ext] = p
+    names, seqs = gu.read_fasta(paths["fa"])
+    ix = ol.build_index(seqs, names, entry["k"], entry["s"])
+    prefix = os.path.join(str(tmpdir), tag)
+    assert ol.lib().or_index_write(ix, prefix.encode()) == 0
+    ol.lib().or_index_free(ix)
+    with gzip.open(os.path.join(gu.GOLD, tag + ".refdump.txt.gz"), "rt") as g:
+        pairs = parse(g.read())
+    opts = entry["opts"].split()
+    min_basq = int(opts[opts.index("-q") + 1]) if "-q" in opts else 0
+    return dict(prefix=prefix, reads1=gu.read_fastq(paths["_1.fq"]), reads2=gu.read_fastq(paths["_2.fq"]), pairs=pairs, min_basq=min_basq,
+                names=names, seqs=seqs)
