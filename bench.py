@@ -297,7 +297,7 @@ def main():
         def fetch(mp, n):
             nonlocal mapped, total_res
             out = mp.fetch_end()
-            st = np.ctypeslib.as_array(C.cast(out.stat, C.POINTER(C.c_uint32)), shape=(n, 8))
+            st = np.ctypeslib.as_array(C.cast(out.stat, C.POINTER(C.c_uint32)), shape=(n, 10))
             mapped += int((st[:, 7] > 0).sum())
             total_res += int(out.res_off[n])
             if collect:

@@ -75,9 +75,12 @@ typedef struct smaltgpu_result {
   uint32_t q_start, q_end;     /* 1-based, on the original read */
   uint64_t s_start, s_end;     /* 1-based, in sequence sidx (concatenated offset if sidx < 0) */
   int32_t sidx;
-  uint32_t reverse;            /* 1: reverse-complement strand */
+  uint32_t reverse;            /* bit 0: reverse-complement strand; bit 1 (SMALTGPU_RES_CANDFIRST): first alignment of its
+                                * candidate, i.e. of one resultSetAddFromAli call (what a binding needs to append a call's
+                                * alignments to a ResultSet that is not empty, results.c:1906-1935) */
   uint32_t stroffs, strlen;    /* DiffStr bytes in `diffstr`, strlen counts the terminating 0 */
 } smaltgpu_result;
+enum { SMALTGPU_RES_REVERSE = 1, SMALTGPU_RES_CANDFIRST = 2 };
 
 /* Per-read scalars the host post-processing needs (resultSetAlignmentStats rmap.c:1338,
  * resultSetGetMaxSwat results.c:2163). */
@@ -87,6 +90,9 @@ typedef struct smaltgpu_readstat {
   uint32_t n_hits_used, n_hits_tot;
   int32_t errcode;                    /* 0 or SMALTGPU_E* for this read */
   uint32_t nres;
+  int32_t max1scor;                   /* best score of the score pass (rmap.c:1355); < 1: mapSingleRead returned before the
+                                       * traceback pass and did NOT re-sort the ResultSet (rmap.c:1376) */
+  int32_t reserved;
 } smaltgpu_readstat;
 
 typedef struct smaltgpu_batch_out {
@@ -145,6 +151,32 @@ void smaltgpu_mapper_free(smaltgpu_mapper *m);
 int smaltgpu_map_batch(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals,
                        const uint64_t *read_off, uint32_t nreads, const smaltgpu_params *par,
                        smaltgpu_batch_out *out);
+
+/* ---- paired reads: the mapSingleRead calls inside rmapPair (rmap.c:1744-2112) ----
+ * rmapPair maps the mate with fewer k-mer hits first, then the other mate with its seeding restricted to the intervals the
+ * first one implies (setupInterValFromResultSet rmap.c:354, collectHitsFromInterVal :438), and -- depending on the mapping
+ * qualities and proper pairs found (results.c / resultpairs.c, host side) -- the second mate again without restriction and
+ * the first mate again restricted, seeded against an on-the-fly k=5 s=1 index over the interval windows (setupFineHashTable
+ * :495).  A binding runs a block of pairs through these rounds as batches: every round is one smaltgpu_map_batch_ctx call
+ * over the reads that take part in it, with the per-read context of the round. */
+typedef struct smaltgpu_interval { int32_t sidx; uint32_t lo, hi; } smaltgpu_interval;   /* interval.c:44-49: 0-based, inclusive, in sequence sidx */
+typedef struct smaltgpu_callctx {
+  const uint64_t *iv_off;        /* nreads + 1 offsets into iv, or NULL: no read is restricted.  An empty list is a valid
+                                  * restriction (no seeds).  Intervals as interValPrune leaves them: sorted, disjoint */
+  const smaltgpu_interval *iv;
+  const int32_t *min_swatscor;   /* per read, overrides par->min_swatscor (rmap.c:2031), or NULL */
+  const int32_t *prev_max;       /* per read (swatscor_max, swatscor_2ndmax) of the ResultSet the call appends to, or NULL (blank
+                                  * sets): the traceback pass raises its threshold to the set's second-best score
+                                  * (rmap.c:881-885); stat[].swatscor_max / _2ndmax return the pair after the call */
+  int32_t fine_index;            /* != 0: seed against the on-the-fly index of each read's intervals (needs iv_off);
+                                  * hit info is collected in the long form (initRMAPINFO, rmap.c:2024) */
+} smaltgpu_callctx;
+int smaltgpu_map_batch_ctx(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
+                           const smaltgpu_params *par, const smaltgpu_callctx *ctx, smaltgpu_batch_out *out);
+/* calcTotalNumberOfHits (rmap.c:1076) of every read: k-mer hits over both strands counting only words with at most
+ * par->ktuple_maxhit hits -- what rmapPair compares to decide which mate is mapped first (rmap.c:1866-1870). */
+int smaltgpu_hit_totals(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
+                        const smaltgpu_params *par, uint32_t *nhits);
 
 /* Same with the inputs already resident in HBM (device pointers); results stay on the device
  * until smaltgpu_fetch_results().  Used by bench.py so that the timed region starts with the

@@ -25,7 +25,7 @@ int resultSetInjectRaw(ResultSet *rsp, unsigned n, const smaltgpu_result *res, c
     rp->swrank = 0;
     rp->status = RSLTFLAG_SELECT;
     if (res[i].sidx == RESULTSET_UNKNOWN_SEQIDX) rp->status |= RSLTFLAG_NOSEQID;
-    if (res[i].reverse) rp->status |= RSLTFLAG_REVERSE;
+    if (res[i].reverse & SMALTGPU_RES_REVERSE) rp->status |= RSLTFLAG_REVERSE;
     rp->stroffs = DIFFSTR_LENGTH(rsp->diffstrp);
     rp->strlen = (int)res[i].strlen;
     memset(&view, 0, sizeof(view));

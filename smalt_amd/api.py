@@ -47,7 +47,16 @@ class Result(C.Structure):
 class ReadStat(C.Structure):
     _fields_ = [("swatscor_max", C.c_int32), ("swatscor_2ndmax", C.c_int32), ("n_ali_done", C.c_int32),
                 ("n_ali_tot", C.c_int32), ("n_hits_used", C.c_uint32), ("n_hits_tot", C.c_uint32),
-                ("errcode", C.c_int32), ("nres", C.c_uint32)]
+                ("errcode", C.c_int32), ("nres", C.c_uint32), ("max1scor", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Interval(C.Structure):
+    _fields_ = [("sidx", C.c_int32), ("lo", C.c_uint32), ("hi", C.c_uint32)]
+
+
+class CallCtx(C.Structure):
+    _fields_ = [("iv_off", C.POINTER(C.c_uint64)), ("iv", C.POINTER(Interval)), ("min_swatscor", C.POINTER(C.c_int32)),
+                ("prev_max", C.POINTER(C.c_int32)), ("fine_index", C.c_int32)]
 
 
 class MapperOpts(C.Structure):
@@ -91,6 +100,9 @@ def lib():
         L.smaltgpu_mapper_free.argtypes = [C.c_void_p]
         L.smaltgpu_map_batch.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint32,
                                          C.POINTER(Params), C.POINTER(BatchOut)]
+        L.smaltgpu_map_batch_ctx.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint32,
+                                             C.POINTER(Params), C.POINTER(CallCtx), C.POINTER(BatchOut)]
+        L.smaltgpu_hit_totals.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(Params), C.POINTER(C.c_uint32)]
         L.smaltgpu_map_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
                                                 C.POINTER(Params)]
         L.smaltgpu_fetch_results.argtypes = [C.c_void_p, C.POINTER(BatchOut)]
@@ -230,6 +242,49 @@ class Mapper:
             _check(rv)
         return self._unpack(out)
 
+    def map_batch_ctx(self, reads: Sequence[bytes], quals: Optional[Sequence[bytes]], params: Params, intervals=None, min_swatscor=None,
+                      prev_max=None, fine_index: bool = False):
+        """One round of rmapPair over a batch (smaltgpu_map_batch_ctx): intervals = per read a list of (sidx, lo, hi) or None
+        for no restriction at all; min_swatscor = per-read thresholds; prev_max = per read (max, 2ndmax) of the ResultSet
+        the call appends to; fine_index = seed against the on-the-fly k=5 index of the intervals.
+        -> (results, stats, cand_first flags per result)"""
+        bases, q, off = self._pack(reads, quals)
+        n = len(reads)
+        ctx = CallCtx()
+        keep = []
+        if intervals is not None:
+            ivo = (C.c_uint64 * (n + 1))()
+            flat = [iv for lst in intervals for iv in lst]
+            t = 0
+            for i, lst in enumerate(intervals):
+                ivo[i] = t
+                t += len(lst)
+            ivo[n] = t
+            arr = (Interval * max(1, len(flat)))(*[Interval(a, b, c) for a, b, c in flat])
+            ctx.iv_off, ctx.iv = ivo, arr
+            keep += [ivo, arr]
+        if min_swatscor is not None:
+            ms = (C.c_int32 * max(1, n))(*min_swatscor)
+            ctx.min_swatscor = ms
+            keep.append(ms)
+        if prev_max is not None:
+            pm = (C.c_int32 * max(1, 2 * n))(*[x for pr_ in prev_max for x in pr_])
+            ctx.prev_max = pm
+            keep.append(pm)
+        ctx.fine_index = 1 if fine_index else 0
+        out = BatchOut()
+        _check(lib().smaltgpu_map_batch_ctx(self.h, bases, q, off, n, C.byref(params), C.byref(ctx), C.byref(out)))
+        res, stats = self._unpack(out)
+        cf = [[bool(out.res[j].reverse & 2) for j in range(out.res_off[i], out.res_off[i + 1])] for i in range(n)]
+        return res, stats, cf
+
+    def hit_totals(self, reads: Sequence[bytes], quals: Optional[Sequence[bytes]], params: Params) -> List[int]:
+        """calcTotalNumberOfHits (rmap.c:1076) per read: what rmapPair compares to pick the mate it maps first."""
+        bases, q, off = self._pack(reads, quals)
+        out = (C.c_uint32 * max(1, len(reads)))()
+        _check(lib().smaltgpu_hit_totals(self.h, bases, q, off, len(reads), C.byref(params), out))
+        return list(out)[:len(reads)]
+
     def map_batch_raw(self, bases, off, quals, params: Params) -> BatchOut:
         """smaltgpu_map_batch on contiguous host arrays (numpy uint8 bases / uint64 offsets); the returned
         views stay valid until the next call on this mapper."""
@@ -245,12 +300,12 @@ class Mapper:
             rr = []
             for j in range(out.res_off[i], out.res_off[i + 1]):
                 r = out.res[j]
-                rr.append(dict(reverse=int(r.reverse), score=r.swatscor, q_start=r.q_start, q_end=r.q_end, s_start=r.s_start,
+                rr.append(dict(reverse=int(r.reverse & 1), score=r.swatscor, q_start=r.q_start, q_end=r.q_end, s_start=r.s_start,
                                s_end=r.s_end, sidx=r.sidx, diffstr=bytes(out.diffstr[r.stroffs:r.stroffs + r.strlen])))
             res.append(rr)
             s = out.stat[i]
             stats.append(dict(swmax=s.swatscor_max, sw2nd=s.swatscor_2ndmax, nseg=s.n_ali_done, nseg_tot=s.n_ali_tot,
-                              nhit=s.n_hits_used, nhit_tot=s.n_hits_tot, err=s.errcode))
+                              nhit=s.n_hits_used, nhit_tot=s.n_hits_tot, err=s.errcode, max1=s.max1scor))
         return res, stats
 
     def map_batch_device(self, d_bases: int, d_quals: int, d_off: int, nreads: int, total_bases: int, params: Params):

@@ -320,6 +320,16 @@ struct smaltgpu_mapper {
   MapPar last_par;
   bool have_host_off = false;
   int debug = 0;
+  // per-read context of rmapPair's rounds (smaltgpu_map_batch_ctx): device copies, grown on demand
+  struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t n) { if (n <= cap) return 0; if (p) (void)hipFree(p); p = nullptr; cap = 0; size_t c = n + n / 2 + 256; if (hipMalloc(&p, c) != hipSuccess) return -1; cap = c; return 0; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  };
+  DevBuf cx_ivoff, cx_iv, cx_minsw, cx_prevmax, cx_fineidx, cx_finepos, cx_fineoff;
+  std::vector<uint32_t> h_ivoff, h_fineoff;
+  std::vector<HitInfoHdr> h_hi;
+  bool last_fine = false;
   uint64_t remap_batches = 0;               // device batches smaltgpu_map_batch ran to recover from pool overflows (diagnostic)
   hipEvent_t ev[T_NUM + 1] = {nullptr};
   double ms[T_NUM] = {0};
@@ -506,6 +516,7 @@ extern "C" void smaltgpu_mapper_free(smaltgpu_mapper *m) {
                 m->sw_rows, m->align_scr, m->align_scr2};
   for (void *p : ps) if (p) (void)hipFree(p);
   m->h_stat.release(); m->h_res.release(); m->h_dstr.release();
+  m->cx_ivoff.release(); m->cx_iv.release(); m->cx_minsw.release(); m->cx_prevmax.release(); m->cx_fineidx.release(); m->cx_finepos.release(); m->cx_fineoff.release();
   if (m->ev_fetch) (void)hipEventDestroy(m->ev_fetch);
   for (int i = 0; i <= T_NUM; i++) if (m->ev[i]) (void)hipEventDestroy(m->ev[i]);
   if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -537,11 +548,18 @@ static int check_par(const smaltgpu_mapper *m, const smaltgpu_params *p) {
 }
 
 // the device pipeline over reads already in HBM
+// cx: the per-read context of one of rmapPair's rounds, already on the device (upload_ctx), or null
+struct CtxDev { const uint32_t *iv_off; const IvRec *iv; const int32_t *min_sw, *prevmax; uint32_t *fine_idx, *fine_pos; const uint32_t *fine_off; };
+
 static int run_pipeline(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_off, uint32_t n,
-                        const smaltgpu_params *par) {
+                        const smaltgpu_params *par, const CtxDev *cx = nullptr, bool seed_only = false) {
   Batch &b = m->b;
   const DevIndex &d = m->ix->d;
-  const MapPar p = to_par(par);
+  MapPar p = to_par(par);
+  b.iv_off = cx ? cx->iv_off : nullptr; b.iv = cx ? cx->iv : nullptr; b.min_sw = cx ? cx->min_sw : nullptr; b.prevmax = cx ? cx->prevmax : nullptr;
+  b.fine_idx = cx ? cx->fine_idx : nullptr; b.fine_pos = cx ? cx->fine_pos : nullptr; b.fine_off = cx ? cx->fine_off : nullptr;
+  if (b.fine_idx) p.flags |= FLG_NOSHRTINFO;            // initRMAPINFO, not the short form (rmap.c:2024)
+  m->last_fine = b.fine_idx != nullptr;
   m->last_par = p; m->last_n = n;
   b.nreads = n; b.codes = m->d_codes; b.codes_rc = m->d_codes_rc; b.qual = d_quals; b.read_off = d_off;
   hipStream_t s = m->stream;
@@ -567,9 +585,15 @@ static int run_pipeline(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_
   }
   HIPCHK(hipEventRecord(m->ev[T_ENCODE], s));
   rv = launch_encode(s, d_bases, d_off, n, m->d_codes, m->d_codes_rc);
+  if (!rv && b.fine_idx) rv = launch_fine_index(s, b, d);
   HIPCHK(hipEventRecord(m->ev[T_SEED], s));
   if (!rv) rv = launch_seed(s, b, d, p, m->seed_scr, m->seed_bytes, m->seed_slots);
   HIPCHK(hipEventRecord(m->ev[T_CANDS], s));
+  if (seed_only) {
+    for (int i = T_CANDS + 1; i <= T_NUM; i++) HIPCHK(hipEventRecord(m->ev[i], s));
+    if (rv) return fail(SMALTGPU_ENODEV, "kernel launch failed: %s", hipGetErrorString((hipError_t)rv));
+    return SMALTGPU_OK;
+  }
   { CandGeom g = cgeom; g.ngrp = ngrp; g.debug = slot_per_read; if (!two_pass) g.pass = 0; if (!rv) rv = launch_cands(s, b, d, p, cscr, cslots, g); }
   if (two_pass) { CandGeom g = m->cg2; g.ngrp = ngrp; g.debug = 0; g.pass = 2; if (!rv) rv = launch_cands(s, b, d, p, m->cand_scr2, m->cand_slots2, g); }
   HIPCHK(hipEventRecord(m->ev[T_SW_FULL], s));
@@ -655,13 +679,14 @@ extern "C" int smaltgpu_fetch_end(smaltgpu_mapper *m, smaltgpu_batch_out *out) {
     m->h_res_off[i] = w;
     smaltgpu_readstat &os = m->o_stat[i];
     os.swatscor_max = st.swmax; os.swatscor_2ndmax = st.sw2nd; os.n_ali_done = st.nseg; os.n_ali_tot = st.nseg_tot;
-    os.n_hits_used = st.nhit; os.n_hits_tot = st.nhit_tot; os.errcode = st.err; os.nres = st.nres;
+    os.n_hits_used = st.nhit; os.n_hits_tot = st.nhit_tot; os.errcode = st.err; os.nres = st.nres; os.max1scor = st.max1; os.reserved = 0;
     if (st.err) { if (!first_err) { first_err = st.err; first_err_read = i; } nerr++; }
     for (uint32_t j = 0; j < st.nres; j++) {
       const Result &r = m->h_res[st.res_off + j];
       smaltgpu_result &o = m->o_res[w++];
       o.swatscor = r.swatscor; o.q_start = r.q_start; o.q_end = r.q_end; o.s_start = r.s_start; o.s_end = r.s_end;
-      o.sidx = r.sidx; o.reverse = r.reverse; o.stroffs = (uint32_t)(st.dstr_off + r.stroffs); o.strlen = r.strlen;
+      o.sidx = r.sidx; o.reverse = (r.reverse ? SMALTGPU_RES_REVERSE : 0u) | (r.pad ? SMALTGPU_RES_CANDFIRST : 0u);
+      o.stroffs = (uint32_t)(st.dstr_off + r.stroffs); o.strlen = r.strlen;
     }
   }
   m->h_res_off[n] = w;
@@ -678,9 +703,63 @@ extern "C" int smaltgpu_fetch_results(smaltgpu_mapper *m, smaltgpu_batch_out *ou
   return smaltgpu_fetch_end(m, out);
 }
 
-// one device batch over reads in host memory: bases/quals + read_off[0..n]
+// the context of a round to the device; fills cd
+static int upload_ctx(smaltgpu_mapper *m, const smaltgpu_callctx *ctx, uint32_t n, CtxDev *cd) {
+  memset(cd, 0, sizeof(*cd));
+  hipStream_t s = m->stream;
+  const DevIndex &d = m->ix->d;
+  if (ctx->fine_index && !ctx->iv_off) return fail(SMALTGPU_EARG, "fine_index needs intervals");
+  if (ctx->iv_off) {
+    if (!ctx->iv && ctx->iv_off[n] > ctx->iv_off[0]) return fail(SMALTGPU_EARG, "null interval array");
+    const uint64_t i0 = ctx->iv_off[0], niv = ctx->iv_off[n] - i0;
+    if (niv > 0xFFFFFFF0ull) return fail(SMALTGPU_EARG, "too many intervals");
+    m->h_ivoff.resize((size_t)n + 1);
+    m->h_fineoff.assign((size_t)n + 1, 0);
+    for (uint32_t i = 0; i <= n; i++) m->h_ivoff[i] = (uint32_t)(ctx->iv_off[i] - i0);
+    for (uint32_t i = 0; i < n; i++) {
+      uint64_t npos = 0;
+      if (m->h_ivoff[i + 1] - m->h_ivoff[i] > (uint32_t)IV_MAX) return fail(SMALTGPU_EARG, "read %u has more than %d search intervals", i, (int)IV_MAX);
+      for (uint64_t v = ctx->iv_off[i]; v < ctx->iv_off[i + 1]; v++) {
+        const smaltgpu_interval &iv = ctx->iv[v];
+        if (iv.sidx < 0 || iv.sidx >= d.nseq || iv.hi < iv.lo || m->ix->sop[(size_t)iv.sidx] + iv.hi >= m->ix->sop[(size_t)iv.sidx + 1])
+          return fail(SMALTGPU_EARG, "interval %llu of read %u lies outside its sequence", (unsigned long long)(v - ctx->iv_off[i]), i);
+        if (iv.hi - iv.lo + 1 >= (uint32_t)FINE_K) npos += iv.hi - iv.lo + 1 - FINE_K + 1;
+      }
+      if (m->h_fineoff[i] + npos > 0xFFFFFFF0ull) return fail(SMALTGPU_EARG, "interval windows too large");
+      m->h_fineoff[i + 1] = (uint32_t)(m->h_fineoff[i] + npos);
+    }
+    if (m->cx_ivoff.ensure(((size_t)n + 1) * 4) || m->cx_iv.ensure((size_t)(niv ? niv : 1) * sizeof(IvRec))) return fail(SMALTGPU_ENOMEM, "device memory");
+    HIPCHK(hipMemcpyAsync(m->cx_ivoff.p, m->h_ivoff.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
+    static_assert(sizeof(IvRec) == sizeof(smaltgpu_interval), "interval layout");
+    if (niv) HIPCHK(hipMemcpyAsync(m->cx_iv.p, ctx->iv + i0, (size_t)niv * sizeof(IvRec), hipMemcpyHostToDevice, s));
+    cd->iv_off = (const uint32_t *)m->cx_ivoff.p; cd->iv = (const IvRec *)m->cx_iv.p;
+    if (ctx->fine_index) {
+      if (d.totlen + 1 > 0xFFFFFFFFull) return fail(SMALTGPU_EARG, "on-the-fly index: reference longer than 2^32 - 1 bases (rmap.c:1537-1541 would raise the stride)");
+      if (m->cx_fineidx.ensure((size_t)n * FINE_IDX_STRIDE * 4) || m->cx_finepos.ensure(((size_t)m->h_fineoff[n] + 1) * 4) || m->cx_fineoff.ensure(((size_t)n + 1) * 4))
+        return fail(SMALTGPU_ENOMEM, "device memory");
+      HIPCHK(hipMemcpyAsync(m->cx_fineoff.p, m->h_fineoff.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
+      cd->fine_idx = (uint32_t *)m->cx_fineidx.p; cd->fine_pos = (uint32_t *)m->cx_finepos.p; cd->fine_off = (const uint32_t *)m->cx_fineoff.p;
+    }
+  }
+  if (ctx->min_swatscor) {
+    // 0 is legal here: rmapPair passes the first mate's second-best score, which is 0 when there is none (rmap.c:2003-2031);
+    // the threshold block of mapSingleRead then raises it to the best first-pass score (rmap.c:1385-1393)
+    for (uint32_t i = 0; i < n; i++) if (ctx->min_swatscor[i] < 0) return fail(SMALTGPU_EARG, "negative min_swatscor");
+    if (m->cx_minsw.ensure((size_t)(n ? n : 1) * 4)) return fail(SMALTGPU_ENOMEM, "device memory");
+    if (n) HIPCHK(hipMemcpyAsync(m->cx_minsw.p, ctx->min_swatscor, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    cd->min_sw = (const int32_t *)m->cx_minsw.p;
+  }
+  if (ctx->prev_max) {
+    if (m->cx_prevmax.ensure((size_t)(n ? n : 1) * 8)) return fail(SMALTGPU_ENOMEM, "device memory");
+    if (n) HIPCHK(hipMemcpyAsync(m->cx_prevmax.p, ctx->prev_max, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    cd->prevmax = (const int32_t *)m->cx_prevmax.p;
+  }
+  return SMALTGPU_OK;
+}
+
+// one device batch over reads in host memory: bases/quals + read_off[0..n]; ctx (may be null) is indexed like the reads
 static int map_range(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
-                     const smaltgpu_params *par, smaltgpu_batch_out *out) {
+                     const smaltgpu_params *par, smaltgpu_batch_out *out, const smaltgpu_callctx *ctx = nullptr, bool seed_only = false) {
   const uint64_t total = read_off[nreads] - read_off[0];
   m->h_off.resize((size_t)nreads + 1);
   for (uint32_t i = 0; i <= nreads; i++) {
@@ -691,9 +770,11 @@ static int map_range(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *qu
   HIPCHK(hipMemcpyAsync(m->d_bases, bases + read_off[0], total, hipMemcpyHostToDevice, m->stream));
   if (quals) HIPCHK(hipMemcpyAsync(m->d_quals, quals + read_off[0], total, hipMemcpyHostToDevice, m->stream));
   HIPCHK(hipMemcpyAsync(m->d_off, m->h_off.data(), ((size_t)nreads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
-  const int rv = run_pipeline(m, m->d_bases, quals ? m->d_quals : nullptr, m->d_off, nreads, par);
+  CtxDev cd;
+  if (ctx) { const int cr = upload_ctx(m, ctx, nreads, &cd); if (cr) return cr; }
+  const int rv = run_pipeline(m, m->d_bases, quals ? m->d_quals : nullptr, m->d_off, nreads, par, ctx ? &cd : nullptr, seed_only);
   m->have_host_off = true;
-  if (rv) return rv;
+  if (rv || seed_only) return rv;
   return smaltgpu_fetch_results(m, out);
 }
 
@@ -703,7 +784,7 @@ static int map_range(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *qu
 // together, in halves when none of them fitted -- down to a single read, for which the pools hold the reference's
 // maximum of candidates.  Results are per read, so the outcome equals that of one unlimited batch.
 static int remap_overflowed(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
-                            const smaltgpu_params *par, smaltgpu_batch_out *out) {
+                            const smaltgpu_params *par, smaltgpu_batch_out *out, const smaltgpu_callctx *ctx = nullptr) {
   struct Part { std::vector<smaltgpu_result> res; std::vector<uint8_t> dstr; };
   std::vector<smaltgpu_readstat> stat(out->stat, out->stat + nreads);
   std::vector<uint64_t> off0(out->res_off, out->res_off + nreads + 1);
@@ -715,7 +796,9 @@ static int remap_overflowed(smaltgpu_mapper *m, const uint8_t *bases, const uint
   std::vector<std::vector<uint32_t>> todo(1);
   for (uint32_t i = 0; i < nreads; i++) if (stat[i].errcode == SMALTGPU_ECAP) todo[0].push_back(i);
   std::vector<uint8_t> sb, sq;
-  std::vector<uint64_t> so;
+  std::vector<uint64_t> so, civo;
+  std::vector<smaltgpu_interval> civ;
+  std::vector<int32_t> cms, cpm;
   uint32_t npermanent = 0, nbatches = 0;
   while (!todo.empty()) {
     std::vector<uint32_t> L;
@@ -729,8 +812,22 @@ static int remap_overflowed(smaltgpu_mapper *m, const uint8_t *bases, const uint
       so.push_back(sb.size());
     }
     if (sb.empty()) sb.push_back(0);
+    smaltgpu_callctx sub;
+    if (ctx) {                                          // the same reads' slice of the round's context
+      sub = *ctx;
+      civo.assign(1, 0); civ.clear(); cms.clear(); cpm.clear();
+      for (uint32_t i : L) {
+        if (ctx->iv_off) { civ.insert(civ.end(), ctx->iv + ctx->iv_off[i], ctx->iv + ctx->iv_off[i + 1]); civo.push_back(civ.size()); }
+        if (ctx->min_swatscor) cms.push_back(ctx->min_swatscor[i]);
+        if (ctx->prev_max) { cpm.push_back(ctx->prev_max[2 * (size_t)i]); cpm.push_back(ctx->prev_max[2 * (size_t)i + 1]); }
+      }
+      if (civ.empty()) civ.resize(1);
+      if (ctx->iv_off) { sub.iv_off = civo.data(); sub.iv = civ.data(); }
+      if (ctx->min_swatscor) sub.min_swatscor = cms.data();
+      if (ctx->prev_max) sub.prev_max = cpm.data();
+    }
     smaltgpu_batch_out o;
-    const int rv = map_range(m, sb.data(), quals ? sq.data() : nullptr, so.data(), (uint32_t)L.size(), par, &o);
+    const int rv = map_range(m, sb.data(), quals ? sq.data() : nullptr, so.data(), (uint32_t)L.size(), par, &o, ctx ? &sub : nullptr);
     nbatches++;
     if (rv && !((rv == SMALTGPU_ECAP || rv == SMALTGPU_EINTERNAL) && o.nreads == L.size())) return rv;
     std::vector<uint32_t> failed;
@@ -783,6 +880,27 @@ static int remap_overflowed(smaltgpu_mapper *m, const uint8_t *bases, const uint
 
 extern "C" int smaltgpu_map_batch(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
                                    const smaltgpu_params *par, smaltgpu_batch_out *out) {
+  return smaltgpu_map_batch_ctx(m, bases, quals, read_off, nreads, par, nullptr, out);
+}
+
+extern "C" int smaltgpu_hit_totals(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
+                                    const smaltgpu_params *par, uint32_t *nhits) {
+  if (!m || !bases || !read_off || !par || !nhits) return fail(SMALTGPU_EARG, "null argument");
+  if (nreads > m->max_reads) return fail(SMALTGPU_EARG, "batch of %u reads exceeds the mapper's capacity %u", nreads, m->max_reads);
+  if (read_off[nreads] - read_off[0] > m->max_bases) return fail(SMALTGPU_EARG, "batch exceeds the mapper's base capacity");
+  int rv = check_par(m, par);
+  if (rv) return rv;
+  rv = map_range(m, bases, quals, read_off, nreads, par, nullptr, nullptr, true);       // encode + seeding (S1, S2) only
+  if (rv) return rv;
+  m->h_hi.resize(2 * (size_t)nreads + 1);
+  if (nreads) HIPCHK(hipMemcpyAsync(m->h_hi.data(), m->b.hi, 2 * (size_t)nreads * sizeof(HitInfoHdr), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  for (uint32_t i = 0; i < nreads; i++) nhits[i] = m->h_hi[2 * (size_t)i].nhit_cut + m->h_hi[2 * (size_t)i + 1].nhit_cut;
+  return SMALTGPU_OK;
+}
+
+extern "C" int smaltgpu_map_batch_ctx(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
+                                       const smaltgpu_params *par, const smaltgpu_callctx *ctx, smaltgpu_batch_out *out) {
   if (!m || !bases || !read_off || !par || !out) return fail(SMALTGPU_EARG, "null argument");
   if (nreads > m->max_reads) return fail(SMALTGPU_EARG, "batch of %u reads exceeds the mapper's capacity %u", nreads, m->max_reads);
   const uint64_t total = read_off[nreads] - read_off[0];
@@ -790,8 +908,8 @@ extern "C" int smaltgpu_map_batch(smaltgpu_mapper *m, const uint8_t *bases, cons
   int rv = check_par(m, par);
   if (rv) return rv;
   out->nreads = 0;
-  rv = map_range(m, bases, quals, read_off, nreads, par, out);
-  if (rv == SMALTGPU_ECAP && out->nreads == nreads && nreads > 0 && !m->debug) return remap_overflowed(m, bases, quals, read_off, nreads, par, out);
+  rv = map_range(m, bases, quals, read_off, nreads, par, out, ctx);
+  if (rv == SMALTGPU_ECAP && out->nreads == nreads && nreads > 0 && !m->debug) return remap_overflowed(m, bases, quals, read_off, nreads, par, out, ctx);
   return rv;
 }
 
@@ -826,15 +944,16 @@ extern "C" long smaltgpu_dump_read(smaltgpu_mapper *m, uint32_t i, const char *n
       fetch(qmask, b.qmask + 2 * (size_t)i * m->qmax, 2 * (size_t)m->qmax) || fetch(ch, b.ch + i, 1) || fetch(ctl, b.ctl + i, 1) ||
       fetch(st, b.stat + i, 1) || fetch(slot, m->cand_scr_dbg + m->cand_bytes * i, m->cand_bytes)) return SMALTGPU_ENODEV;
   const uint32_t ngrp = (m->last_par.flags & FLG_SEQBYSEQ) ? (uint32_t)d.nseq : 1u;
-  const bool v2 = cands_v2_applicable(m->last_par, d.k, d.s, (uint32_t)(m->h_off[i + 1] - m->h_off[i]));
-  CandScratch cx = cand_scratch_carve(slot.data(), m->qmax, d.s, m->cg.hcap, ngrp, m->cg.segcap, m->cg.candcap);
-  CandsV2Scratch c2 = cands_v2_carve(nullptr, 0, slot.data(), m->qmax, d.s, m->cg.hcap_strand, ngrp, m->cg.candcap, true);
+  const int dk = m->last_fine ? (int)FINE_K : d.k, dsx = m->last_fine ? (int)FINE_S : d.s;
+  const bool v2 = cands_v2_applicable(m->last_par, dk, dsx, (uint32_t)(m->h_off[i + 1] - m->h_off[i]));
+  CandScratch cx = cand_scratch_carve(slot.data(), m->qmax, dsx, m->cg.hcap, ngrp, m->cg.segcap, m->cg.candcap);
+  CandsV2Scratch c2 = cands_v2_carve(nullptr, 0, slot.data(), m->qmax, dsx, m->cg.hcap_strand, ngrp, m->cg.candcap, true);
   std::vector<RCand> rc; std::vector<Result> res; std::vector<uint8_t> dstr;
   if (fetch(rc, b.rcpool + ch[0].rc_off, ch[0].n_sort) || fetch(res, b.respool + st[0].res_off, st[0].nres)) return SMALTGPU_ENODEV;
   size_t nd = 0;
   for (uint32_t j = 0; j < st[0].nres; j++) { size_t e = (size_t)res[j].stroffs + res[j].strlen; if (e > nd) nd = e; }
   if (fetch(dstr, b.dstrpool + st[0].dstr_off, nd)) return SMALTGPU_ENODEV;
-  v.qlen = (uint32_t)(m->h_off[i + 1] - m->h_off[i]); v.qmax = m->qmax; v.k = d.k;
+  v.qlen = (uint32_t)(m->h_off[i + 1] - m->h_off[i]); v.qmax = m->qmax; v.k = dk;
   for (int s2 = 0; s2 < 2; s2++) { v.hi[s2] = hi[s2]; v.seeds[s2] = seeds.data() + (size_t)s2 * m->qmax; v.qmask[s2] = qmask.data() + (size_t)s2 * m->qmax; }
   v.ch = ch[0]; v.rc = rc.data(); v.ctl = ctl[0]; v.st = st[0]; v.res = res.data(); v.dstr = dstr.data(); v.ngrp = ngrp;
   if (v2) { v.cand = c2.cand; v.sort_idx = c2.sort_idx; v.sort_keys = c2.sort_keys; v.hitwords = c2.dbg_words; v.grp_first = c2.dbg_first; v.grp_cnt = c2.dbg_cnt; }

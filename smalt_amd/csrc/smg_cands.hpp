@@ -165,7 +165,7 @@ template <bool LONG, class IT>
 SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, bool seqbyseq, uint32_t qlen, int k, int s,
                                uint32_t mincover, uint8_t *cover8, SegCand *cand, uint32_t candcap, uint32_t *ncand_io,
                                uint32_t *max_cover_io, uint32_t *max2nd_io, unsigned long long *ph,
-                               bool hold_tail, uint32_t *nproc_out, uint32_t *reg_base_io, const LongWork &lw) {
+                               bool hold_tail, uint32_t *nproc_out, uint32_t *reg_base_io, const LongWork &lw, const IvRec *ivmap = nullptr) {
   *nproc_out = n;
   if (!n) return 0;
   unsigned long long t0 = phase_clock(), t1;
@@ -344,7 +344,8 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
     if (f) {
       uint32_t lo = 0, hi = nreg;                // hit region of segment m
       while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)w.reg_first[mid] <= m) lo = mid; else hi = mid; }
-      const int32_t seqidx = seqbyseq ? (int32_t)(key_grp(w.dat[w.seed_first[w.segm_first[m]]]) & ((1u << KEY_SEQBITS) - 1)) : -1;
+      int32_t seqidx = seqbyseq ? (int32_t)(key_grp(w.dat[w.seed_first[w.segm_first[m]]]) & ((1u << KEY_SEQBITS) - 1)) : -1;
+      if (ivmap) seqidx = ivmap[seqidx].sx;       // interval-restricted call: the key's group is the interval number (rmap.c:486-490)
       SegCand c;
       const uint32_t ccover = LONG ? lw.ccov[m] : (uint32_t)w.cflag[m];
       if (derive_cand_c(c, w, m, (int)(uint32_t)w.reg_num[m], k, smg, ccover, mincover, reg_base + lo, is_reverse, seqidx)) err = SMG_ERR_ASSERT;
@@ -497,6 +498,51 @@ SMG_HD inline void dbg_hits(const CandsV2Scratch &x, const uint64_t *dat, uint32
   SMG_SYNC();
 }
 
+// hashCollectHitsForSegment's retry protocol (hashhit.c:1416-1546, 1730-1741) for one interval of a restricted call
+// (collectHitsFromInterVal, rmap.c:438-492: use_short_hitinfo = 0).  All n_seeds seeds are visited in read-offset order
+// (seedp + n), but the per-seed ceiling is tested on nhitqual_sortkeyp[n], the n-th SMALLEST hit count when the hit info was
+// collected in its short form (hashhit.c:1478-1481) -- seeds[] is kept in rank order, so seeds[n].nhits is that key and
+// ord[n] the seed at offset rank n (ord == nullptr: the info is unsorted and both orders coincide).
+SMG_HD inline FillDecision fill_decide_iv(const DevIndex &ix, const SeedRec *seeds, const uint32_t *ord, uint32_t n_seeds, uint32_t lo, uint32_t hi,
+                                          uint32_t nhit_max, int nhits_alloc, uint8_t *qmask) {
+  FillDecision d;
+  uint32_t m = nhit_max;
+  for (;;) {
+    uint32_t total = 0, n;
+    bool aborted = false;
+    for (n = 0; n < n_seeds; n++) {
+      const SeedRec &sp = seeds[ord ? ord[n] : n];
+      if (m > 0 && seeds[n].nhits > m) { qmask[sp.qoffs] = HQ_MULTIHIT; continue; }
+      const uint32_t *posp;
+      const uint32_t nhits = index_positions(ix, sp.posidx, &posp);
+      const uint32_t a = lower_bound_u32(posp, nhits, lo);
+      const uint32_t nh = nhits - a;
+      if (nh == 0) continue;
+      if (total + nh > (uint32_t)nhits_alloc) {
+        if (m > 0) { aborted = true; break; }
+        qmask[sp.qoffs] = HQ_MULTIHIT;
+        continue;
+      }
+      total += lower_bound_u32(posp, nhits, hi) - a;
+    }
+    d.n_used = n;
+    d.m_final = m;
+    m /= 2;
+    if (!(aborted && m > (uint32_t)MINHIT_PER_TUPLE)) break;
+  }
+  return d;
+}
+
+// k-mer serial range [plo, phi) of interval v (hashCollectHitsForSegment, hashhit.c:1711-1717, called with
+// sop[sx] + lo and sop[sx] + hi + 1, rmap.c:462-474)
+SMG_HD inline void iv_serials(const DevIndex &ix, const IvRec &v, uint32_t *plo, uint32_t *phi) {
+  const uint64_t offs = ix.sop[v.sx];
+  const uint64_t a = (offs + v.lo) / (uint64_t)ix.s;
+  uint64_t b = (offs + v.hi + 1) / (uint64_t)ix.s;
+  if (b > 0xFFFFFFFFull) b = 0xFFFFFFFFull;
+  *plo = (uint32_t)a; *phi = (uint32_t)b;
+}
+
 // true when the parallel form applies to this read
 SMG_HD inline bool cands_v2_applicable(const MapPar &p, int k, int s, uint32_t qlen) {
   return qlen < (1u << KEY_QBITS) && read_min_cover(p, qlen) < (uint32_t)(k + s);     // calcMinKtup (rmap.c:240-247) gives min_ktup == 1
@@ -539,12 +585,94 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   uint32_t ncand = 0, max_cover = 0, max2nd = 0, nhits_total = 0;
   if (x.dbg_first) { SMG_PAR_CHUNKS(base, 2 * ngrp) { uint32_t g = base + SMG_LANE; if (g < 2 * ngrp) { x.dbg_first[g] = 0; x.dbg_cnt[g] = 0; } } }
 
+  // rmapPair's restricted calls (rmap.c:1940-1954, :2010-2039): one hit list per interval instead of per sequence
+  const bool ivmode = b.iv_off != nullptr;
+  const uint32_t niv = ivmode ? b.iv_off[r + 1] - b.iv_off[r] : 0u;
+  const IvRec *ivr = ivmode ? b.iv + b.iv_off[r] : nullptr;
+  if (ivmode && (niv > (uint32_t)IV_MAX || (uint64_t)2 * niv > x.candcap)) err = SMG_ERR_CAP;
+
   for (uint32_t st = 0; st < 2 && !err; st++) {
     const uint32_t rs = 2 * r + st;
     const unsigned long long ts = phase_clock();
     const HitInfoHdr hdr = b.hi[rs];
     const SeedRec *seeds = b.seeds + (size_t)rs * b.qmax;
     uint8_t *qmask = b.qmask + (size_t)rs * b.qmax;
+    if (ivmode) {
+      // All seeds take part (use_short_hitinfo = 0), in read-offset order.  Hits are few (the intervals are a few hundred
+      // bases), so the strand always takes the HBM working set; what costs is finding each position list's slice.
+      const uint32_t n_all = hdr.n_seeds;
+      uint32_t tot = 0;
+      SMG_PAR_CHUNKS(base, n_all) { const uint32_t n = base + SMG_LANE; if (n < n_all && !(ncut > 0 && seeds[n].nhits > ncut)) tot += seeds[n].nhits; }
+      tot = wave_sum_u32(tot);
+      const bool all_in = tot <= (uint32_t)nhits_alloc;        // the allocation boundary cannot be reached: every seed below the ceiling contributes
+      FillDecision *dec = (FillDecision *)x.sort_keys;         // per interval (the ranking arrays are dead until S6)
+      uint32_t *ord = nullptr;
+      if (all_in) {
+        SMG_PAR_CHUNKS(base, n_all) { const uint32_t n = base + SMG_LANE; if (n < n_all && ncut > 0 && seeds[n].nhits > ncut) qmask[seeds[n].qoffs] = HQ_MULTIHIT; }
+      } else {
+        if (hdr.status & HI_SORTED) {                           // rank order -> read-offset order
+          ord = x.sort_idx;
+          SMG_PAR_CHUNKS(base, n_all) {
+            const uint32_t i = base + SMG_LANE;
+            if (i < n_all) { const uint32_t q = seeds[i].qoffs; uint32_t rk = 0; for (uint32_t j = 0; j < n_all; j++) rk += seeds[j].qoffs < q; ord[rk] = i; }
+          }
+          SMG_SYNC();
+        }
+        SMG_PAR_CHUNKS(base, niv) {
+          const uint32_t g = base + SMG_LANE;
+          if (g < niv) { uint32_t plo, phi; iv_serials(ix, ivr[g], &plo, &phi); dec[g] = fill_decide_iv(ix, seeds, ord, n_all, plo, phi, ncut, nhits_alloc, qmask); }
+        }
+      }
+      SMG_SYNC();
+      StrandWork<uint32_t> wg = strand_work_carve<uint32_t>(x.hbm, x.hcap_strand);
+      uint32_t nkeys = 0;
+      const uint32_t npairs = n_all * niv;
+      bool ovf = false;
+      SMG_PAR_CHUNKS(base, npairs) {
+        const uint32_t pi = base + SMG_LANE;
+        uint32_t cnt = 0, a = 0, g = 0, qo = 0;
+        const uint32_t *posp = nullptr;
+        if (pi < npairs) {
+          const uint32_t n = pi / niv;
+          g = pi - n * niv;
+          const SeedRec sd = seeds[ord ? ord[n] : n];
+          bool take = all_in ? !(ncut > 0 && sd.nhits > ncut) : (n < dec[g].n_used && !(dec[g].m_final > 0 && seeds[n].nhits > dec[g].m_final));
+          if (take) {
+            uint32_t plo, phi;
+            iv_serials(ix, ivr[g], &plo, &phi);
+            const uint32_t nh = index_positions(ix, sd.posidx, &posp);
+            a = lower_bound_u32(posp, nh, plo);
+            cnt = lower_bound_u32(posp, nh, phi) - a;
+            qo = sd.qoffs;
+          }
+        }
+        uint32_t incl = cnt;
+#if defined(__HIP_DEVICE_COMPILE__)
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if ((int)SMG_LANE >= o) incl += v; }
+#endif
+        const uint32_t at = nkeys + incl - cnt;
+        if (at + cnt <= x.hcap_strand) {
+          for (uint32_t j = 0; j < cnt; j++)
+            wg.dat[at + j] = ((uint64_t)g << (KEY_DIAGBITS + KEY_QBITS)) | (hit_diag_m(st != 0, posp[a + j], qo, smagic) << KEY_QBITS) | qo;
+        } else ovf = true;
+#if defined(__HIP_DEVICE_COMPILE__)
+        nkeys += (uint32_t)__shfl((int)incl, 63);
+#else
+        nkeys += incl;
+#endif
+      }
+      if (wave_any(ovf)) { err = SMG_ERR_CAP; break; }
+      SMG_SYNC();
+      uint32_t nproc = nkeys, reg_base = 0;
+      const int rv = strand_cands<LONG>(wg, nkeys, st != 0, true, qlen, k, s, min_cover, x.cover8, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph,
+                                        false, &nproc, &reg_base, x.lw, ivr);
+      t0 = phase_clock();
+      if (rv) { err = rv; break; }
+      SMG_LANE0 { ch.nhits[st] = nkeys; }
+      nhits_total += nkeys;
+      SMG_SYNC();
+      continue;
+    }
     const uint32_t n_use = hdr.seed_rank > 0 ? hdr.seed_rank : hdr.n_seeds;
     uint32_t tot = 0;
     SMG_PAR_CHUNKS(base, n_use) {

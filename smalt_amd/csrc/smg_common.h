@@ -70,7 +70,9 @@ struct MapPar {                   // scalar arguments of rmapSingle (rmap.h:127-
 struct SeedRec { uint32_t posidx, nhits, qoffs; };                 // hashhit.c:148-162
 struct HitInfoHdr {                                                 // hashhit.c:164-213
   uint32_t n_seeds, seed_rank, status, qlen;
-  uint32_t nhit_rank, nhit_tot, pad0, pad1;
+  uint32_t nhit_rank, nhit_tot;
+  uint32_t nhit_cut;        // hashCalcHitInfoNumberOfHits(ktuple_maxhit), hashhit.c:1171: what rmapPair compares to pick the rarer mate (rmap.c:1868)
+  uint32_t pad1;
 };
 
 struct SegSeed { uint64_t sqo; int32_t len; int32_t pad; };        // segment.c:162-192
@@ -122,7 +124,7 @@ struct Result {                                                     // results.c
   uint64_t s_start, s_end;
   int32_t sidx;
   uint32_t stroffs, strlen;
-  uint32_t pad;
+  uint32_t pad;             // 1: first alignment of its candidate (of one resultSetAddFromAli call, results.c:1852)
 };
 
 struct ReadStat {
@@ -132,6 +134,14 @@ struct ReadStat {
   uint32_t nres;
   uint64_t res_off;         // first Result of this read in the pool
   uint64_t dstr_off;
+  int32_t max1;             // best first-pass score (max1scor, rmap.c:1355): < 1 means mapSingleRead returned before the traceback pass
+  int32_t pad;
 };
+
+// rmapPair (rmap.c:1744-2112): one search interval of a read, [lo, hi] 0-based inclusive in sequence sx (interval.c:44-49)
+struct IvRec { int32_t sx; uint32_t lo, hi; };
+enum : int { FINE_K = 5, FINE_S = 1,              // the on-the-fly index of the rescue round (rmap.c:91-92)
+             FINE_NKEYS = 1 << (2 * FINE_K), FINE_IDX_STRIDE = FINE_NKEYS + 8,
+             IV_MAX = (1 << 10) - 1 };            // intervals per read: the interval number takes the sequence field of the hit sort key (KEY_SEQBITS)
 
 }  // namespace smg

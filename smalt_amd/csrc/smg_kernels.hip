@@ -49,14 +49,65 @@ __device__ inline uint32_t next_item(uint32_t *cursor, uint32_t *lds_slot) {
 __global__ void __launch_bounds__(64) k_seed(Batch b, DevIndex ix, MapPar p, uint8_t *gscratch, size_t gbytes, int use_lds) {
   extern __shared__ __align__(16) uint8_t lds[];
   uint8_t *base = use_lds ? lds + LDS_GUARD : gscratch + gbytes * blockIdx.x;
-  SeedScratch x = seed_scratch_carve(base, b.qmax, ix.s);
+  SeedScratch x = seed_scratch_carve(base, b.qmax, b.fine_idx ? (int)FINE_S : ix.s);
   unsigned long long nlook = 0;
   __shared__ uint32_t qslot;
   for (uint32_t rs = next_item(b.next_item + 0, &qslot); rs < 2 * b.nreads; rs = next_item(b.next_item + 0, &qslot)) {
-    nlook += stage_seed(b, ix, p, rs >> 1, rs & 1, x);
+    nlook += stage_seed(b, read_index(b, ix, rs >> 1), p, rs >> 1, rs & 1, x);
     __syncthreads();
   }
   if (threadIdx.x == 0 && nlook) atomicAdd(b.work + WK_LOOKUPS, nlook);
+}
+
+// The on-the-fly index of rmapPair's rescue round (rmap.c:495-517 setupFineHashTable -> hashTableSetUp with an interval set,
+// hashidx.c:549-575): perfect type, k = 5, s = 1, over the windows of ONE read's intervals.  One wave per read: key
+// histogram in LDS, exclusive scan = idx, positions scattered behind per-key cursors, then every key's (short) list put
+// in ascending order -- the reference fills the lists in ascending order because its intervals are sorted and disjoint.
+__global__ void __launch_bounds__(64) k_fine_index(Batch b, DevIndex ix) {
+  __shared__ uint32_t cnt[FINE_NKEYS + 1];
+  for (uint32_t r = blockIdx.x; r < b.nreads; r += gridDim.x) {
+    uint32_t *idx = b.fine_idx + (size_t)r * FINE_IDX_STRIDE;
+    uint32_t *pos = b.fine_pos + b.fine_off[r];
+    const uint32_t cap = b.fine_off[r + 1] - b.fine_off[r];
+    const uint32_t niv = b.iv_off[r + 1] - b.iv_off[r];
+    const IvRec *iv = b.iv + b.iv_off[r];
+    for (uint32_t i = threadIdx.x; i <= (uint32_t)FINE_NKEYS; i += 64) cnt[i] = 0;
+    __syncthreads();
+    for (int pass = 0; pass < 2; pass++) {
+      for (uint32_t v = 0; v < niv; v++) {
+        const uint32_t sl = iv[v].hi - iv[v].lo + 1;
+        if (sl < (uint32_t)FINE_K) continue;                        // hashidx.c:561-563
+        const uint64_t g0 = ix.sop[iv[v].sx] + iv[v].lo;
+        const uint32_t nk = sl - FINE_K + 1;
+        for (uint32_t j = threadIdx.x; j < nk; j += 64) {
+          uint32_t w = 0;
+          bool ok = true;
+          for (int t = 0; t < FINE_K; t++) { const uint32_t c = ref_code(ix.packed, g0 + j + (uint32_t)t); if (c & 4u) ok = false; w = (w << 2) | (c & 3u); }
+          if (!ok) continue;                                         // words with non-standard bases are not indexed (hashidx.c:497-503)
+          if (pass == 0) atomicAdd(&cnt[w], 1u);
+          else { const uint32_t at = atomicAdd(&cnt[w], 1u); if (at < cap) pos[at] = (uint32_t)(g0 + j); }     // serial = base offset (s = 1)
+        }
+      }
+      __syncthreads();
+      if (pass == 0) {
+        if (threadIdx.x == 0) { uint32_t c = 0; for (uint32_t i = 0; i < (uint32_t)FINE_NKEYS; i++) { const uint32_t t = cnt[i]; cnt[i] = c; c += t; } cnt[FINE_NKEYS] = c; }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i <= (uint32_t)FINE_NKEYS; i += 64) idx[i] = cnt[i];
+        __syncthreads();
+      }
+    }
+    for (uint32_t key = threadIdx.x; key < (uint32_t)FINE_NKEYS; key += 64) {      // ascending serials per key
+      const uint32_t a = idx[key], e = idx[key + 1] < cap ? idx[key + 1] : cap;
+      for (uint32_t i = a + 1; i < e; i++) { const uint32_t v = pos[i]; uint32_t j = i; while (j > a && pos[j - 1] > v) { pos[j] = pos[j - 1]; j--; } pos[j] = v; }
+    }
+    __syncthreads();
+  }
+}
+
+int launch_fine_index(hipStream_t s, const Batch &b, const DevIndex &ix) {
+  if (!b.nreads) return 0;
+  hipLaunchKernelGGL(k_fine_index, dim3(b.nreads < 65535u ? b.nreads : 65535u), dim3(64), 0, s, b, ix);
+  return (int)hipGetLastError();
 }
 
 // S3 - S7: one wave per read.  Reads the wave-parallel form covers (smg_cands.hpp) keep their
@@ -81,10 +132,13 @@ __global__ void __launch_bounds__(64, 2) k_cands(Batch b, DevIndex ix, MapPar p,
   for (uint32_t r = next_item(cursor, &qslot); r < b.nreads; r = next_item(cursor, &qslot)) {
     if (g.pass == 2 && b.ch[r].err != SMG_ERR_RETRY) continue;       // wave-uniform: the first pass finished this read
     uint8_t *base = gscratch + g.slot_bytes * (g.debug ? r : blockIdx.x);
-    if (cands_v2_applicable(p, ix.k, ix.s, read_len(b, r))) {
-      CandsV2Scratch x = cands_v2_carve(lds + LDS_GUARD, lds_bytes, base, b.qmax, ix.s, g.hcap_strand, g.ngrp, g.candcap, g.debug != 0);
+    const DevIndex rix = read_index(b, ix, r);
+    if (cands_v2_applicable(p, rix.k, rix.s, read_len(b, r))) {
+      CandsV2Scratch x = cands_v2_carve(lds + LDS_GUARD, lds_bytes, base, b.qmax, rix.s, g.hcap_strand, g.ngrp, g.candcap, g.debug != 0);
       x.window = g.window; x.lds_hits = g.lds_hits; x.tab = g.tab; x.pass = g.pass;
-      nhit += stage_cands_v2<LONGK>(b, ix, p, r, x, ph);
+      nhit += stage_cands_v2<LONGK>(b, rix, p, r, x, ph);
+    } else if (b.iv_off) {                                           // interval-restricted calls exist in the wave-parallel form only
+      if (threadIdx.x == 0) { CandHdr &ch = b.ch[r]; ch.ncand = ch.n_sort = ch.n_mincover = ch.n_reserved = 0; ch.rc_off = 0; ch.err = SMG_ERR_ASSERT; ch.max_cover = ch.max2nd_cover = 0; }
     } else if (g.pass == 1) {                                        // the sequential form waits for the full-size slots
       if (threadIdx.x == 0) { CandHdr &ch = b.ch[r]; ch.ncand = ch.n_sort = ch.n_mincover = ch.n_reserved = 0; ch.rc_off = 0; ch.err = SMG_ERR_RETRY; }
     } else {
@@ -105,7 +159,7 @@ __global__ void __launch_bounds__(64, 2) k_cands(Batch b, DevIndex ix, MapPar p,
 __global__ void __launch_bounds__(256) k_replay(Batch b, DevIndex ix, MapPar p) {
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < b.nreads) {
-    stage_replay(b, ix, p, r);
+    stage_replay(b, read_index(b, ix, r), p, r);
     atomicAdd(b.work + WK_CELLS_BAND, (unsigned long long)b.ctl[r].n_scored);     // candidates the reference would have scored
   }
 }

@@ -41,7 +41,25 @@ struct Batch {                          // one block of reads resident in HBM
   uint32_t *next_item;                  // [5] work-queue cursors of the persistent kernels (seed, cands, align, align pass 2, cands pass 2)
   uint32_t *align_retry, *align_retry_n; // reads the first K3 pass deferred to the second one (SMG_ERR_RETRY), and how many
   unsigned long long *work;             // [WK_NWORK] work counters (WK_*), one atomic per workgroup
+  // ---- per-read context of the mapSingleRead calls rmapPair makes (rmap.c:1744-2112); all null for plain batches ----
+  const uint32_t *iv_off; const IvRec *iv;   // seeding restricted to intervals iv[iv_off[r] .. iv_off[r+1]) (collectHitsFromInterVal, rmap.c:438-492)
+  const int32_t *min_sw;                // [nreads] min_swatscor of the call (rmap.c:2031: the first mate's second-best score)
+  const int32_t *prevmax;               // [2 * nreads] running score maxima of the ResultSet the call appends to (rmap.c:881-885)
+  uint32_t *fine_idx, *fine_pos;        // on-the-fly k=5 s=1 index of each read over its intervals (rmap.c:495-517): idx[r][FINE_IDX_STRIDE], pos
+  const uint32_t *fine_off;             // [nreads + 1] first position of read r in fine_pos
 };
+
+// the index a read is seeded against: the mapper's, or the read's own on-the-fly index
+SMG_HD inline DevIndex read_index(const Batch &b, const DevIndex &ix, uint32_t r) {
+  if (!b.fine_idx) return ix;
+  DevIndex f = ix;
+  f.k = FINE_K; f.s = FINE_S; f.typ = IDX_PERFECT; f.nbits_key = 2 * FINE_K; f.nbits_lo = 0; f.nkeys = FINE_NKEYS; f.nwords = 0;
+  f.idx = b.fine_idx + (size_t)r * FINE_IDX_STRIDE;
+  f.pos = b.fine_pos + b.fine_off[r];
+  f.npos = b.fine_off[r + 1] - b.fine_off[r];
+  f.wordidx = f.posidx = nullptr;
+  return f;
+}
 enum : int { WK_LOOKUPS = 0, WK_HITS = 1, WK_CELLS_FULL = 2, WK_TASKS_FULL = 3, WK_CELLS_BAND = 4, WK_NCAND = 5, WK_NKEPT = 6,
               WK_QN_TASKS = 7 /* ranked candidates of reads with non-ACGT codes */, WK_LONG_TASKS = 17 /* windows > SW_SHORT_WMAX */, WK_STRIP_TASKS = 18 /* beyond the register tiling */,
               WK_PHASE0 = 8 /* .. 23: shader-clock ticks per phase of k_cands (diagnostic) */,
@@ -146,7 +164,7 @@ SMG_HD inline uint32_t stage_seed(const Batch &b, const DevIndex &ix, const MapP
   const int minqval = p.min_basq + 33;
 
   if (qlen < (uint32_t)k) {          // ERRCODE_SHORTSEQ, swallowed by rmapSingle (rmap.c:1736)
-    SMG_LANE0 { hdr.n_seeds = 0; hdr.seed_rank = 0; hdr.status = st ? HI_REVERSE : 0; hdr.qlen = qlen; hdr.nhit_rank = hdr.nhit_tot = 0; }
+    SMG_LANE0 { hdr.n_seeds = 0; hdr.seed_rank = 0; hdr.status = st ? HI_REVERSE : 0; hdr.qlen = qlen; hdr.nhit_rank = hdr.nhit_tot = 0; hdr.nhit_cut = 0; }
     return 0;
   }
   const uint32_t nk = qlen - (uint32_t)k + 1;
@@ -303,14 +321,19 @@ SMG_HD inline uint32_t stage_seed(const Batch &b, const DevIndex &ix, const MapP
     hdr.n_seeds = nseeds; hdr.seed_rank = seed_rank; hdr.status = status; hdr.qlen = qlen;
   }
   SMG_SYNC();
+  uint32_t ncutsum = 0;
+  const uint32_t hcut = p.ncut > 0 ? (uint32_t)p.ncut : 0u;
   SMG_PAR_CHUNKS(base, nseeds) {
     uint32_t i = base + SMG_LANE;
     if (i < nseeds) {
       uint32_t src = x.sidx[i];
       SeedRec sr; sr.posidx = x.sposidx[src]; sr.nhits = x.key[i]; sr.qoffs = x.sqoffs[src];
       out[i] = sr;
+      if (!hcut || sr.nhits <= hcut) ncutsum += sr.nhits;
     }
   }
+  ncutsum = wave_sum_u32(ncutsum);
+  SMG_LANE0 { hdr.nhit_cut = ncutsum; }
   return nlook;
 }
 
@@ -681,7 +704,9 @@ SMG_HD inline void stage_replay(const Batch &b, const DevIndex &ix, const MapPar
   const CandHdr ch = b.ch[r];
   ReadCtl ctl;
   ctl.pad = 0;
-  replay_scores(ctl, b.rcpool + ch.rc_off, ch.n_sort, ch.cover_deficit, p, ix.s, ix.k, read_len(b, r));
+  MapPar q = p;
+  if (b.min_sw) q.min_swatscor = b.min_sw[r];          // rmapPair passes its own threshold to some calls (rmap.c:2031)
+  replay_scores(ctl, b.rcpool + ch.rc_off, ch.n_sort, ch.cover_deficit, q, ix.s, ix.k, read_len(b, r));
   if (ch.err) ctl.go = 0;
   b.ctl[r] = ctl;
 }
@@ -1145,7 +1170,8 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
   unsigned long long aph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (x.pass == 2 && st.err != SMG_ERR_RETRY) return;       // wave-uniform: the first pass finished this read (the kernel walks the retry list)
   SMG_LANE0 {
-    x.state[S_MINSW] = ctl.min_swatscor; x.state[S_SWMAX] = 0; x.state[S_SW2ND] = 0;
+    // a call that appends to a ResultSet continues that set's running score maxima (rmap.c:881-885 reads them)
+    x.state[S_MINSW] = ctl.min_swatscor; x.state[S_SWMAX] = b.prevmax ? b.prevmax[2 * r] : 0; x.state[S_SW2ND] = b.prevmax ? b.prevmax[2 * r + 1] : 0;
     x.state[S_NRES] = 0; x.state[S_NDSTR] = 0; x.state[S_ERR] = ch.err; x.state[S_SP] = 0; x.state[S_NALI] = 0;
   }
   // both orientations of the read next to the DP rows (codes are read once per column)
@@ -1154,7 +1180,7 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
     if (i < qlen) { x.qcodes[i] = b.codes[b.read_off[r] + i]; x.qcodes[x.qstride + i] = b.codes_rc[b.read_off[r] + i]; }
   }
   SMG_SYNC();
-  const uint32_t ncand = (ctl.go && qlen >= (uint32_t)ix.k) ? (uint32_t)ctl.n_scored : 0u;
+  const uint32_t ncand = (ctl.go && qlen >= (uint32_t)(b.fine_idx ? (int)FINE_K : ix.k)) ? (uint32_t)ctl.n_scored : 0u;
   // Candidates are visited in rank order, but only those whose first-pass score reaches the threshold are aligned
   // (rmap.c:826-828), typically one to three of a few hundred, and the threshold only rises while the read is
   // processed (rmap.c:881-885).  64 scores are tested at once against the initial threshold; the survivors are
@@ -1345,7 +1371,7 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
           else { nr.q_start = cur.q_start + 1; nr.q_end = cur.q_end + 1; }
           nr.s_start = (uint64_t)((uint32_t)c.rs + (uint32_t)cur.s_start + 1u);   // soffs is passed as SEQLEN_t
           nr.s_end = (uint64_t)((uint32_t)c.rs + (uint32_t)cur.s_end + 1u);
-          nr.sidx = c.sqidx; nr.reverse = is_rev ? 1u : 0u; nr.pad = 0;
+          nr.sidx = c.sqidx; nr.reverse = is_rev ? 1u : 0u; nr.pad = (i == 0) ? 1u : 0u;
           nr.stroffs = cur.stroffs; nr.strlen = cur.strlen;
           const Result *pp = rp - 1;
           is_new = (arrlen < 2) || !(nr.s_start == pp->s_start && nr.s_end == pp->s_end && nr.q_start == pp->q_start &&
@@ -1378,6 +1404,7 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
     st.nhit = b.hi[2 * r].nhit_rank + b.hi[2 * r + 1].nhit_rank;
     st.nhit_tot = b.hi[2 * r].nhit_tot + b.hi[2 * r + 1].nhit_tot;
     st.err = x.state[S_ERR];
+    st.max1 = ctl.max1; st.pad = 0;
     st.nres = st.err ? 0 : nres;
     st.res_off = atomic_add_u64(b.res_count, st.nres);
     st.dstr_off = atomic_add_u64(b.dstr_count, st.err ? 0 : nd);

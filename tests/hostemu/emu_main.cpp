@@ -95,6 +95,7 @@ int main(int argc, char **argv) {
   std::vector<uint8_t> dstrpool((size_t)n * 4096 + 16);
   uint32_t rc_count = 0; unsigned long long res_count = 0, dstr_count = 0; int32_t err_flag = 0;
   Batch b;
+  memset((void *)&b, 0, sizeof(b));        // no retry list, no pair context
   b.nreads = n; b.qmax = qmax; b.codes = codes.data(); b.codes_rc = codes_rc.data(); b.qual = qual.data(); b.read_off = off.data();
   b.hi = hi.data(); b.seeds = seeds.data(); b.qmask = qmask.data(); b.ch = ch.data(); b.rcpool = rcpool.data(); b.rccap = rccap;
   b.rc_count = &rc_count; b.ctl = ctl.data(); b.stat = stat.data(); b.respool = respool.data(); b.rescap = respool.size();

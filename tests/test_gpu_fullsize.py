@@ -81,7 +81,7 @@ def _map(w, reads2d):
     n = reads2d.shape[0]
     off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(reads2d.shape[1]))
     out = w["mp"].map_batch_raw(np.ascontiguousarray(reads2d).reshape(-1), off, None, w["gix"].default_params())
-    st = np.ctypeslib.as_array(C.cast(out.stat, C.POINTER(C.c_uint32)), shape=(n, 8)).copy()
+    st = np.ctypeslib.as_array(C.cast(out.stat, C.POINTER(C.c_uint32)), shape=(n, 10)).copy()
     return _results(out, n) + (st,)
 
 
