@@ -40,3 +40,29 @@ int resultSetInjectRaw(ResultSet *rsp, unsigned n, const smaltgpu_result *res, c
   rsp->swatscor_2ndmax = swatscor_2ndmax;
   return ERRCODE_SUCCESS;
 }
+
+/* A mapSingleRead call of rmapPair that APPENDS to a ResultSet (rmap.c:1976-1989, :2019-2039).  `res` are the alignments
+ * of the call as the library returns them for a fresh set, `swatscor_max/2ndmax` the set's running maxima after the call
+ * (the library was given the maxima before it, smaltgpu_callctx.prev_max).  resultSetAddFromAli (results.c:1852-1942)
+ * compares the first alignment of a candidate with the set's last one: if it repeats it, it is popped, and what the same
+ * call writes after a popped slot is lost (the array length is not advanced again) -- SMALTGPU_RES_CANDFIRST marks where the
+ * next candidate's alignments begin.  Within the call itself the library has applied the same rule already. */
+int resultSetAppendRaw(ResultSet *rsp, unsigned n, const smaltgpu_result *res, const unsigned char *dstr,
+                       int swatscor_max, int swatscor_2ndmax)
+{
+  unsigned first = 0;
+  const size_t nold = ARRLEN(rsp->resr);
+  if (n > 0 && nold > 0) {
+    const Result *lp = rsp->resr + nold - 1;
+    if ((SEQLEN_t)res[0].s_start == lp->s_start && (SEQLEN_t)res[0].s_end == lp->s_end && res[0].q_start == lp->q_start &&
+        res[0].q_end == lp->q_end && res[0].swatscor == lp->swatscor && res[0].sidx == lp->sidx)        /* isIdenticalResult, results.c:556 */
+      for (first = 1; first < n && !(res[first].reverse & SMALTGPU_RES_CANDFIRST); first++);
+  }
+  if (first < n) {
+    const int errcode = resultSetInjectRaw(rsp, n - first, res + first, dstr, swatscor_max, swatscor_2ndmax);
+    if (errcode) return errcode;
+  } else if (n > 0) rsp->status = 0;
+  rsp->swatscor_max = swatscor_max;          /* also what alignments that were popped again raised (results.c:1918) */
+  rsp->swatscor_2ndmax = swatscor_2ndmax;
+  return ERRCODE_SUCCESS;
+}

@@ -27,6 +27,8 @@
 /* results_inject.c (our TU around the reference's results.c) */
 extern int resultSetInjectRaw(ResultSet *rsp, unsigned n, const smaltgpu_result *res, const unsigned char *dstr,
                               int swatscor_max, int swatscor_2ndmax);
+extern int resultSetAppendRaw(ResultSet *rsp, unsigned n, const smaltgpu_result *res, const unsigned char *dstr,
+                              int swatscor_max, int swatscor_2ndmax);
 
 enum { GPU_MAXMAPPERS = 256 };
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -41,6 +43,8 @@ static struct {
   char *bases, *quals; uint64_t *off; size_t basecap;
   smaltgpu_batch_out out; int nbatch;          /* results of the last rmapGpuBatch */
   GpuCombOut comb; int use_comb;               /* ... when they came from a combined batch (gpu_combine.c) */
+  struct GpuPair_ *pairs; int npairs, cap_pairs; /* paired blocks (rmapGpuPairBatch): per-pair state incl. its own two ResultSets */
+  ResultSet *save_rsr, *save_rsm;
 } g_map[GPU_MAXMAPPERS];
 static int g_nmap = 0;
 
@@ -248,4 +252,306 @@ int rmapGpuFinish(ErrMsg *errmsgp, RMap *rmp, int i, SeqFastq *readp, short max_
     ERRMSGNO(errmsgp, errcode);
   if ((errcode = resultSetFilterResults(rmp->rsrp, rsfp, readp))) ERRMSGNO(errmsgp, errcode);
   return ERRCODE_SUCCESS;
+}
+
+
+/* ================================================================================================================
+ * Paired reads: rmapPair (rmap.c:1744-2112) for a whole block of pairs.
+ *
+ * rmapPair makes two to four mapSingleRead calls per pair and decides between them on mapping qualities, proper pairs and
+ * scores -- all of it results.c / resultpairs.c, which stay the reference's own code here.  The calls themselves go to the
+ * GPU as ROUNDS over the block (smaltgpu_map_batch_ctx):
+ *   round A  the mate with fewer k-mer hits (smaltgpu_hit_totals; rmap.c:1866-1905), unrestricted
+ *   round B  the other mate, seeding restricted to the intervals round A implies (rmap.c:1933-1954)
+ *   round C  pairs without a proper pair / low mapping quality / weak restricted score: the other mate unrestricted (:1965-1989)
+ *   round D  of those, pairs whose second mate came out better: the first mate restricted, over the on-the-fly k=5 index (:1994-2039)
+ * Every pair owns two ResultSets for the duration of the block; rmapGpuPairFinish makes them the RMap's for the final
+ * pairing, filters and the report.  The statements below follow rmapPair line by line; only the mapSingleRead calls are
+ * deferred to the next round.
+ * ================================================================================================================ */
+typedef struct GpuPair_ {
+  ResultSet *rs[2];            /* [0] read, [1] mate */
+  SeqFastq *sq[2];
+  unsigned char first;         /* which of the two is mapped first (rare_mate) */
+  unsigned char skip;          /* both shorter than the word length: nothing to do (rmap.c:1834) */
+  unsigned char lone, lone_w;  /* exactly one mate (lone_w) is long enough: it is mapped alone */
+  int fpp_err;                 /* return code of resultSetFindProperPairs (rmap.c:1956-1961, :2050) */
+  unsigned char need_c, need_d;
+  RSLTPAIRFLG_t pairflg;
+  int mapq1, swscor1, swscor2_restricted, n_proper, minsw_d;
+} GpuPair;
+
+/* one round: the chosen mate of the pairs sel[0..ns) through the library; per-read context arrays are indexed like sel */
+static int gpuPairRound(ErrMsg *errmsgp, int slot, GpuPair *pairs, const int *sel, const unsigned char *which, int ns,
+                        const smaltgpu_params *par, const uint64_t *iv_off, const smaltgpu_interval *iv, const int32_t *minsw,
+                        const int32_t *prevmax, int fine, smaltgpu_batch_out *out)
+{
+  int i, has_qual = 1;
+  size_t tot = 0;
+  uint32_t rlen, qlen, j, maxlen = 1;
+  char cod, qcod;
+  smaltgpu_callctx ctx;
+  for (i = 0; i < ns; i++) { (void)seqFastqGetConstSequence(pairs[sel[i]].sq[which[i]], &rlen, &cod); tot += rlen; if (rlen > maxlen) maxlen = rlen; }
+  if (gpuMapperForBatch(g_map[slot].rmp, maxlen, (uint32_t)ns, tot, 1) != slot) ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+  for (i = 0, tot = 0; i < ns; i++) {
+    const char *seqp = seqFastqGetConstSequence(pairs[sel[i]].sq[which[i]], &rlen, &cod);
+    const char *qualp = seqFastqGetConstQualityFactors(pairs[sel[i]].sq[which[i]], &qlen, &qcod);
+    g_map[slot].off[i] = tot;
+    for (j = 0; j < rlen; j++) g_map[slot].bases[tot + j] = (cod == SEQCOD_ASCII) ? seqp[j] : GPU_ALPHA[seqp[j] & SEQCOD_ALPHA_MASK];
+    if (qualp && qlen == rlen) memcpy(g_map[slot].quals + tot, qualp, rlen); else has_qual = 0;
+    tot += rlen;
+  }
+  g_map[slot].off[ns] = tot;
+  memset(&ctx, 0, sizeof(ctx));
+  ctx.iv_off = iv_off; ctx.iv = iv; ctx.min_swatscor = minsw; ctx.prev_max = prevmax; ctx.fine_index = fine;
+  if (smaltgpu_map_batch_ctx(g_map[slot].mp, (const uint8_t *)g_map[slot].bases, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
+                             g_map[slot].off, (uint32_t)ns, par, &ctx, out)) {
+    fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error());
+    ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+  }
+  return ERRCODE_SUCCESS;
+}
+
+/* what mapSingleRead does with the alignments (rmap.c:1337, :903-911, :1418): stats, results, sort + mapping qualities */
+static int gpuPairTake(ErrMsg *errmsgp, RMap *rmp, GpuPair *pp, int w, const smaltgpu_batch_out *o, int i, short max_depth,
+                       const ScoreMatrix *scormtxp, const SeqSet *ssp, const SeqCodec *codecp)
+{
+  int errcode;
+  ResultSet *rs = pp->rs[w];
+  if (o->stat[i].errcode) { fprintf(stderr, "smaltgpu: read failed on the device (code %d)\n", o->stat[i].errcode); ERRMSGNO(errmsgp, ERRCODE_FAILURE); }
+  resultSetAlignmentStats(rs, o->stat[i].n_ali_done, o->stat[i].n_ali_tot, max_depth, o->stat[i].n_hits_used, o->stat[i].n_hits_tot);
+  if ((errcode = resultSetAppendRaw(rs, (unsigned)(o->res_off[i + 1] - o->res_off[i]), o->res + o->res_off[i], o->diffstr,
+                                    o->stat[i].swatscor_max, o->stat[i].swatscor_2ndmax)))
+    ERRMSGNO(errmsgp, errcode);
+  if (o->stat[i].max1scor < 1) return ERRCODE_SUCCESS;            /* mapSingleRead returned at rmap.c:1376: no re-sort */
+  if ((errcode = makeRMAPPROFfromRead(rmp->prp, pp->sq[w], scormtxp, codecp))) ERRMSGNO(errmsgp, errcode);
+  if ((errcode = resultSetSortAndAssignSequence(rs, rmp->bfp->sqbfp, 0, pp->sq[w], rmp->prp->scorprofp, rmp->prp->scorprofRCp, ssp, codecp)))
+    ERRMSGNO(errmsgp, errcode);
+  return ERRCODE_SUCCESS;
+}
+
+int rmapGpuPairBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, SeqFastq *const *mates, int n, int d_min, int d_max,
+                     RSLTPAIRLIB_t pairlibcode, int ktuple_maxhit, double tupcovmin, int min_swatscor, UCHAR min_basqval,
+                     short target_depth, short max_depth, RMAPFLG_t rmapflg, const ScoreMatrix *scormtxp, const HashTable *htp,
+                     const SeqSet *ssp, const SeqCodec *codecp)
+{
+  int i, slot, ns, errcode = ERRCODE_SUCCESS;
+  uint32_t rlen, *tot = NULL;
+  const UCHAR ktup = hashTableGetKtupLen(htp, NULL);
+  short mismatchscor, gapinitscor, gapextscor, matchscor;
+  smaltgpu_params par;
+  smaltgpu_batch_out o;
+  GpuPair *pairs;
+  int *sel = NULL;
+  unsigned char *which = NULL;
+  uint64_t *iv_off = NULL;
+  smaltgpu_interval *iv = NULL;
+  size_t niv = 0, cap_iv = 0;
+  int32_t *minsw = NULL, *prevmax = NULL;
+  SeqFastq **all = NULL;
+
+  pthread_once(&g_once, gpuReadConfig);
+  if ((slot = gpuMapperForBatch(rmp, 64, 1, 64, 1)) < 0) { fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error()); ERRMSGNO(errmsgp, ERRCODE_FAILURE); }
+  if (g_map[slot].cap_pairs < n) {
+    GpuPair *np = realloc(g_map[slot].pairs, (size_t)n * sizeof(GpuPair));
+    if (!np) ERRMSGNO(errmsgp, ERRCODE_NOMEM);
+    memset(np + g_map[slot].cap_pairs, 0, (size_t)(n - g_map[slot].cap_pairs) * sizeof(GpuPair));
+    g_map[slot].pairs = np; g_map[slot].cap_pairs = n;
+  }
+  pairs = g_map[slot].pairs;
+  g_map[slot].npairs = 0;
+  sel = malloc((size_t)2 * n * sizeof(int)); which = malloc((size_t)2 * n); tot = malloc((size_t)2 * n * sizeof(uint32_t));
+  iv_off = malloc(((size_t)n + 1) * sizeof(uint64_t)); minsw = malloc((size_t)n * sizeof(int32_t)); prevmax = malloc((size_t)2 * n * sizeof(int32_t));
+  all = malloc((size_t)2 * n * sizeof(SeqFastq *));
+  if (!sel || !which || !tot || !iv_off || !minsw || !prevmax || !all) ERRMSGNO(errmsgp, ERRCODE_NOMEM);
+
+  /* penalties as the reference derives them for a read (rmap.c:1259) */
+  if ((errcode = makeRMAPPROFfromRead(rmp->prp, reads[0], scormtxp, codecp))) ERRMSGNO(errmsgp, errcode);
+  matchscor = scoreProfileGetAvgPenalties(&mismatchscor, &gapinitscor, &gapextscor, rmp->prp->scorprofp);
+  smaltgpu_params_default(&par, g_ix);
+  par.ktuple_maxhit = ktuple_maxhit; par.min_swatscor = min_swatscor; par.min_swatscor_below_max = MINSCOR_BELOW_MAX_BEST;
+  par.min_basqval = min_basqval; par.target_depth = target_depth; par.max_depth = max_depth;
+  par.rmapflg = rmapflg & (SMALTGPU_FLG_BEST | SMALTGPU_FLG_SEQBYSEQ | SMALTGPU_FLG_NOSHRTINFO | SMALTGPU_FLG_SENSITIVE);
+  par.match = matchscor; par.mismatch = mismatchscor; par.gap_init = gapinitscor; par.gap_ext = gapextscor;
+  if (tupcovmin < 1.01) { par.min_cover = 0; par.min_cover_frac = tupcovmin; }      /* smalt.c:1113-1147: per read and per mate */
+  else { par.min_cover = (uint32_t)tupcovmin; par.min_cover_frac = 0.0; }
+
+  /* ---- which mate first: k-mer hit totals of all 2n reads (rmap.c:1866-1905) ---- */
+  for (i = 0; i < n; i++) {
+    GpuPair *pp = pairs + i;
+    int w;
+    for (w = 0; w < 2; w++) {
+      if (!pp->rs[w] && !(pp->rs[w] = resultSetCreate(0, 0))) ERRMSGNO(errmsgp, ERRCODE_NOMEM);
+      resultSetBlank(pp->rs[w]);
+    }
+    pp->sq[0] = reads[i]; pp->sq[1] = mates[i];
+    pp->pairflg = RSLTPAIRFLG_PAIRED; pp->first = 0; pp->skip = pp->lone = pp->need_c = pp->need_d = 0;
+    pp->mapq1 = pp->swscor1 = pp->swscor2_restricted = pp->n_proper = pp->minsw_d = pp->fpp_err = 0;
+    all[2 * i] = reads[i]; all[2 * i + 1] = mates[i];
+  }
+  {
+    /* hit totals need the reads on the device: one seeding-only batch over both mates of every pair */
+    size_t nb = 0;
+    uint32_t maxlen = 1, qlen, j;
+    char cod, qcod;
+    int has_qual = 1;
+    for (i = 0; i < 2 * n; i++) { (void)seqFastqGetConstSequence(all[i], &rlen, &cod); nb += rlen; if (rlen > maxlen) maxlen = rlen; }
+    if (gpuMapperForBatch(rmp, maxlen, (uint32_t)(2 * n), nb, 1) != slot) ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+    for (i = 0, nb = 0; i < 2 * n; i++) {
+      const char *seqp = seqFastqGetConstSequence(all[i], &rlen, &cod);
+      const char *qualp = seqFastqGetConstQualityFactors(all[i], &qlen, &qcod);
+      g_map[slot].off[i] = nb;
+      for (j = 0; j < rlen; j++) g_map[slot].bases[nb + j] = (cod == SEQCOD_ASCII) ? seqp[j] : GPU_ALPHA[seqp[j] & SEQCOD_ALPHA_MASK];
+      if (qualp && qlen == rlen) memcpy(g_map[slot].quals + nb, qualp, rlen); else has_qual = 0;
+      nb += rlen;
+    }
+    g_map[slot].off[2 * n] = nb;
+    if (smaltgpu_hit_totals(g_map[slot].mp, (const uint8_t *)g_map[slot].bases, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
+                            g_map[slot].off, (uint32_t)(2 * n), &par, tot)) {
+      fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error());
+      ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+    }
+  }
+  for (i = 0; i < n; i++) {
+    GpuPair *pp = pairs + i;
+    uint32_t l0, l1;
+    (void)seqFastqGetConstSequence(pp->sq[0], &l0, NULL);
+    (void)seqFastqGetConstSequence(pp->sq[1], &l1, NULL);
+    if (l0 < ktup && l1 < ktup) { pp->skip = 1; continue; }          /* rmap.c:1833-1834 */
+    /* One mate shorter than the word length (rmap.c:1836-1864): the other one is mapped unrestricted, and the rounds that
+     * follow (nothing for the short mate, an empty restriction, no proper pair -> blank + the same unrestricted call)
+     * leave exactly that mapping.  nhit of the short mate is 0, so it counts as the mate mapped first. */
+    if (l0 < ktup || l1 < ktup) { pp->lone = 1; pp->lone_w = (l0 < ktup) ? 1 : 0; }
+    if (tot[2 * i] > tot[2 * i + 1]) { pp->pairflg |= RSLTPAIRFLG_RAREMATE; pp->first = 1; }
+  }
+
+  /* ---- round A: the first mate, unrestricted (rmap.c:1907-1918) ---- */
+  for (i = 0, ns = 0; i < n; i++) if (!pairs[i].skip && !pairs[i].lone) { sel[ns] = i; which[ns] = pairs[i].first; ns++; }
+  if (ns) {
+    if ((errcode = gpuPairRound(errmsgp, slot, pairs, sel, which, ns, &par, NULL, NULL, NULL, NULL, 0, &o))) return errcode;
+    for (i = 0; i < ns; i++) if ((errcode = gpuPairTake(errmsgp, rmp, pairs + sel[i], which[i], &o, i, max_depth, scormtxp, ssp, codecp))) return errcode;
+  }
+  /* ---- intervals from the first mate's results (rmap.c:1920-1938), round B: the second mate restricted (:1940-1954) ---- */
+  for (i = 0, niv = 0; i < ns; i++) {
+    GpuPair *pp = pairs + sel[i];
+    const int w = pp->first;
+    int v, nv;
+    pp->mapq1 = resultSetGetMappingScore(pp->rs[w], &pp->swscor1);
+    if ((errcode = setupInterValFromResultSet(rmp->ivr, d_min, d_max, pp->sq[w], pp->sq[!w], htp, ssp, pp->rs[w]))) ERRMSGNO(errmsgp, errcode);
+    interValPrune(rmp->ivr);
+    nv = interValNum(rmp->ivr);
+    iv_off[i] = niv;
+    if (niv + (size_t)nv > cap_iv) { cap_iv = 2 * (niv + (size_t)nv) + 64; if (!(iv = realloc(iv, cap_iv * sizeof(*iv)))) ERRMSGNO(errmsgp, ERRCODE_NOMEM); }
+    for (v = 0; v < nv; v++) {
+      SEQLEN_t lo, hi; SEQNUM_t sx;
+      interValGet(&lo, &hi, &sx, NULL, v, rmp->ivr);
+      iv[niv].sidx = (int32_t)sx; iv[niv].lo = lo; iv[niv].hi = hi; niv++;
+    }
+    which[i] = (unsigned char)!w;
+  }
+  iv_off[ns] = niv;
+  if (ns) {
+    if (!iv && !(iv = malloc(sizeof(*iv)))) ERRMSGNO(errmsgp, ERRCODE_NOMEM);
+    if ((errcode = gpuPairRound(errmsgp, slot, pairs, sel, which, ns, &par, iv_off, iv, NULL, NULL, 0, &o))) return errcode;
+    for (i = 0; i < ns; i++) if ((errcode = gpuPairTake(errmsgp, rmp, pairs + sel[i], which[i], &o, i, max_depth, scormtxp, ssp, codecp))) return errcode;
+  }
+  /* ---- proper pairs so far; who needs the unrestricted round (rmap.c:1956-1969) ---- */
+  for (i = 0; i < ns; i++) {
+    GpuPair *pp = pairs + sel[i];
+    const int w2 = !pp->first;
+    errcode = resultSetFindProperPairs(rmp->pairp, d_min, d_max, MAXNUM_PAIRS_TOTAL, 0, pairlibcode, pp->rs[0], pp->rs[1]);
+    if ((errcode) && errcode != ERRCODE_PAIRNUM) ERRMSGNO(errmsgp, errcode);
+    pp->fpp_err = errcode;
+    resultSetGetMappingScore(pp->rs[w2], &pp->swscor2_restricted);
+    resultSetGetNumberOfPairs(&pp->n_proper, rmp->pairp);
+    if ((rmapflg & RMAPFLG_ALLPAIR) || pp->n_proper < 1 || pp->mapq1 < MAPSCORE_UNIQUE_MAPPED_1ST ||
+        !scorIsAboveFractMax(pp->swscor2_restricted, pp->swscor1, MINFRACT_MAXSCOR_2ND, pp->sq[w2], pp->sq[!w2])) {
+      pp->need_c = 1;
+      if (pp->n_proper < 1) resultSetBlank(pp->rs[w2]);
+    } else {
+      pp->pairflg = (RSLTPAIRFLG_t)(pp->pairflg | ((pp->first == 0) ? RSLTPAIRFLG_RESTRICT_2nd : RSLTPAIRFLG_RESTRICT_1st));
+      if (errcode) ERRMSGNO(errmsgp, errcode);                   /* rmap.c:2050 with the code of resultSetFindProperPairs */
+    }
+  }
+  /* ---- round C: the second mate unrestricted (rmap.c:1976-1989); lone mates join here ---- */
+  for (i = 0, ns = 0; i < n; i++) {
+    GpuPair *pp = pairs + i;
+    if (pp->skip || !(pp->need_c || pp->lone)) continue;
+    sel[ns] = i; which[ns] = pp->lone ? pp->lone_w : (unsigned char)!pp->first;
+    prevmax[2 * ns] = resultSetGetMaxSwat(pp->rs[which[ns]], &prevmax[2 * ns + 1]);
+    ns++;
+  }
+  if (ns) {
+    if ((errcode = gpuPairRound(errmsgp, slot, pairs, sel, which, ns, &par, NULL, NULL, NULL, prevmax, 0, &o))) return errcode;
+    for (i = 0; i < ns; i++) if ((errcode = gpuPairTake(errmsgp, rmp, pairs + sel[i], which[i], &o, i, max_depth, scormtxp, ssp, codecp))) return errcode;
+  }
+  /* ---- who needs the first mate again, restricted by the second one's results (rmap.c:1991-2008) ---- */
+  {
+    int nd = 0;
+    for (i = 0, niv = 0; i < ns; i++) {
+      GpuPair *pp = pairs + sel[i];
+      const int w2 = which[i], w1 = !w2;
+      int mapq2, swscor2, v, nv;
+      if (pp->lone) continue;                                     /* the first mate is shorter than the word length (rmap.c:2012) */
+      mapq2 = resultSetGetMappingScore(pp->rs[w2], &swscor2);
+      if (!(mapq2 > MAPSCORE_UNIQUE_MAPPED_1ST || swscor2 > pp->swscor2_restricted || swscor2 > pp->swscor1)) {
+        if (pp->fpp_err) ERRMSGNO(errmsgp, pp->fpp_err);          /* rmap.c:2050: the code of resultSetFindProperPairs is still standing */
+        continue;
+      }
+      resultSetGetScorStats(pp->rs[w1], NULL, NULL, &pp->minsw_d, NULL);
+      if ((errcode = setupInterValFromResultSet(rmp->ivr, d_min, d_max, pp->sq[w2], pp->sq[w1], htp, ssp, pp->rs[w2]))) ERRMSGNO(errmsgp, errcode);
+      interValPrune(rmp->ivr);
+      (void)seqFastqGetConstSequence(pp->sq[w1], &rlen, NULL);
+      if (ktup > rlen) continue;
+      nv = interValNum(rmp->ivr);
+      iv_off[nd] = niv;
+      if (niv + (size_t)nv > cap_iv) { cap_iv = 2 * (niv + (size_t)nv) + 64; if (!(iv = realloc(iv, cap_iv * sizeof(*iv)))) ERRMSGNO(errmsgp, ERRCODE_NOMEM); }
+      for (v = 0; v < nv; v++) {
+        SEQLEN_t lo, hi; SEQNUM_t sx;
+        interValGet(&lo, &hi, &sx, NULL, v, rmp->ivr);
+        iv[niv].sidx = (int32_t)sx; iv[niv].lo = lo; iv[niv].hi = hi; niv++;
+      }
+      pp->need_d = 1;
+      sel[nd] = sel[i]; which[nd] = (unsigned char)w1;
+      minsw[nd] = pp->minsw_d;
+      prevmax[2 * nd] = resultSetGetMaxSwat(pp->rs[w1], &prevmax[2 * nd + 1]);
+      nd++;
+    }
+    iv_off[nd] = niv;
+    /* ---- round D: over the on-the-fly index of the intervals (rmap.c:2010-2039; setupFineHashTable cannot run out of
+     *      positions here: the windows of one pair hold far fewer than FINEHASH_MAXKTUPPOS words) ---- */
+    if (nd) {
+      if ((errcode = gpuPairRound(errmsgp, slot, pairs, sel, which, nd, &par, iv_off, iv, minsw, prevmax, 1, &o))) return errcode;
+      for (i = 0; i < nd; i++) if ((errcode = gpuPairTake(errmsgp, rmp, pairs + sel[i], which[i], &o, i, max_depth, scormtxp, ssp, codecp))) return errcode;
+    }
+  }
+  g_map[slot].npairs = n;
+  free(sel); free(which); free(tot); free(iv_off); free(iv); free(minsw); free(prevmax); free(all);
+  return ERRCODE_SUCCESS;
+}
+
+/* the tail of rmapPair for pair i of the block (rmap.c:2080-2110): the pair's ResultSets become the RMap's, so that
+ * rmapGetData and the report see them; rmapGpuPairRelease puts the RMap's own sets back */
+int rmapGpuPairFinish(ErrMsg *errmsgp, RMap *rmp, int i, RSLTPAIRFLG_t *pairflgp, int d_min, int d_max, RSLTPAIRLIB_t pairlibcode,
+                      const ResultFilter *rsfp)
+{
+  int errcode, slot;
+  GpuPair *pp;
+  if ((slot = gpuMapperForBatch(rmp, 1, 1, 1, 0)) < 0 || i < 0 || i >= g_map[slot].npairs) ERRMSGNO(errmsgp, ERRCODE_ASSERT);
+  pp = g_map[slot].pairs + i;
+  rmapBlank(rmp);
+  g_map[slot].save_rsr = rmp->rsrp; g_map[slot].save_rsm = rmp->rsmp;
+  rmp->rsrp = pp->rs[0]; rmp->rsmp = pp->rs[1];
+  *pairflgp = pp->pairflg;
+  if (pp->skip) return ERRCODE_SUCCESS;
+  if ((errcode = resultSetFindPairs(rmp->pairp, *pairflgp, pairlibcode, d_min, d_max, rmp->rsrp, rmp->rsmp))) ERRMSGNO(errmsgp, errcode);
+  if ((errcode = resultSetFilterResults(rmp->rsrp, rsfp, pp->sq[0]))) ERRMSGNO(errmsgp, errcode);
+  if ((errcode = resultSetFilterResults(rmp->rsmp, rsfp, pp->sq[1]))) ERRMSGNO(errmsgp, errcode);
+  return ERRCODE_SUCCESS;
+}
+
+void rmapGpuPairRelease(RMap *rmp)
+{
+  const int slot = gpuMapperForBatch(rmp, 1, 1, 1, 0);
+  if (slot >= 0 && g_map[slot].save_rsr) { rmp->rsrp = g_map[slot].save_rsr; rmp->rsmp = g_map[slot].save_rsm; g_map[slot].save_rsr = g_map[slot].save_rsm = NULL; }
 }

@@ -3,7 +3,8 @@
  * that maps a block of reads (processArgBlock, smalt.c:1221: one rmapSingle per read) is replaced, at the point where
  * smalt.c registers it with the thread pool, by a version that sends the whole block through the GPU path in one batch
  * (integration/rmap_gpu.c: rmapGpuBatch) and then runs the reference's own per-read tail -- post-processing and report
- * (smalt.c:1172-1185) -- read by read.  Paired reads and the split/complexity modes keep the reference's own worker. */
+ * (smalt.c:1172-1185) -- read by read.  A block of read PAIRS goes through rmapPair's rounds on the GPU (rmapGpuPairBatch),
+ * pairing and report pair by pair.  The split/complexity modes and pairs with -c keep the reference's own worker. */
 #include "threads.h"
 static int smaltgpu_threadsSetTask(uint8_t task_typ, short n_threads, THREAD_INITF *initf, const void *initargp, THREAD_PROCF *procf,
                                    THREAD_CLEANF *cleanf, THREAD_CHECKF *checkf, THREAD_CMPF *cmpf, size_t argsz);
@@ -14,6 +15,13 @@ static int smaltgpu_threadsSetTask(uint8_t task_typ, short n_threads, THREAD_INI
 extern int rmapGpuBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, int n, int ktuple_maxhit, double tupcovmin,
                         int min_swatscor, int min_swatscor_below_max, unsigned char min_basqval, short target_depth, short max_depth,
                         RMAPFLG_t rmapflg, const ScoreMatrix *scormtxp, const SeqCodec *codecp);
+extern int rmapGpuPairBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, SeqFastq *const *mates, int n, int d_min, int d_max,
+                            RSLTPAIRLIB_t pairlibcode, int ktuple_maxhit, double tupcovmin, int min_swatscor, unsigned char min_basqval,
+                            short target_depth, short max_depth, RMAPFLG_t rmapflg, const ScoreMatrix *scormtxp, const HashTable *htp,
+                            const SeqSet *ssp, const SeqCodec *codecp);
+extern int rmapGpuPairFinish(ErrMsg *errmsgp, RMap *rmp, int i, RSLTPAIRFLG_t *pairflgp, int d_min, int d_max, RSLTPAIRLIB_t pairlibcode,
+                             const ResultFilter *rsfp);
+extern void rmapGpuPairRelease(RMap *rmp);
 extern int rmapGpuFinish(ErrMsg *errmsgp, RMap *rmp, int i, SeqFastq *readp, short max_depth, const ScoreMatrix *scormtxp,
                          const ResultFilter *rsfp, const HashTable *htp, const SeqSet *ssp, const SeqCodec *codecp);
 
@@ -33,12 +41,54 @@ static int processArgBlockGpu(ErrMsg *errmsgp,
 
   n = blockp->n_iobf;
   if (n < 1) return ERRCODE_SUCCESS;
-  if (blockp->iobfp[0].isPaired || (rmapflg & (RMAPFLG_SPLIT | RMAPFLG_CMPLXW)) || macop->tupcovmin < 0)
+  /* not on the GPU path: split reads, complexity weighting, and pairs with a cover threshold (-c: the interval-restricted
+   * rounds of rmapPair exist in the library for the default -c 0 only) */
+  if ((macop->rmapflg & (RMAPFLG_SPLIT | RMAPFLG_CMPLXW)) || macop->tupcovmin < 0 || (blockp->iobfp[0].isPaired && macop->tupcovmin > 0.0))
     return processArgBlock(errmsgp,
 #ifdef THREADS_DEBUG
                            readno,
 #endif
                            targp, bufargp);
+  if (blockp->iobfp[0].isPaired) {             /* rmapPair for the whole block (integration/rmap_gpu.c: rounds A-D on the GPU) */
+    SeqFastq **mates;
+    if (!(reads = malloc((size_t)2 * n * sizeof(*reads)))) return ERRCODE_NOMEM;
+    mates = reads + n;
+    for (i = 0; i < n && !errcode; i++) {               /* as the head of processMapArgs (smalt.c:1102-1137) */
+      SmaltIOBuffArg *brgp = blockp->iobfp + i;
+      ERRMSG_READNO(errmsgp, brgp->readno + 1);
+      ERRMSG_READNAM(errmsgp, seqFastqGetSeqName(brgp->readp));
+      if (!brgp->isPaired) ERRMSGNO(errmsgp, ERRCODE_ASSERT);
+      if ((errcode = seqFastqEncode(brgp->readp, macop->codecp))) ERRMSGNO(errmsgp, errcode);
+      if ((errcode = seqFastqEncode(brgp->matep, macop->codecp))) ERRMSGNO(errmsgp, errcode);
+      reads[i] = brgp->readp; mates[i] = brgp->matep;
+    }
+    if (!errcode)
+      errcode = rmapGpuPairBatch(errmsgp, map->rmp, reads, mates, n, macop->insert_min, macop->insert_max, macop->pairtyp,
+                                 macop->nhitmax_tuple, macop->tupcovmin, macop->min_swatscor, macop->minbasq, SMALT_TARGET_DEPTH,
+                                 SMALT_MAX_DEPTH, (RMAPFLG_t)(macop->rmapflg | RMAPFLG_PAIRED), macop->scormtxp, macop->htp, macop->ssp,
+                                 macop->codecp);
+    for (i = 0; i < n && !errcode; i++) {               /* as the tail of rmapPair + processMapArgs (rmap.c:2080-2110, smalt.c:1166-1183) */
+      SmaltIOBuffArg *brgp = blockp->iobfp + i;
+      const ResultSet *rsltp, *rslt_matep;
+      const ResultPairs *pairp;
+      ERRMSG_READNO(errmsgp, brgp->readno + 1);
+      ERRMSG_READNAM(errmsgp, seqFastqGetSeqName(brgp->readp));
+      if ((errcode = rmapGpuPairFinish(errmsgp, map->rmp, i, &brgp->pairflg, macop->insert_min, macop->insert_max, macop->pairtyp, macop->rfp)))
+        break;
+      rmapGetData(&rsltp, &rslt_matep, &pairp, NULL, NULL, map->rmp);
+      errcode = resultSetAddPairToReport(brgp->rep, macop->ihp, pairp, brgp->pairflg, macop->rsltouflg, rsltp, rslt_matep);
+      if ((errcode)) ERRMSGNO(errmsgp, errcode);
+      if (MENU_SAMPLE == macop->subprogtyp &&
+          ERRCODE_SUCCESS == resultSetInferInsertSize(&brgp->isiz, RSLTSAMSPEC_V1P4, rsltp, rslt_matep))
+        brgp->pairflg |= RSLTPAIRFLG_INSERTSIZ;
+      rmapGpuPairRelease(map->rmp);
+    }
+    free(reads);
+#ifdef THREADS_DEBUG
+    *readno = (i > 1) ? blockp->iobfp->readno : 0;
+#endif
+    return errcode;
+  }
   if (!(reads = malloc((size_t)n * sizeof(*reads)))) return ERRCODE_NOMEM;
   for (i = 0; i < n && !errcode; i++) {                 /* as the head of processMapArgs (smalt.c:1102-1112) */
     SmaltIOBuffArg *brgp = blockp->iobfp + i;

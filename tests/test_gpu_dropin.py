@@ -50,6 +50,8 @@ def _data(tmp, nchr, chrlen, nreads, rlen, seed, with_n=False):
 ])
 def test_smalt_map_prints_the_same(k, s, nchr, chrlen, rlen, opts, tmp_path):
     tmp = str(tmp_path)
+    if "-r" not in opts:
+        opts = opts + ["-r", "3"]          # the default -r 0 seeds the tie-breaking draws with the time of day (randef.h:19)
     fa, fq = _data(tmp, nchr, chrlen, 1200, rlen, seed=k * 100 + s + nchr, with_n=True)
     pre = os.path.join(tmp, "idx")
     subprocess.run([SMALT, "index", "-k", str(k), "-s", str(s), pre, fa], check=True, capture_output=True)
@@ -96,3 +98,64 @@ def test_binding_goes_through_the_library_and_threads(tmp_path):
     for x, y in zip(a, b):
         if x != y:                       # only the reads whose best alignment is not unique may differ (class R / mapq 0-3)
             assert x.split()[0].split(":")[1] in ("R", "S") or int(x.split()[0].split(":")[2]) <= 3, (x, y)
+
+
+def _pair_data(tmp, nchr, chrlen, npairs, rlen, seed, rep=0.3, ins=(300, 30)):
+    from smalt_amd import synth
+    ch = synth.make_reference(nchr, chrlen, seed=seed, repeat_frac=rep, n_fam=2, cons_len=400, divergence=0.03)
+    fa = os.path.join(tmp, "ref.fa")
+    synth.write_fasta(fa, ch)
+    r1, r2, _ = synth.make_pairs(ch, npairs, rlen, seed=seed + 1, insert_mean=ins[0], insert_sd=ins[1], sub_rate=0.02, indel_read_frac=0.2)
+    rng = np.random.default_rng(seed + 2)
+    fqs = []
+    for which, reads in ((1, r1), (2, r2)):
+        fq = os.path.join(tmp, "reads_%d.fq" % which)
+        with open(fq, "wb") as f:
+            for i, r in enumerate(reads):
+                b = bytearray(synth.codes_to_ascii(r))
+                u = rng.random()
+                if u < 0.03:
+                    b = bytearray(synth.codes_to_ascii(rng.integers(0, 4, size=len(b), dtype=np.uint8)))    # maps nowhere
+                elif u < 0.05:
+                    b = b[:int(rng.integers(5, 16))]                                                        # around the word length
+                elif u < 0.10:
+                    b = b[:int(rng.integers(24, len(b)))]
+                if rng.random() < 0.05 and len(b) > 4:
+                    b[int(rng.integers(0, len(b)))] = ord("N")
+                q = bytes(33 + int(x) for x in rng.integers(5, 41, size=len(b)))
+                f.write(b"@p%d/%d\n" % (i, which) + bytes(b) + b"\n+\n" + q + b"\n")
+        fqs.append(fq)
+    return fa, fqs
+
+
+@pytest.mark.skipif(not (os.path.exists(SMALT) and os.path.exists(SMALT_GPU)), reason="reference binaries not built (make -C oracle ref ref_gpu)")
+@pytest.mark.parametrize("k,s,nchr,chrlen,rlen,ins,opts", [
+    (13, 6, 3, 300_000, 100, (300, 30), ["-f", "cigar", "-i", "500"]),                          # BASELINE configs[2] shape in small
+    (13, 6, 3, 300_000, 150, (300, 30), ["-f", "sam", "-i", "500", "-q", "10"]),                # SAM with mapping qualities and flags, -q
+    (11, 3, 2, 200_000, 75, (350, 40), ["-f", "sam", "-i", "600", "-j", "100", "-l", "mp"]),    # mate-pair library, insert range
+    (13, 6, 3, 300_000, 100, (300, 30), ["-f", "cigar", "-i", "500", "-n", "3", "-O", "-r", "-1"]),   # worker threads
+    (13, 6, 600, 2_000, 100, (300, 30), ["-f", "sam", "-i", "500"]),                            # >= 512 reference sequences: concatenated mode
+    (13, 6, 2, 250_000, 100, (300, 30), ["-f", "cigar", "-i", "500", "-x"]),                    # exhaustive search (long hit info for both mates)
+])
+def test_smalt_map_pairs_prints_the_same(k, s, nchr, chrlen, rlen, ins, opts, tmp_path):
+    """Paired reads: rmapPair's rounds (rare mate, restricted mate, unrestricted re-map, re-map over the on-the-fly k=5 index)
+    run on the GPU for whole blocks of pairs (integration/rmap_gpu.c: rmapGpuPairBatch); pairing, mapping qualities, pair
+    classes and output are the reference's own code.  Byte-identical output to the unmodified `smalt map`."""
+    tmp = str(tmp_path)
+    if "-r" not in opts:
+        opts = opts + ["-r", "3"]          # the default -r 0 seeds the tie-breaking draws with the time of day (randef.h:19)
+    fa, fqs = _pair_data(tmp, nchr, chrlen, 700, rlen, seed=k * 131 + s + nchr, rep=0.3 if nchr < 100 else 0.0, ins=ins)
+    pre = os.path.join(tmp, "idx")
+    subprocess.run([SMALT, "index", "-k", str(k), "-s", str(s), pre, fa], check=True, capture_output=True)
+    out_ref, out_gpu = os.path.join(tmp, "ref.out"), os.path.join(tmp, "gpu.out")
+    subprocess.run([SMALT, "map"] + opts + ["-o", out_ref, pre] + fqs, check=True, capture_output=True)
+    env = dict(os.environ, SMALTGPU_INDEX_PREFIX=pre)
+    a = [ln for ln in open(out_ref).read().split("\n") if not ln.startswith("@PG")]
+    assert sum(1 for ln in a if ln and not ln.startswith("@")) >= 1000
+    for extra in ({}, {"SMALTGPU_CANDS_PER_READ": "8"}):
+        r = subprocess.run([SMALT_GPU, "map"] + opts + ["-o", out_gpu, pre] + fqs, capture_output=True, env=dict(env, **extra))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        b = [ln for ln in open(out_gpu).read().split("\n") if not ln.startswith("@PG")]
+        assert len(a) == len(b)
+        diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
+        assert not diff, (extra, len(diff), diff[:3])
