@@ -21,6 +21,7 @@ typedef struct {
   const char *bases, *quals; const uint64_t *off; uint32_t n;
   const smaltgpu_params *par;
   GpuCombOut *out;
+  const GpuCombCtx *ctx;        /* round of rmapPair this request belongs to (NULL: plain reads); only equal kinds are combined */
   int done, rv;
   char err[256];                /* smaltgpu_last_error() is per thread: the leader copies its message to every request */
 } CombReq;
@@ -44,6 +45,9 @@ struct CombSlot {
   int busy;
   smaltgpu_mapper *mp; uint32_t cap_reads, cap_len;
   char *bases, *quals; uint64_t *off; size_t basecap;
+  /* merged per-read context of a paired round */
+  uint64_t *iv_off; smaltgpu_interval *iv; int32_t *minsw, *prevmax; uint32_t *tot;
+  size_t cap_ivoff, cap_iv, cap_minsw, cap_prevmax, cap_tot;
 };
 /* ONE queue of pending worker blocks for all devices -- the reference's workers pull blocks from one FIFO (threads.c:548);
  * here whichever device has a free mapper slot takes the next cohort, so a device that got repeat-rich reads does not
@@ -113,7 +117,44 @@ static void run_batch(struct CombSlot *d, const smaltgpu_index *ix, CombReq **re
       pos += len;
     }
     d->off[k] = pos;
-    rv = smaltgpu_map_batch(d->mp, (const uint8_t *)d->bases, has_qual ? (const uint8_t *)d->quals : NULL, d->off, ntot, reqs[0]->par, &o);
+    if (!reqs[0]->ctx) rv = smaltgpu_map_batch(d->mp, (const uint8_t *)d->bases, has_qual ? (const uint8_t *)d->quals : NULL, d->off, ntot, reqs[0]->par, &o);
+    else {                                              /* a round of rmapPair: the requests' contexts side by side */
+      const GpuCombCtx *c0 = reqs[0]->ctx;
+      smaltgpu_callctx ctx;
+      size_t niv = 0;
+      memset(&ctx, 0, sizeof(ctx));
+      if (c0->iv_off) for (i = 0; i < nreq; i++) niv += (size_t)(reqs[i]->ctx->iv_off[reqs[i]->n] - reqs[i]->ctx->iv_off[0]);
+      if ((c0->iv_off && (grow((void **)&d->iv_off, &d->cap_ivoff, (size_t)ntot + 1, sizeof(uint64_t)) || grow((void **)&d->iv, &d->cap_iv, niv + 1, sizeof(smaltgpu_interval)))) ||
+          (c0->minsw && grow((void **)&d->minsw, &d->cap_minsw, (size_t)ntot + 1, sizeof(int32_t))) ||
+          (c0->prevmax && grow((void **)&d->prevmax, &d->cap_prevmax, 2 * (size_t)ntot + 2, sizeof(int32_t))) ||
+          (c0->kind == GPUCOMB_TOTALS && grow((void **)&d->tot, &d->cap_tot, (size_t)ntot + 1, sizeof(uint32_t)))) rv = SMALTGPU_ENOMEM;
+      else {
+        for (i = 0, k = 0, niv = 0; i < nreq; i++) {
+          const GpuCombCtx *c = reqs[i]->ctx;
+          uint32_t j;
+          for (j = 0; j < reqs[i]->n; j++, k++) {
+            if (c->iv_off) {
+              uint64_t v;
+              d->iv_off[k] = niv;
+              for (v = c->iv_off[j]; v < c->iv_off[j + 1]; v++) d->iv[niv++] = c->iv[v];
+            }
+            if (c->minsw) d->minsw[k] = c->minsw[j];
+            if (c->prevmax) { d->prevmax[2 * k] = c->prevmax[2 * j]; d->prevmax[2 * k + 1] = c->prevmax[2 * j + 1]; }
+          }
+        }
+        if (c0->iv_off) { d->iv_off[k] = niv; ctx.iv_off = d->iv_off; ctx.iv = d->iv; }
+        if (c0->minsw) ctx.min_swatscor = d->minsw;
+        if (c0->prevmax) ctx.prev_max = d->prevmax;
+        ctx.fine_index = c0->kind == GPUCOMB_FINE;
+        if (c0->kind == GPUCOMB_TOTALS) {
+          rv = smaltgpu_hit_totals(d->mp, (const uint8_t *)d->bases, has_qual ? (const uint8_t *)d->quals : NULL, d->off, ntot, reqs[0]->par, d->tot);
+          for (i = 0, k = 0; i < nreq && !rv; i++) { memcpy(reqs[i]->ctx->tot_out, d->tot + k, (size_t)reqs[i]->n * sizeof(uint32_t)); k += reqs[i]->n; }
+          for (i = 0; i < nreq; i++) { reqs[i]->rv = rv; if (rv) { strncpy(reqs[i]->err, smaltgpu_last_error(), sizeof(reqs[i]->err) - 1); reqs[i]->err[sizeof(reqs[i]->err) - 1] = 0; } }
+          return;
+        }
+        rv = smaltgpu_map_batch_ctx(d->mp, (const uint8_t *)d->bases, has_qual ? (const uint8_t *)d->quals : NULL, d->off, ntot, reqs[0]->par, &ctx, &o);
+      }
+    }
     /* pool overflows are recovered inside the library; what can remain is a read that fails on its own (stat[].errcode):
      * the batch is complete for every other read, so hand the slices out and let the owner of that read report it */
     if ((rv == SMALTGPU_ECAP || rv == SMALTGPU_EINTERNAL) && o.nreads == ntot) rv = 0;
@@ -150,6 +191,12 @@ static void run_batch(struct CombSlot *d, const smaltgpu_index *ix, CombReq **re
 int gpuCombineSubmit(int ndev, const smaltgpu_index *const *ixs, const char *bases, const char *quals, const uint64_t *off, uint32_t n,
                      const smaltgpu_params *par, GpuCombOut *out, char *errbuf, size_t errcap)
 {
+  return gpuCombineSubmitCtx(ndev, ixs, bases, quals, off, n, par, NULL, out, errbuf, errcap);
+}
+
+int gpuCombineSubmitCtx(int ndev, const smaltgpu_index *const *ixs, const char *bases, const char *quals, const uint64_t *off, uint32_t n,
+                        const smaltgpu_params *par, const GpuCombCtx *ctx, GpuCombOut *out, char *errbuf, size_t errcap)
+{
   struct CombQueue *d = &g_q;
   CombReq req;
   if (ndev < 1 || ndev > COMB_MAXDEV || !ixs || !n) return SMALTGPU_EARG;
@@ -163,7 +210,7 @@ int gpuCombineSubmit(int ndev, const smaltgpu_index *const *ixs, const char *bas
     d->init = 1;
   }
   pthread_mutex_unlock(&g_init);
-  req.bases = bases; req.quals = quals; req.off = off; req.n = n; req.par = par; req.out = out; req.done = 0; req.rv = 0; req.err[0] = 0;
+  req.bases = bases; req.quals = quals; req.off = off; req.n = n; req.par = par; req.out = out; req.ctx = ctx; req.done = 0; req.rv = 0; req.err[0] = 0;
   pthread_mutex_lock(&d->mu);
   while (d->npending >= COMB_MAXREQ) pthread_cond_wait(&d->cv, &d->mu);
   d->pending[d->npending++] = &req;
@@ -188,12 +235,16 @@ int gpuCombineSubmit(int ndev, const smaltgpu_index *const *ixs, const char *bas
         if (d->npending == before) break;
       }
       const uint32_t maxreads = g_cfg.combine_reads;
-      for (i = 0; i < d->npending; i++) {
-        if (ntake && reads + d->pending[i]->n > maxreads) break;
-        reads += d->pending[i]->n; take[ntake++] = d->pending[i];
+      {                                                    /* the oldest request decides the kind of batch; other kinds keep their place in the queue */
+        const int kind = d->pending[0]->ctx ? d->pending[0]->ctx->kind : GPUCOMB_PLAIN;
+        int keep = 0;
+        for (i = 0; i < d->npending; i++) {
+          const int ki = d->pending[i]->ctx ? d->pending[i]->ctx->kind : GPUCOMB_PLAIN;
+          if (ki == kind && !(ntake && reads + d->pending[i]->n > maxreads) && ntake < COMB_MAXREQ) { reads += d->pending[i]->n; take[ntake++] = d->pending[i]; }
+          else d->pending[keep++] = d->pending[i];
+        }
+        d->npending = keep;
       }
-      memmove(d->pending, d->pending + ntake, (size_t)(d->npending - ntake) * sizeof(d->pending[0]));
-      d->npending -= ntake;
       d->assembling = 0;                                     /* the next leader may collect while this batch runs */
       pthread_cond_broadcast(&d->cv);
       pthread_mutex_unlock(&d->mu);

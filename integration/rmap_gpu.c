@@ -281,33 +281,62 @@ typedef struct GpuPair_ {
   int mapq1, swscor1, swscor2_restricted, n_proper, minsw_d;
 } GpuPair;
 
-/* one round: the chosen mate of the pairs sel[0..ns) through the library; per-read context arrays are indexed like sel */
-static int gpuPairRound(ErrMsg *errmsgp, int slot, GpuPair *pairs, const int *sel, const unsigned char *which, int ns,
-                        const smaltgpu_params *par, const uint64_t *iv_off, const smaltgpu_interval *iv, const int32_t *minsw,
-                        const int32_t *prevmax, int fine, smaltgpu_batch_out *out)
+/* reads into the worker's staging buffers; returns has_qual */
+static int gpuStage(int slot, SeqFastq *const *sq, int ns)
 {
   int i, has_qual = 1;
   size_t tot = 0;
-  uint32_t rlen, qlen, j, maxlen = 1;
+  uint32_t rlen, qlen, j;
   char cod, qcod;
-  smaltgpu_callctx ctx;
-  for (i = 0; i < ns; i++) { (void)seqFastqGetConstSequence(pairs[sel[i]].sq[which[i]], &rlen, &cod); tot += rlen; if (rlen > maxlen) maxlen = rlen; }
-  if (gpuMapperForBatch(g_map[slot].rmp, maxlen, (uint32_t)ns, tot, 1) != slot) ERRMSGNO(errmsgp, ERRCODE_FAILURE);
-  for (i = 0, tot = 0; i < ns; i++) {
-    const char *seqp = seqFastqGetConstSequence(pairs[sel[i]].sq[which[i]], &rlen, &cod);
-    const char *qualp = seqFastqGetConstQualityFactors(pairs[sel[i]].sq[which[i]], &qlen, &qcod);
+  for (i = 0; i < ns; i++) {
+    const char *seqp = seqFastqGetConstSequence(sq[i], &rlen, &cod);
+    const char *qualp = seqFastqGetConstQualityFactors(sq[i], &qlen, &qcod);
     g_map[slot].off[i] = tot;
     for (j = 0; j < rlen; j++) g_map[slot].bases[tot + j] = (cod == SEQCOD_ASCII) ? seqp[j] : GPU_ALPHA[seqp[j] & SEQCOD_ALPHA_MASK];
     if (qualp && qlen == rlen) memcpy(g_map[slot].quals + tot, qualp, rlen); else has_qual = 0;
     tot += rlen;
   }
   g_map[slot].off[ns] = tot;
-  memset(&ctx, 0, sizeof(ctx));
-  ctx.iv_off = iv_off; ctx.iv = iv; ctx.min_swatscor = minsw; ctx.prev_max = prevmax; ctx.fine_index = fine;
-  if (smaltgpu_map_batch_ctx(g_map[slot].mp, (const uint8_t *)g_map[slot].bases, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
-                             g_map[slot].off, (uint32_t)ns, par, &ctx, out)) {
-    fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error());
-    ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+  return has_qual;
+}
+
+/* One round: reads sq[0..ns) through the library with the round's per-read context.  By default the rounds of all worker
+ * threads meet in the shared queue (gpu_combine.c: requests of the same kind form one batch on a shared mapper);
+ * SMALTGPU_NO_COMBINE gives the worker its own mapper.  kind GPUCOMB_TOTALS fills tot_out instead of out. */
+static int gpuPairRound(ErrMsg *errmsgp, int slot, SeqFastq *const *sq, int ns, const smaltgpu_params *par, int kind,
+                        const uint64_t *iv_off, const smaltgpu_interval *iv, const int32_t *minsw, const int32_t *prevmax,
+                        uint32_t *tot_out, smaltgpu_batch_out *out)
+{
+  int i, has_qual;
+  size_t tot = 0;
+  uint32_t rlen, maxlen = 1;
+  for (i = 0; i < ns; i++) { (void)seqFastqGetConstSequence(sq[i], &rlen, NULL); tot += rlen; if (rlen > maxlen) maxlen = rlen; }
+  if (gpuMapperForBatch(g_map[slot].rmp, maxlen, (uint32_t)ns, tot, !g_combine) != slot) ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+  has_qual = gpuStage(slot, sq, ns);
+  if (g_combine) {
+    GpuCombCtx cc;
+    char emsg[256] = "";
+    memset(&cc, 0, sizeof(cc));
+    cc.kind = kind; cc.iv_off = iv_off; cc.iv = iv; cc.minsw = minsw; cc.prevmax = prevmax; cc.tot_out = tot_out;
+    if (gpuCombineSubmitCtx(g_ndev, (const smaltgpu_index *const *)g_ixdev, g_map[slot].bases, has_qual ? g_map[slot].quals : NULL, g_map[slot].off,
+                            (uint32_t)ns, par, kind == GPUCOMB_PLAIN ? NULL : &cc, &g_map[slot].comb, emsg, sizeof(emsg))) {
+      fprintf(stderr, "smaltgpu: %s\n", emsg);
+      ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+    }
+    if (out) { out->nreads = (uint32_t)ns; out->res_off = g_map[slot].comb.res_off; out->res = g_map[slot].comb.res; out->diffstr = g_map[slot].comb.dstr; out->stat = g_map[slot].comb.stat; }
+  } else {
+    int rv;
+    if (kind == GPUCOMB_TOTALS)
+      rv = smaltgpu_hit_totals(g_map[slot].mp, (const uint8_t *)g_map[slot].bases, has_qual ? (const uint8_t *)g_map[slot].quals : NULL, g_map[slot].off, (uint32_t)ns, par, tot_out);
+    else {
+      smaltgpu_callctx ctx;
+      memset(&ctx, 0, sizeof(ctx));
+      ctx.iv_off = iv_off; ctx.iv = iv; ctx.min_swatscor = minsw; ctx.prev_max = prevmax; ctx.fine_index = kind == GPUCOMB_FINE;
+      rv = smaltgpu_map_batch_ctx(g_map[slot].mp, (const uint8_t *)g_map[slot].bases, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
+                                  g_map[slot].off, (uint32_t)ns, par, &ctx, out);
+      if ((rv == SMALTGPU_ECAP || rv == SMALTGPU_EINTERNAL) && out->nreads == (uint32_t)ns) rv = 0;      /* gpuPairTake reports the read */
+    }
+    if (rv) { fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error()); ERRMSGNO(errmsgp, ERRCODE_FAILURE); }
   }
   return ERRCODE_SUCCESS;
 }
@@ -348,10 +377,10 @@ int rmapGpuPairBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, SeqFast
   smaltgpu_interval *iv = NULL;
   size_t niv = 0, cap_iv = 0;
   int32_t *minsw = NULL, *prevmax = NULL;
-  SeqFastq **all = NULL;
+  SeqFastq **all = NULL, **rsq = NULL;
 
   pthread_once(&g_once, gpuReadConfig);
-  if ((slot = gpuMapperForBatch(rmp, 64, 1, 64, 1)) < 0) { fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error()); ERRMSGNO(errmsgp, ERRCODE_FAILURE); }
+  if ((slot = gpuMapperForBatch(rmp, 64, 1, 64, !g_combine)) < 0) { fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error()); ERRMSGNO(errmsgp, ERRCODE_FAILURE); }
   if (g_map[slot].cap_pairs < n) {
     GpuPair *np = realloc(g_map[slot].pairs, (size_t)n * sizeof(GpuPair));
     if (!np) ERRMSGNO(errmsgp, ERRCODE_NOMEM);
@@ -362,8 +391,8 @@ int rmapGpuPairBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, SeqFast
   g_map[slot].npairs = 0;
   sel = malloc((size_t)2 * n * sizeof(int)); which = malloc((size_t)2 * n); tot = malloc((size_t)2 * n * sizeof(uint32_t));
   iv_off = malloc(((size_t)n + 1) * sizeof(uint64_t)); minsw = malloc((size_t)n * sizeof(int32_t)); prevmax = malloc((size_t)2 * n * sizeof(int32_t));
-  all = malloc((size_t)2 * n * sizeof(SeqFastq *));
-  if (!sel || !which || !tot || !iv_off || !minsw || !prevmax || !all) ERRMSGNO(errmsgp, ERRCODE_NOMEM);
+  all = malloc((size_t)2 * n * sizeof(SeqFastq *)); rsq = malloc((size_t)n * sizeof(SeqFastq *));
+  if (!sel || !which || !tot || !iv_off || !minsw || !prevmax || !all || !rsq) ERRMSGNO(errmsgp, ERRCODE_NOMEM);
 
   /* penalties as the reference derives them for a read (rmap.c:1259) */
   if ((errcode = makeRMAPPROFfromRead(rmp->prp, reads[0], scormtxp, codecp))) ERRMSGNO(errmsgp, errcode);
@@ -389,29 +418,8 @@ int rmapGpuPairBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, SeqFast
     pp->mapq1 = pp->swscor1 = pp->swscor2_restricted = pp->n_proper = pp->minsw_d = pp->fpp_err = 0;
     all[2 * i] = reads[i]; all[2 * i + 1] = mates[i];
   }
-  {
-    /* hit totals need the reads on the device: one seeding-only batch over both mates of every pair */
-    size_t nb = 0;
-    uint32_t maxlen = 1, qlen, j;
-    char cod, qcod;
-    int has_qual = 1;
-    for (i = 0; i < 2 * n; i++) { (void)seqFastqGetConstSequence(all[i], &rlen, &cod); nb += rlen; if (rlen > maxlen) maxlen = rlen; }
-    if (gpuMapperForBatch(rmp, maxlen, (uint32_t)(2 * n), nb, 1) != slot) ERRMSGNO(errmsgp, ERRCODE_FAILURE);
-    for (i = 0, nb = 0; i < 2 * n; i++) {
-      const char *seqp = seqFastqGetConstSequence(all[i], &rlen, &cod);
-      const char *qualp = seqFastqGetConstQualityFactors(all[i], &qlen, &qcod);
-      g_map[slot].off[i] = nb;
-      for (j = 0; j < rlen; j++) g_map[slot].bases[nb + j] = (cod == SEQCOD_ASCII) ? seqp[j] : GPU_ALPHA[seqp[j] & SEQCOD_ALPHA_MASK];
-      if (qualp && qlen == rlen) memcpy(g_map[slot].quals + nb, qualp, rlen); else has_qual = 0;
-      nb += rlen;
-    }
-    g_map[slot].off[2 * n] = nb;
-    if (smaltgpu_hit_totals(g_map[slot].mp, (const uint8_t *)g_map[slot].bases, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
-                            g_map[slot].off, (uint32_t)(2 * n), &par, tot)) {
-      fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error());
-      ERRMSGNO(errmsgp, ERRCODE_FAILURE);
-    }
-  }
+  /* hit totals: one seeding-only batch over both mates of every pair */
+  if ((errcode = gpuPairRound(errmsgp, slot, all, 2 * n, &par, GPUCOMB_TOTALS, NULL, NULL, NULL, NULL, tot, NULL))) return errcode;
   for (i = 0; i < n; i++) {
     GpuPair *pp = pairs + i;
     uint32_t l0, l1;
@@ -428,7 +436,8 @@ int rmapGpuPairBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, SeqFast
   /* ---- round A: the first mate, unrestricted (rmap.c:1907-1918) ---- */
   for (i = 0, ns = 0; i < n; i++) if (!pairs[i].skip && !pairs[i].lone) { sel[ns] = i; which[ns] = pairs[i].first; ns++; }
   if (ns) {
-    if ((errcode = gpuPairRound(errmsgp, slot, pairs, sel, which, ns, &par, NULL, NULL, NULL, NULL, 0, &o))) return errcode;
+    for (i = 0; i < ns; i++) rsq[i] = pairs[sel[i]].sq[which[i]];
+    if ((errcode = gpuPairRound(errmsgp, slot, rsq, ns, &par, GPUCOMB_PLAIN, NULL, NULL, NULL, NULL, NULL, &o))) return errcode;
     for (i = 0; i < ns; i++) if ((errcode = gpuPairTake(errmsgp, rmp, pairs + sel[i], which[i], &o, i, max_depth, scormtxp, ssp, codecp))) return errcode;
   }
   /* ---- intervals from the first mate's results (rmap.c:1920-1938), round B: the second mate restricted (:1940-1954) ---- */
@@ -452,7 +461,8 @@ int rmapGpuPairBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, SeqFast
   iv_off[ns] = niv;
   if (ns) {
     if (!iv && !(iv = malloc(sizeof(*iv)))) ERRMSGNO(errmsgp, ERRCODE_NOMEM);
-    if ((errcode = gpuPairRound(errmsgp, slot, pairs, sel, which, ns, &par, iv_off, iv, NULL, NULL, 0, &o))) return errcode;
+    for (i = 0; i < ns; i++) rsq[i] = pairs[sel[i]].sq[which[i]];
+    if ((errcode = gpuPairRound(errmsgp, slot, rsq, ns, &par, GPUCOMB_RESTRICTED, iv_off, iv, NULL, NULL, NULL, &o))) return errcode;
     for (i = 0; i < ns; i++) if ((errcode = gpuPairTake(errmsgp, rmp, pairs + sel[i], which[i], &o, i, max_depth, scormtxp, ssp, codecp))) return errcode;
   }
   /* ---- proper pairs so far; who needs the unrestricted round (rmap.c:1956-1969) ---- */
@@ -482,7 +492,8 @@ int rmapGpuPairBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, SeqFast
     ns++;
   }
   if (ns) {
-    if ((errcode = gpuPairRound(errmsgp, slot, pairs, sel, which, ns, &par, NULL, NULL, NULL, prevmax, 0, &o))) return errcode;
+    for (i = 0; i < ns; i++) rsq[i] = pairs[sel[i]].sq[which[i]];
+    if ((errcode = gpuPairRound(errmsgp, slot, rsq, ns, &par, GPUCOMB_APPEND, NULL, NULL, NULL, prevmax, NULL, &o))) return errcode;
     for (i = 0; i < ns; i++) if ((errcode = gpuPairTake(errmsgp, rmp, pairs + sel[i], which[i], &o, i, max_depth, scormtxp, ssp, codecp))) return errcode;
   }
   /* ---- who needs the first mate again, restricted by the second one's results (rmap.c:1991-2008) ---- */
@@ -521,12 +532,13 @@ int rmapGpuPairBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, SeqFast
     /* ---- round D: over the on-the-fly index of the intervals (rmap.c:2010-2039; setupFineHashTable cannot run out of
      *      positions here: the windows of one pair hold far fewer than FINEHASH_MAXKTUPPOS words) ---- */
     if (nd) {
-      if ((errcode = gpuPairRound(errmsgp, slot, pairs, sel, which, nd, &par, iv_off, iv, minsw, prevmax, 1, &o))) return errcode;
+      for (i = 0; i < nd; i++) rsq[i] = pairs[sel[i]].sq[which[i]];
+      if ((errcode = gpuPairRound(errmsgp, slot, rsq, nd, &par, GPUCOMB_FINE, iv_off, iv, minsw, prevmax, NULL, &o))) return errcode;
       for (i = 0; i < nd; i++) if ((errcode = gpuPairTake(errmsgp, rmp, pairs + sel[i], which[i], &o, i, max_depth, scormtxp, ssp, codecp))) return errcode;
     }
   }
   g_map[slot].npairs = n;
-  free(sel); free(which); free(tot); free(iv_off); free(iv); free(minsw); free(prevmax); free(all);
+  free(sel); free(which); free(tot); free(iv_off); free(iv); free(minsw); free(prevmax); free(all); free(rsq);
   return ERRCODE_SUCCESS;
 }
 

@@ -117,3 +117,47 @@ def make_reads_gpu(ref: torch.Tensor, sop: np.ndarray, n: int, length: int, seed
     ascii_reads = table[rd.to(torch.int64)].contiguous().view(-1)
     truth = torch.stack([seq, pos, strand.to(torch.int64)], dim=1)
     return ascii_reads, truth
+
+
+def _noisy_reads(ref, start, rc, length, g, sub_rate, indel_read_frac):
+    """reads of `length` bases read off the concatenated reference at global offsets `start` (forward orientation), then
+    reverse-complemented where rc: substitutions, and one 1-base indel in a fraction of the reads (as make_reads_gpu)"""
+    dev = ref.device
+    n = start.numel()
+    ar = torch.arange(length, device=dev)[None, :]
+    has_indel = torch.rand(n, device=dev, generator=g) < indel_read_frac
+    is_del = torch.rand(n, device=dev, generator=g) < 0.5
+    p = torch.randint(10, length - 10, (n,), device=dev, generator=g)[:, None]
+    adj = torch.where(has_indel[:, None] & is_del[:, None] & (ar >= p), 1, 0) - \
+        torch.where(has_indel[:, None] & (~is_del[:, None]) & (ar > p), 1, 0)
+    rd = ref[(start[:, None] + ar + adj).reshape(-1)].view(n, length)
+    ins = has_indel[:, None] & (~is_del[:, None]) & (ar == p)
+    rd = torch.where(ins, torch.randint(0, 4, (n, length), dtype=torch.uint8, device=dev, generator=g), rd)
+    mut = torch.rand((n, length), device=dev, generator=g) < sub_rate
+    rd = torch.where(mut, (rd + torch.randint(1, 4, (n, length), dtype=torch.uint8, device=dev, generator=g)) & 3, rd)
+    rd = torch.where(rc[:, None], (3 - rd).flip(1), rd)
+    table = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    return table[rd.to(torch.int64)].contiguous().view(-1)
+
+
+def make_pairs_gpu(ref: torch.Tensor, sop: np.ndarray, n: int, length: int, seed: int, insert_mean: float = 300.0, insert_sd: float = 30.0,
+                   sub_rate: float = 0.01, indel_read_frac: float = 0.02):
+    """Paired-end reads, FR orientation (BASELINE configs[2]): fragments of length N(insert_mean,
+    insert_sd) at uniform loci, either strand.  -> (ASCII reads [n*length], ASCII mates [n*length], truth int64 [n,4] =
+    (seq, fragment start, strand, fragment length)); all on the device."""
+    dev = ref.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    nseq = len(sop) - 1
+    seq = torch.randint(0, nseq, (n,), device=dev, generator=g)
+    sop_t = torch.as_tensor(np.asarray(sop, dtype=np.int64), device=dev)
+    flen = torch.clamp((torch.randn(n, device=dev, generator=g) * insert_sd + insert_mean).round().to(torch.int64), min=length)
+    slen = sop_t[seq + 1] - sop_t[seq]
+    pos = (torch.rand(n, device=dev, generator=g, dtype=torch.float64) * (slen - flen - 4).to(torch.float64)).to(torch.int64)
+    strand = torch.rand(n, device=dev, generator=g) < 0.5
+    left = sop_t[seq] + pos                                   # first `length` bases of the fragment's forward strand
+    right = sop_t[seq] + pos + flen - length                  # its last `length` bases
+    # forward fragment: read = left, mate = revcomp(right); reverse fragment: read = revcomp(right), mate = left
+    r1 = _noisy_reads(ref, torch.where(strand, right, left), strand, length, g, sub_rate, indel_read_frac)
+    r2 = _noisy_reads(ref, torch.where(strand, left, right), ~strand, length, g, sub_rate, indel_read_frac)
+    return r1, r2, torch.stack([seq, pos, strand.to(torch.int64), flen], dim=1)

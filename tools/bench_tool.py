@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--nchr", type=int, default=24)
     ap.add_argument("--chr-mbp", type=float, default=125.0)
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--paired", action="store_true", help="BASELINE configs[2]: read PAIRS (FR, fragments N(300,30), -i 500); --reads counts pairs, rates are pairs/s")
     a = ap.parse_args()
     import torch
     from smalt_amd import gpuindex, indexfile
@@ -39,7 +40,11 @@ def main():
     ref = gpuindex.make_reference_gpu(a.nchr, chrlen, 20261004, dev)
     packed = gpuindex.pack_reference(ref)
     idx, pos = gpuindex.build_perfect_index(ref, sop, k, s)
-    reads, _ = gpuindex.make_reads_gpu(ref, sop, a.reads, rlen, 777)
+    if a.paired:
+        reads, mates, _ = gpuindex.make_pairs_gpu(ref, sop, a.reads, rlen, 777)
+        md = mates.cpu().numpy().reshape(a.reads, rlen)
+    else:
+        reads, _ = gpuindex.make_reads_gpu(ref, sop, a.reads, rlen, 777)
     rd = reads.cpu().numpy().reshape(a.reads, rlen)
     smalt, smalt_gpu = os.path.join(ROOT, "oracle", "_ref", "smalt"), os.path.join(ROOT, "oracle", "_ref", "smalt_gpu")
     gthreads = a.gpu_threads or a.threads
@@ -56,10 +61,16 @@ def main():
             with open(path, "wb") as f:
                 for i in range(n):
                     f.write(b"@r%d\n" % i + rd[i].tobytes() + b"\n+\n" + q + b"\n")
+            if a.paired:
+                with open(path + ".mates", "wb") as f:
+                    for i in range(n):
+                        f.write(b"@r%d\n" % i + md[i].tobytes() + b"\n+\n" + q + b"\n")
 
         def run(binary, nthr, fq, out, env=None):
             t = time.time()
-            r = subprocess.run([binary, "map", "-n", str(nthr), "-O", "-r", "-1", "-f", "cigar", "-o", out, prefix, fq], capture_output=True, env=env)
+            inputs = [fq, fq + ".mates"] if a.paired else [fq]
+            r = subprocess.run([binary, "map", "-n", str(nthr), "-O", "-r", "-1", "-f", "cigar"] + (["-i", "500"] if a.paired else []) + ["-o", out, prefix] + inputs,
+                               capture_output=True, env=env)
             if r.returncode:
                 raise SystemExit("%s failed: %s" % (binary, r.stderr.decode()[-1500:]))
             return time.time() - t
@@ -80,7 +91,7 @@ def main():
         identical = c[:ncmp] == g[:ncmp]
         cpu_rate = (a.cpu_reads - nsmall) / max(t_c1 - t_c0, 1e-6)
         gpu_rate = (a.reads - nsmall) / max(t_g1 - t_g0, 1e-6)
-        print(json.dumps({"what": "whole program `smalt map`, reads/s with the index load removed", "threads_cpu": a.threads, "threads_gpu_bound": gthreads,
+        print(json.dumps({"what": "whole program `smalt map`, %s/s with the index load removed" % ("read pairs" if a.paired else "reads"), "paired": a.paired, "threads_cpu": a.threads, "threads_gpu_bound": gthreads,
                           "cpu_reads_per_s": cpu_rate, "gpu_bound_reads_per_s": gpu_rate, "speedup": gpu_rate / cpu_rate,
                           "outputs_identical_on_common_reads": identical, "lines_compared": ncmp,
                           "wall_s": {"cpu_small": t_c0, "cpu": t_c1, "gpu_small": t_g0, "gpu": t_g1}, "reads": {"cpu": a.cpu_reads, "gpu": a.reads}}))
