@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--sub-batch", type=int, default=262144)
     ap.add_argument("--streams", type=int, default=1, help="mappers (HIP streams) that take the sub-batches in turn: kernels of consecutive sub-batches overlap")
+    ap.add_argument("--paired", action="store_true", help="BASELINE configs[2]: 1 M read PAIRS (2 x read-len, FR, fragments N(300,30), -i 500) through the reference "
+                    "program bound to the library (oracle/_ref/smalt_gpu): rmapPair's rounds run on the GPU, pairing and mapping qualities are the reference's host code; pairs/s")
     ap.add_argument("--static-shards", action="store_true", help="N > 1: contiguous shard per rank instead of the shared sub-batch cursor")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-buffers", action="store_true", help="skip the extra PCIe-inclusive measurement of smaltgpu_map_batch on pageable host buffers")
@@ -170,8 +172,36 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
+def paired_line(args):
+    """configs[2].  rmapPair (rmap.c:1744) decides between its mapping rounds on mapping qualities and proper pairs, which are
+    the reference's results.c / resultpairs.c (host side): the measurable unit is therefore the reference
+    program with its worker bound to the library (tools/bench_tool.py --paired), index and reads on disk, start-up removed by
+    the difference of two runs.  Its output is compared with the unmodified program's on the CPU sample."""
+    n = args.reads or 1_000_000
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_tool.py"), "--paired", "--reads", str(n), "--cpu-reads", str(min(n, max(4000, args.cpu_sample // 6))),
+           "--read-len", str(args.read_len), "--nchr", str(args.nchr), "--chr-mbp", str(args.chr_mbp), "--threads", str(len(os.sched_getaffinity(0))),
+           "--gpu-threads", str(len(os.sched_getaffinity(0)))]
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode:
+        raise SystemExit("bench_tool failed: " + r.stderr[-1500:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    return {"metric": "mapped read pairs/sec (1M pairs 2x%dbp vs 3Gbp ref)" % args.read_len, "value": d["gpu_bound_reads_per_s"], "unit": "read pairs/s", "n_gpus": 1,
+            "steps": 1, "warmup": 0, "ms_per_step": (d["wall_s"]["gpu"] - d["wall_s"]["gpu_small"]) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "configs[2]: %d read pairs 2 x %d bp (FR, fragments N(300,30), -i 500) vs %d x %.0f Mbp synthetic reference, k=13 s=6; whole bound program "
+                                   "`smalt_gpu map -n %d` from FASTQ files to CIGAR output, index load removed" % (n, args.read_len, args.nchr, args.chr_mbp, d["threads_gpu_bound"]),
+                       "outputs_identical_on_common_pairs": d["outputs_identical_on_common_reads"], "lines_compared": d["lines_compared"], "wall_s": d["wall_s"], "bench_wall_s": time.time() - t0},
+            "roofline": None,
+            "cpu_baseline": {"value": d["cpu_reads_per_s"], "unit": "read pairs/s", "cores": d["threads_cpu"], "kind": "reference", "cpu_model": cpu_model(),
+                             "sample": "smalt map -n %d -i 500 on the first %d pairs, same index files (start-up removed by a second, small run)" % (d["threads_cpu"], d["reads"]["cpu"])}}
+
+
 def main():
     args = parse_args()
+    if args.paired:
+        print(json.dumps(paired_line(args)), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))            # before torch / HIP are touched in this process
     import ctypes as C
