@@ -192,6 +192,46 @@ int smaltgpu_fetch_begin(smaltgpu_mapper *m);
 int smaltgpu_fetch_end(smaltgpu_mapper *m, smaltgpu_batch_out *out);
 int smaltgpu_synchronize(smaltgpu_mapper *m);
 
+/* ---- result post-processing: what resultSetSortAndAssignSequence (results.c:2022) does to the raw
+ * alignments of every read of a batch -- assignSequenceIndex (:1695: concatenated mode, sequence and offsets),
+ * sortAndPrune (:759: contained alignments out, output order, score ranks), labelComplementarySegments (:707) and
+ * calcPhredScaledMappingQuality (:1143, with propagateMapQualAsProb :1343).  Host code on worker threads: the mapping
+ * quality is double arithmetic through libm and the orders are libc qsort's on the reference's comparators, so
+ * bit-identical results need the same libm / libc the reference runs on.  `raw` is a batch as smaltgpu_map_batch returns it
+ * (alignments of ONE mapSingleRead call per read), `quals` / `read_off` the reads' phred+33 qualities (NULL: FASTA input),
+ * `sop` the nseq + 1 cumulative sequence offsets (smaltgpu_index_info).  A read one of whose alignments spans several
+ * reference sequences (splitMultiSpan, results.c:1472) is flagged needs_reference and not processed. ---- */
+typedef struct smaltgpu_post_result {  /* struct _RESULT (results.c:121-160) after the post-processing */
+  int32_t swatscor;
+  uint32_t q_start, q_end;
+  uint64_t s_start, s_end;             /* relative to sequence sidx once it is assigned */
+  int32_t sidx;
+  uint32_t status;                     /* RSLTFLAG_* (results.h:67-78): SELECT 0x01, REVERSE 0x04, NOSEQID 0x08, SINGLE 0x100 */
+  int32_t mapscor;                     /* PHRED-scaled mapping quality */
+  double prob;
+  int16_t rsltx, qsegx, swrank, pad;
+  uint32_t stroffs, strlen;
+} smaltgpu_post_result;
+typedef struct smaltgpu_post_out {
+  uint32_t nreads;
+  const uint64_t *res_off;             /* nreads + 1 offsets into res: the result array of read i in its original order */
+  const smaltgpu_post_result *res;
+  const uint8_t *diffstr;              /* = raw->diffstr */
+  const uint64_t *sort_off;            /* nreads + 1 offsets into sortr / segsrtr */
+  const int32_t *sortr;                /* ResultSet.sortr: indices into the read's results, by decreasing score (results.c:478) */
+  const int32_t *segsrtr;              /* ResultSet.segsrtr: by read segment, then score */
+  const uint64_t *seg_off;             /* nreads + 1 offsets into segnor */
+  const int32_t *segnor;               /* ResultSet.segnor: qsegno + 1 bounds of the segments in segsrtr */
+  const int32_t *qsegno;               /* per read */
+  const uint32_t *setstatus;           /* per read: RSLTSETFLG_* (results.c:93-100) */
+  const int32_t *needs_reference;      /* per read: 1 = left to the caller (alignment across a sequence junction) */
+} smaltgpu_post_out;
+typedef struct smaltgpu_post smaltgpu_post;     /* owns the arrays of a smaltgpu_post_out */
+smaltgpu_post *smaltgpu_post_create(void);
+void smaltgpu_post_free(smaltgpu_post *p);
+int smaltgpu_postprocess(smaltgpu_post *p, const uint64_t *sop, int64_t nseq, const smaltgpu_batch_out *raw, const uint8_t *quals,
+                         const uint64_t *read_off, int nthreads, smaltgpu_post_out *out);
+
 /* Per-kernel device time (ms, HIP events on the mapper's stream) and work counters of the last
  * batch: names in smaltgpu_timer_name().  For bench.py's roofline object. */
 int smaltgpu_timers(const smaltgpu_mapper *m, double *ms, uint64_t *work, int n);

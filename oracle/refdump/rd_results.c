@@ -48,3 +48,33 @@ void rdDumpResultsFrom(FILE *fp, const ResultSet *rsp, unsigned first, int swmax
   fprintf(fp, "RX %u %d %d %d %d %u %u\n", (unsigned) ((n > first)? n - first: 0), swmax, sw2nd,
 	  rsp->n_ali_done, rsp->n_ali_tot, rsp->n_hits_used, rsp->n_hits_tot);
 }
+
+/* -p: the state resultSetSortAndAssignSequence (results.c:2022: assignSequenceIndex :1695, sortAndPrune :759,
+ * labelComplementarySegments :707, calcPhredScaledMappingQualityPerQuerySegment) leaves behind.
+ * The output filters (resultSetFilterResults) and the report set further status bits afterwards; they are masked out. */
+void rdDumpPost(FILE *fp, const ResultSet *rsp)
+{
+  size_t i, n = ARRLEN(rsp->resr), ns = ARRLEN(rsp->sortr);
+  const unsigned mask = ~(unsigned) (RSLTFLAG_NOOUTPUT | RSLTFLAG_BELOWRELSW | RSLTFLAG_REPORTED);
+  fprintf(fp, "PS %u %u %d %u\n", (unsigned) n, (unsigned) ns, (int) rsp->qsegno, (unsigned) (rsp->status));
+  for (i=0; i<n; i++) {
+    const Result *rp = rsp->resr + i;
+    int j;
+    fprintf(fp, "RF %u %u %d %d %.17g %u %u %llu %llu %lld %d %d %d ", (unsigned) i, (unsigned) (rp->status & mask), rp->swatscor, rp->mapscor, rp->prob,
+	    rp->q_start, rp->q_end, (unsigned long long) rp->s_start, (unsigned long long) rp->s_end, (long long) rp->sidx,
+	    (int) rp->rsltx, (int) rp->qsegx, (int) rp->swrank);
+    for (j=0; j<rp->strlen; j++) fprintf(fp, "%02x", (unsigned) rsp->diffstrp->dstrp[rp->stroffs + j]);
+    fputc('\n', fp);
+  }
+  fprintf(fp, "SO");
+  for (i=0; i<ns; i++) fprintf(fp, " %d", (int) (rsp->sortr[i] - rsp->resr));
+  fputc('\n', fp);
+  if (ns > 0 && (rsp->status & RSLTSETFLG_SEGIDX)) {
+    fprintf(fp, "SS");
+    for (i=0; i<ARRLEN(rsp->segsrtr); i++) fprintf(fp, " %d", (int) (rsp->segsrtr[i] - rsp->resr));
+    fputc('\n', fp);
+    fprintf(fp, "SG");
+    for (i=0; i<ARRLEN(rsp->segnor); i++) fprintf(fp, " %d", (int) rsp->segnor[i]);
+    fputc('\n', fp);
+  }
+}

@@ -37,6 +37,8 @@ static int rd_msr_hook(ErrMsg *errmsgp, RMAPBUFF *bufp, ResultSet *rssp, const R
 extern void rdDumpHitInfo(FILE *fp, char strand, const HashHitInfo *hip);
 extern void rdDumpCands(FILE *fp, const SegAliCands *sacp);
 extern void rdDumpResults(FILE *fp, const ResultSet *rsp);
+extern void rdDumpPost(FILE *fp, const ResultSet *rsp);
+static int g_with_post = 0;
 extern void rdDumpResultsFrom(FILE *fp, const ResultSet *rsp, unsigned first, int swmax, int sw2nd);
 extern void rdDumpLastResult(FILE *fp, const ResultSet *rsp);
 extern unsigned rdResultNum(const ResultSet *rsp);
@@ -94,6 +96,7 @@ static int rd_msr_hook(ErrMsg *errmsgp, RMAPBUFF *bufp, ResultSet *rssp, const R
   printf("READ %llu %s len=%u err=%d\n", g_pm.pairno, seqFastqGetSeqName(readp), readlen, rv);
   dumpStages(stdout, rmrp, bufp, readlen, hashTableGetKtupLen(htp, NULL));
   rdDumpResultsFrom(stdout, rssp, nbefore, mx, mx2);      /* RX: new results, the set's running maxima after the call */
+  if (g_with_post) rdDumpPost(stdout, rssp);
   return rv;
 }
 
@@ -148,8 +151,9 @@ int main(int argc, char *argv[])
   SeqIO *mfp = NULL;
   SeqFastq *matep = NULL;
 
-  while ((c = getopt(argc, argv, "m:d:c:q:H:S:xnP:i:j:l:")) != -1) {
+  while ((c = getopt(argc, argv, "m:d:c:q:H:S:xnpP:i:j:l:")) != -1) {
     switch (c) {
+    case 'p': g_with_post = 1; break;
     case 'P': matefil = optarg; break;
     case 'i': ins_max = atoi(optarg); break;
     case 'j': ins_min = atoi(optarg); break;
@@ -227,6 +231,7 @@ int main(int argc, char *argv[])
     printf("READ %llu %s len=%u err=%d\n", readno++, seqFastqGetSeqName(readp), readlen, errcode);
     dumpStages(stdout, rmp->mrp, rmp->bfp, readlen, ktup);
     rdDumpResults(stdout, rmp->rsrp);
+    if (g_with_post) rdDumpPost(stdout, rmp->rsrp);
     if (with_hitlists && readlen >= ktup)
       dumpHitLists(stdout, rmp, ncut, (BOOL) ((rmapflg & RMAPFLG_SEQBYSEQ) != 0), htp, ssp);
   }

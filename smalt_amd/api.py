@@ -59,6 +59,19 @@ class CallCtx(C.Structure):
                 ("prev_max", C.POINTER(C.c_int32)), ("fine_index", C.c_int32)]
 
 
+class PostResult(C.Structure):
+    _fields_ = [("swatscor", C.c_int32), ("q_start", C.c_uint32), ("q_end", C.c_uint32), ("s_start", C.c_uint64), ("s_end", C.c_uint64),
+                ("sidx", C.c_int32), ("status", C.c_uint32), ("mapscor", C.c_int32), ("prob", C.c_double), ("rsltx", C.c_int16),
+                ("qsegx", C.c_int16), ("swrank", C.c_int16), ("pad", C.c_int16), ("stroffs", C.c_uint32), ("strlen", C.c_uint32)]
+
+
+class PostOut(C.Structure):
+    _fields_ = [("nreads", C.c_uint32), ("res_off", C.POINTER(C.c_uint64)), ("res", C.POINTER(PostResult)), ("diffstr", C.POINTER(C.c_uint8)),
+                ("sort_off", C.POINTER(C.c_uint64)), ("sortr", C.POINTER(C.c_int32)), ("segsrtr", C.POINTER(C.c_int32)),
+                ("seg_off", C.POINTER(C.c_uint64)), ("segnor", C.POINTER(C.c_int32)), ("qsegno", C.POINTER(C.c_int32)),
+                ("setstatus", C.POINTER(C.c_uint32)), ("needs_reference", C.POINTER(C.c_int32))]
+
+
 class MapperOpts(C.Structure):
     _fields_ = [("cands_per_read", C.c_uint32), ("slot_budget_gb", C.c_uint32)]
 
@@ -103,6 +116,10 @@ def lib():
         L.smaltgpu_map_batch_ctx.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint32,
                                              C.POINTER(Params), C.POINTER(CallCtx), C.POINTER(BatchOut)]
         L.smaltgpu_hit_totals.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(Params), C.POINTER(C.c_uint32)]
+        L.smaltgpu_post_create.restype = C.c_void_p
+        L.smaltgpu_post_free.argtypes = [C.c_void_p]
+        L.smaltgpu_postprocess.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64, C.POINTER(BatchOut), C.c_void_p, C.POINTER(C.c_uint64), C.c_int,
+                                           C.POINTER(PostOut)]
         L.smaltgpu_map_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
                                                 C.POINTER(Params)]
         L.smaltgpu_fetch_results.argtypes = [C.c_void_p, C.POINTER(BatchOut)]

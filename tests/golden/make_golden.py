@@ -33,6 +33,10 @@ CONFIGS = [
     dict(tag="g_k13s6_x", nchr=2, chrlen=100000, k=13, s=6, nreads=120, rlen=150, rep=0.15, opts="-x"),
     dict(tag="g_k13s3_short", nchr=2, chrlen=150000, k=13, s=3, nreads=200, rlen=36, rep=0.0, opts="", varlen=True),
     dict(tag="g_k13s6_c05", nchr=2, chrlen=100000, k=13, s=6, nreads=150, rlen=150, rep=0.15, opts="-c 0.5", varlen=True),
+    # >= 512 reference sequences: concatenated mode (assignSequenceIndex places the alignments, results.c:1695)
+    # (post_only: in this mode the reference's RS lines show the alignments AFTER assignSequenceIndex, the stage dumps of the
+    #  path show them before -- the fixture serves tests/test_postprocess.py, which is about exactly that step)
+    dict(tag="g_k11s4_cat", nchr=600, chrlen=1500, k=11, s=4, nreads=200, rlen=100, rep=0.0, opts="-d -1", qualmix=True, post_only=True),
 ]
 
 
@@ -82,8 +86,13 @@ def make(cfg, tmp):
             g.write(open(src, "rb").read())
     with gzip.GzipFile(os.path.join(HERE, tag + ".refdump.txt.gz"), "wb", mtime=0) as g:
         g.write(dump)
+    # the same reads with the state after result post-processing (refdump -p: SURVEY 8f N1), reduced to the lines that matter
+    post = subprocess.run([os.path.join(REF, "refdump"), "-n", "-p"] + cfg["opts"].split() + [pre, fq], check=True, capture_output=True).stdout
+    keep = [ln for ln in post.split(b"\n") if ln[:2] in (b"RE", b"RC", b"RS", b"RX", b"PS", b"RF", b"SO", b"SS", b"SG")]
+    with gzip.GzipFile(os.path.join(HERE, tag + ".post.txt.gz"), "wb", mtime=0) as g:
+        g.write(b"\n".join(keep) + b"\n")
     return dict(tag=tag, k=cfg["k"], s=cfg["s"], opts=cfg["opts"], sma_md5=md5(pre + ".sma"), smi_md5=md5(pre + ".smi"),
-                dump_lines=dump.count(b"\n"))
+                dump_lines=dump.count(b"\n"), post_only=bool(cfg.get("post_only")))
 
 
 if __name__ == "__main__":

@@ -9,7 +9,8 @@ import oracle_lib as ol
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, "golden")
-MANIFEST = json.load(open(os.path.join(GOLD, "manifest.json")))
+MANIFEST_ALL = json.load(open(os.path.join(GOLD, "manifest.json")))
+MANIFEST = [e for e in MANIFEST_ALL if not e.get("post_only")]        # fixtures whose stage dumps the path reproduces line by line
 
 
 def read_fasta(path):
