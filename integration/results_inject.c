@@ -66,3 +66,37 @@ int resultSetAppendRaw(ResultSet *rsp, unsigned n, const smaltgpu_result *res, c
   rsp->swatscor_2ndmax = swatscor_2ndmax;
   return ERRCODE_SUCCESS;
 }
+
+/* The state resultSetSortAndAssignSequence (results.c:2022) leaves in a ResultSet, taken from the library's post-processing
+ * (smaltgpu_postprocess) instead of being computed here: `pr` are the set's n alignments in array order (the
+ * raw alignments were injected before with resultSetInjectRaw), sortr/segsrtr index into them. */
+int resultSetInjectPost(ResultSet *rsp, unsigned n, const smaltgpu_post_result *pr, unsigned nsort, const int32_t *sortr,
+                        const int32_t *segsrtr, unsigned nsegnor, const int32_t *segnor, int qsegno, unsigned setstatus)
+{
+  unsigned i;
+  if (n != (unsigned) ARRLEN(rsp->resr)) return ERRCODE_ASSERT;
+  for (i = 0; i < n; i++) {
+    Result *rp = rsp->resr + i;
+    rp->serialno = (short) i;
+    rp->status = (RSLTFLG_t) pr[i].status;
+    rp->mapscor = pr[i].mapscor;
+    rp->prob = pr[i].prob;
+    rp->s_start = (SETSIZ_t) pr[i].s_start; rp->s_end = (SETSIZ_t) pr[i].s_end;
+    rp->sidx = pr[i].sidx;
+    rp->rsltx = pr[i].rsltx; rp->qsegx = pr[i].qsegx; rp->swrank = pr[i].swrank;
+  }
+  if (nsort > ARRNALLOC(rsp->sortr)) { void *hp = ARREALLOC(rsp->sortr, nsort); if (!hp) return ERRCODE_NOMEM; rsp->sortr = hp; }
+  for (i = 0; i < nsort; i++) rsp->sortr[i] = rsp->resr + sortr[i];
+  ARRLEN(rsp->sortr) = nsort;
+  rsp->qsegno = (short) qsegno;
+  if (nsegnor > 0) {
+    if (nsort > ARRNALLOC(rsp->segsrtr)) { void *hp = ARREALLOC(rsp->segsrtr, nsort); if (!hp) return ERRCODE_NOMEM; rsp->segsrtr = hp; }
+    if (nsegnor > ARRNALLOC(rsp->segnor)) { void *hp = ARREALLOC(rsp->segnor, nsegnor); if (!hp) return ERRCODE_NOMEM; rsp->segnor = hp; }
+    for (i = 0; i < nsort; i++) rsp->segsrtr[i] = rsp->resr + segsrtr[i];
+    ARRLEN(rsp->segsrtr) = nsort;
+    for (i = 0; i < nsegnor; i++) rsp->segnor[i] = (short) segnor[i];
+    ARRLEN(rsp->segnor) = nsegnor;
+  }
+  rsp->status = (uint8_t) setstatus;
+  return ERRCODE_SUCCESS;
+}

@@ -27,6 +27,8 @@
 /* results_inject.c (our TU around the reference's results.c) */
 extern int resultSetInjectRaw(ResultSet *rsp, unsigned n, const smaltgpu_result *res, const unsigned char *dstr,
                               int swatscor_max, int swatscor_2ndmax);
+extern int resultSetInjectPost(ResultSet *rsp, unsigned n, const smaltgpu_post_result *pr, unsigned nsort, const int32_t *sortr,
+                               const int32_t *segsrtr, unsigned nsegnor, const int32_t *segnor, int qsegno, unsigned setstatus);
 extern int resultSetAppendRaw(ResultSet *rsp, unsigned n, const smaltgpu_result *res, const unsigned char *dstr,
                               int swatscor_max, int swatscor_2ndmax);
 
@@ -35,6 +37,7 @@ static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 enum { GPU_MAXDEV = 16 };
 static smaltgpu_index *g_ixdev[GPU_MAXDEV];      /* one index image per device, shared by the mappers on it */
 static int g_ndev = 0, g_nphys = 0;              /* index images (logical devices) and GPUs present */
+static int g_libpost = 1;                        /* SMALTGPU_REF_POST unset: result post-processing by the library */
 static int g_combine = 1;                        /* SMALTGPU_NO_COMBINE unset */
 static const char *g_prefix = NULL;              /* SMALTGPU_INDEX_PREFIX */
 #define g_ix (g_ixdev[0])
@@ -43,6 +46,8 @@ static struct {
   char *bases, *quals; uint64_t *off; size_t basecap;
   smaltgpu_batch_out out; int nbatch;          /* results of the last rmapGpuBatch */
   GpuCombOut comb; int use_comb;               /* ... when they came from a combined batch (gpu_combine.c) */
+  smaltgpu_post *post; smaltgpu_post_out pout; int have_post;   /* result post-processing of the last batch by the library (N1) */
+  uint64_t *sop; int64_t nseq;
   struct GpuPair_ *pairs; int npairs, cap_pairs; /* paired blocks (rmapGpuPairBatch): per-pair state incl. its own two ResultSets */
   ResultSet *save_rsr, *save_rsm;
 } g_map[GPU_MAXMAPPERS];
@@ -54,6 +59,7 @@ static void gpuReadConfig(void)
 {
   const char *e = getenv("SMALTGPU_NDEV");       /* worker threads are dealt round-robin to the devices (SMALTGPU_NDEV limits them) */
   g_combine = !getenv("SMALTGPU_NO_COMBINE");
+  g_libpost = !getenv("SMALTGPU_REF_POST");
   g_prefix = getenv("SMALTGPU_INDEX_PREFIX");
   g_nphys = g_ndev = smaltgpu_device_count();
   if (e && atoi(e) > 0) g_ndev = atoi(e);        /* more than there are GPUs: images share devices (rehearsal of the N-device path on one GPU) */
@@ -227,6 +233,22 @@ int rmapGpuBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, int n, int 
     }
   }
   g_map[slot].nbatch = n;
+  /* result post-processing of the whole block by the library (smaltgpu_postprocess: what resultSetSortAndAssignSequence
+   * would compute read by read, results.c:2022); SMALTGPU_REF_POST keeps the reference's own routine instead */
+  g_map[slot].have_post = 0;
+  if (g_libpost) {
+    if (!g_map[slot].post) {
+      smaltgpu_index_desc ds;
+      int64_t s_;
+      if (smaltgpu_index_info(g_ix, &ds)) ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+      if (!(g_map[slot].post = smaltgpu_post_create()) || !(g_map[slot].sop = malloc(((size_t) ds.nseq + 1) * sizeof(uint64_t)))) ERRMSGNO(errmsgp, ERRCODE_NOMEM);
+      for (s_ = 0; s_ <= ds.nseq; s_++) g_map[slot].sop[s_] = ds.sop[s_];       /* = seqSetGetOffsets of the program's SeqSet: same .sma file */
+      g_map[slot].nseq = ds.nseq;
+    }
+    if (smaltgpu_postprocess(g_map[slot].post, g_map[slot].sop, g_map[slot].nseq, &g_map[slot].out, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
+                             g_map[slot].off, 1, &g_map[slot].pout) == SMALTGPU_OK)
+      g_map[slot].have_post = 1;
+  }
   return ERRCODE_SUCCESS;
 }
 
@@ -248,8 +270,16 @@ int rmapGpuFinish(ErrMsg *errmsgp, RMap *rmp, int i, SeqFastq *readp, short max_
                                     o->stat[i].swatscor_max, o->stat[i].swatscor_2ndmax)))
     ERRMSGNO(errmsgp, errcode);
   resultSetAlignmentStats(rmp->rsrp, o->stat[i].n_ali_done, o->stat[i].n_ali_tot, max_depth, o->stat[i].n_hits_used, o->stat[i].n_hits_tot);
-  if ((errcode = resultSetSortAndAssignSequence(rmp->rsrp, rmp->bfp->sqbfp, 0, readp, rmp->prp->scorprofp, rmp->prp->scorprofRCp, ssp, codecp)))
-    ERRMSGNO(errmsgp, errcode);
+  if (o->stat[i].max1scor >= 1) {                       /* mapSingleRead sorts only when the score pass found something (rmap.c:1376) */
+    const smaltgpu_post_out *po = &g_map[slot].pout;
+    if (g_map[slot].have_post && !po->needs_reference[i]) {      /* N1 from the library */
+      if ((errcode = resultSetInjectPost(rmp->rsrp, (unsigned)(po->res_off[i + 1] - po->res_off[i]), po->res + po->res_off[i],
+                                         (unsigned)(po->sort_off[i + 1] - po->sort_off[i]), po->sortr + po->sort_off[i], po->segsrtr + po->sort_off[i],
+                                         (unsigned)(po->seg_off[i + 1] - po->seg_off[i]), po->segnor + po->seg_off[i], po->qsegno[i], po->setstatus[i])))
+        ERRMSGNO(errmsgp, errcode);
+    } else if ((errcode = resultSetSortAndAssignSequence(rmp->rsrp, rmp->bfp->sqbfp, 0, readp, rmp->prp->scorprofp, rmp->prp->scorprofRCp, ssp, codecp)))
+      ERRMSGNO(errmsgp, errcode);                        /* an alignment across a sequence junction (splitMultiSpan), or SMALTGPU_REF_POST */
+  }
   if ((errcode = resultSetFilterResults(rmp->rsrp, rsfp, readp))) ERRMSGNO(errmsgp, errcode);
   return ERRCODE_SUCCESS;
 }
