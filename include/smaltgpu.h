@@ -199,8 +199,11 @@ int smaltgpu_synchronize(smaltgpu_mapper *m);
  * quality is double arithmetic through libm and the orders are libc qsort's on the reference's comparators, so
  * bit-identical results need the same libm / libc the reference runs on.  `raw` is a batch as smaltgpu_map_batch returns it
  * (alignments of ONE mapSingleRead call per read), `quals` / `read_off` the reads' phred+33 qualities (NULL: FASTA input),
- * `sop` the nseq + 1 cumulative sequence offsets (smaltgpu_index_info).  A read one of whose alignments spans several
- * reference sequences (splitMultiSpan, results.c:1472) is flagged needs_reference and not processed. ---- */
+ * `sop` the nseq + 1 cumulative sequence offsets (smaltgpu_index_info).  Concatenated mode: an alignment that spans several
+ * reference sequences is cut at the junctions and its fragments re-scored (splitMultiSpan, results.c:1472: the fragments are
+ * appended to the read's results, out->diffstr then holds their strings too) when `bases` (the reads, ASCII, by read_off),
+ * `packed_host` (a host copy of the packed reference, sequence.c:1360) and `par` (penalties) are given; with any of them
+ * NULL such a read is flagged needs_reference and left alone. ---- */
 typedef struct smaltgpu_post_result {  /* struct _RESULT (results.c:121-160) after the post-processing */
   int32_t swatscor;
   uint32_t q_start, q_end;
@@ -216,7 +219,7 @@ typedef struct smaltgpu_post_out {
   uint32_t nreads;
   const uint64_t *res_off;             /* nreads + 1 offsets into res: the result array of read i in its original order */
   const smaltgpu_post_result *res;
-  const uint8_t *diffstr;              /* = raw->diffstr */
+  const uint8_t *diffstr;              /* raw->diffstr, or a copy of it with the strings of split fragments behind */
   const uint64_t *sort_off;            /* nreads + 1 offsets into sortr / segsrtr */
   const int32_t *sortr;                /* ResultSet.sortr: indices into the read's results, by decreasing score (results.c:478) */
   const int32_t *segsrtr;              /* ResultSet.segsrtr: by read segment, then score */
@@ -229,8 +232,9 @@ typedef struct smaltgpu_post_out {
 typedef struct smaltgpu_post smaltgpu_post;     /* owns the arrays of a smaltgpu_post_out */
 smaltgpu_post *smaltgpu_post_create(void);
 void smaltgpu_post_free(smaltgpu_post *p);
-int smaltgpu_postprocess(smaltgpu_post *p, const uint64_t *sop, int64_t nseq, const smaltgpu_batch_out *raw, const uint8_t *quals,
-                         const uint64_t *read_off, int nthreads, smaltgpu_post_out *out);
+int smaltgpu_postprocess(smaltgpu_post *p, const uint64_t *sop, int64_t nseq, const smaltgpu_batch_out *raw, const uint8_t *bases,
+                         const uint8_t *quals, const uint64_t *read_off, const uint32_t *packed_host, const smaltgpu_params *par, int nthreads,
+                         smaltgpu_post_out *out);
 
 /* Per-kernel device time (ms, HIP events on the mapper's stream) and work counters of the last
  * batch: names in smaltgpu_timer_name().  For bench.py's roofline object. */

@@ -245,8 +245,10 @@ int rmapGpuBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, int n, int 
       for (s_ = 0; s_ <= ds.nseq; s_++) g_map[slot].sop[s_] = ds.sop[s_];       /* = seqSetGetOffsets of the program's SeqSet: same .sma file */
       g_map[slot].nseq = ds.nseq;
     }
-    if (smaltgpu_postprocess(g_map[slot].post, g_map[slot].sop, g_map[slot].nseq, &g_map[slot].out, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
-                             g_map[slot].off, 1, &g_map[slot].pout) == SMALTGPU_OK)
+    /* (no host copy of the packed reference here: alignments across sequence junctions come back flagged and take the
+     *  reference's own routine in rmapGpuFinish) */
+    if (smaltgpu_postprocess(g_map[slot].post, g_map[slot].sop, g_map[slot].nseq, &g_map[slot].out, NULL, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
+                             g_map[slot].off, NULL, NULL, 1, &g_map[slot].pout) == SMALTGPU_OK)
       g_map[slot].have_post = 1;
   }
   return ERRCODE_SUCCESS;

@@ -1,7 +1,29 @@
 /* oracle/refdump/rd_results.c -- TEST INFRASTRUCTURE (golden-vector generator).
  * #includes the reference's results.c text at build time to read the raw Result array. */
+#define resultSetSortAndAssignSequence resultSetSortAndAssignSequence_impl      /* intercepted below (-p) */
 #include "results.c"
+#undef resultSetSortAndAssignSequence
 #include <stdio.h>
+
+/* -p: the alignments as they are BEFORE the post-processing (in concatenated mode assignSequenceIndex rewrites coordinates
+ * and appends the fragments of alignments that span sequences), printed from a wrapper around the reference's routine */
+int rdPostDump = 0;
+int resultSetSortAndAssignSequence(ResultSet *rsp, SeqFastq *sbufp, BOOL search_split, const SeqFastq *sqp,
+				   const ScoreProfile *scpp, const ScoreProfile *scpRCp, const SeqSet *ssp, const SeqCodec *codecp)
+{
+  if (rdPostDump) {
+    size_t i, n = ARRLEN(rsp->resr);
+    int j;
+    for (i=0; i<n; i++) {
+      const Result *rp = rsp->resr + i;
+      printf("RW %u %c %d %u %u %llu %llu %lld ", (unsigned) i, (rp->status & RSLTFLAG_REVERSE)? 'R':'F', rp->swatscor, rp->q_start, rp->q_end,
+	     (unsigned long long) rp->s_start, (unsigned long long) rp->s_end, (long long) rp->sidx);
+      for (j=0; j<rp->strlen; j++) printf("%02x", (unsigned) rsp->diffstrp->dstrp[rp->stroffs + j]);
+      putchar('\n');
+    }
+  }
+  return resultSetSortAndAssignSequence_impl(rsp, sbufp, search_split, sqp, scpp, scpRCp, ssp, codecp);
+}
 
 void rdDumpResults(FILE *fp, const ResultSet *rsp)
 {

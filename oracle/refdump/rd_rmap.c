@@ -38,6 +38,7 @@ extern void rdDumpHitInfo(FILE *fp, char strand, const HashHitInfo *hip);
 extern void rdDumpCands(FILE *fp, const SegAliCands *sacp);
 extern void rdDumpResults(FILE *fp, const ResultSet *rsp);
 extern void rdDumpPost(FILE *fp, const ResultSet *rsp);
+extern int rdPostDump;
 static int g_with_post = 0;
 extern void rdDumpResultsFrom(FILE *fp, const ResultSet *rsp, unsigned first, int swmax, int sw2nd);
 extern void rdDumpLastResult(FILE *fp, const ResultSet *rsp);
@@ -153,7 +154,7 @@ int main(int argc, char *argv[])
 
   while ((c = getopt(argc, argv, "m:d:c:q:H:S:xnpP:i:j:l:")) != -1) {
     switch (c) {
-    case 'p': g_with_post = 1; break;
+    case 'p': g_with_post = 1; rdPostDump = 1; break;
     case 'P': matefil = optarg; break;
     case 'i': ins_max = atoi(optarg); break;
     case 'j': ins_min = atoi(optarg); break;

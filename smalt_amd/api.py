@@ -118,8 +118,8 @@ def lib():
         L.smaltgpu_hit_totals.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(Params), C.POINTER(C.c_uint32)]
         L.smaltgpu_post_create.restype = C.c_void_p
         L.smaltgpu_post_free.argtypes = [C.c_void_p]
-        L.smaltgpu_postprocess.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64, C.POINTER(BatchOut), C.c_void_p, C.POINTER(C.c_uint64), C.c_int,
-                                           C.POINTER(PostOut)]
+        L.smaltgpu_postprocess.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64, C.POINTER(BatchOut), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64),
+                                           C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(PostOut)]
         L.smaltgpu_map_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
                                                 C.POINTER(Params)]
         L.smaltgpu_fetch_results.argtypes = [C.c_void_p, C.POINTER(BatchOut)]

@@ -36,7 +36,7 @@ CONFIGS = [
     # >= 512 reference sequences: concatenated mode (assignSequenceIndex places the alignments, results.c:1695)
     # (post_only: in this mode the reference's RS lines show the alignments AFTER assignSequenceIndex, the stage dumps of the
     #  path show them before -- the fixture serves tests/test_postprocess.py, which is about exactly that step)
-    dict(tag="g_k11s4_cat", nchr=600, chrlen=1500, k=11, s=4, nreads=200, rlen=100, rep=0.0, opts="-d -1", qualmix=True, post_only=True),
+    dict(tag="g_k11s4_cat", nchr=600, chrlen=1500, k=11, s=4, nreads=200, rlen=100, rep=0.0, opts="-d -1", qualmix=True, post_only=True, junction=0.3),
 ]
 
 
@@ -61,6 +61,18 @@ def make(cfg, tmp):
                 lines[i] = ln[:p] + "N" * min(5, len(ln) - p) + ln[p + 5:]
         open(fa, "w").write("\n".join(lines))
     reads, _ = synth.make_reads(ch, cfg["nreads"], cfg["rlen"], seed=seed + 1, sub_rate=0.02, indel_read_frac=0.2)
+    if cfg.get("junction"):             # reads across the junction of two consecutive sequences (splitMultiSpan, results.c:1472)
+        for i in range(len(reads)):
+            if rng.random() < cfg["junction"]:
+                c = int(rng.integers(0, cfg["nchr"] - 1))
+                cut = int(rng.integers(15, cfg["rlen"] - 15))
+                r = np.concatenate([ch[c][len(ch[c]) - cut:], ch[c + 1][:cfg["rlen"] - cut]]).copy()
+                mut = rng.random(len(r)) < 0.02
+                r = np.where(mut, (r + rng.integers(1, 4, size=len(r))) & 3, r).astype(np.uint8)
+                if rng.random() < 0.15:      # an indel next to the junction
+                    p_ = min(len(r) - 2, max(1, cut + int(rng.integers(-6, 7))))
+                    r = np.concatenate([r[:p_], r[p_ + 1:], rng.integers(0, 4, size=1, dtype=np.uint8)])
+                reads[i] = synth.revcomp_codes(r) if rng.random() < 0.5 else r
     with open(fq, "wb") as f:
         for i, r in enumerate(reads):
             b = bytearray(synth.codes_to_ascii(r))
@@ -88,7 +100,7 @@ def make(cfg, tmp):
         g.write(dump)
     # the same reads with the state after result post-processing (refdump -p: SURVEY 8f N1), reduced to the lines that matter
     post = subprocess.run([os.path.join(REF, "refdump"), "-n", "-p"] + cfg["opts"].split() + [pre, fq], check=True, capture_output=True).stdout
-    keep = [ln for ln in post.split(b"\n") if ln[:2] in (b"RE", b"RC", b"RS", b"RX", b"PS", b"RF", b"SO", b"SS", b"SG")]
+    keep = [ln for ln in post.split(b"\n") if ln[:2] in (b"RE", b"RC", b"RW", b"RX", b"PS", b"RF", b"SO", b"SS", b"SG")]
     with gzip.GzipFile(os.path.join(HERE, tag + ".post.txt.gz"), "wb", mtime=0) as g:
         g.write(b"\n".join(keep) + b"\n")
     return dict(tag=tag, k=cfg["k"], s=cfg["s"], opts=cfg["opts"], sma_md5=md5(pre + ".sma"), smi_md5=md5(pre + ".smi"),
