@@ -113,6 +113,8 @@ int smaltgpu_index_create(smaltgpu_index **out, const smaltgpu_index_desc *desc,
 int smaltgpu_index_clone(smaltgpu_index **out, const smaltgpu_index *src, int device);
 void smaltgpu_index_free(smaltgpu_index *ix);
 int smaltgpu_index_info(const smaltgpu_index *ix, smaltgpu_index_desc *desc_out); /* device pointers */
+/* host copy of the packed reference (desc.packed), made on first request; for smaltgpu_postprocess.  NULL on failure */
+const uint32_t *smaltgpu_index_packed_host(const smaltgpu_index *ix);
 void smaltgpu_params_default(smaltgpu_params *p, const smaltgpu_index *ix);
 
 /* ---- index construction (replaces `smalt index`: selectHashTyp smalt.c:268-332, hashTableSetUp

@@ -245,10 +245,11 @@ int rmapGpuBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, int n, int 
       for (s_ = 0; s_ <= ds.nseq; s_++) g_map[slot].sop[s_] = ds.sop[s_];       /* = seqSetGetOffsets of the program's SeqSet: same .sma file */
       g_map[slot].nseq = ds.nseq;
     }
-    /* (no host copy of the packed reference here: alignments across sequence junctions come back flagged and take the
-     *  reference's own routine in rmapGpuFinish) */
-    if (smaltgpu_postprocess(g_map[slot].post, g_map[slot].sop, g_map[slot].nseq, &g_map[slot].out, NULL, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
-                             g_map[slot].off, NULL, NULL, 1, &g_map[slot].pout) == SMALTGPU_OK)
+    /* concatenated mode (rmapflg without SEQBYSEQ): alignments across sequence junctions are cut by the library too, which
+     * needs the packed reference on the host */
+    const uint32_t *packed = (rmapflg & RMAPFLG_SEQBYSEQ) ? NULL : smaltgpu_index_packed_host(g_ix);
+    if (smaltgpu_postprocess(g_map[slot].post, g_map[slot].sop, g_map[slot].nseq, &g_map[slot].out, (const uint8_t *)g_map[slot].bases,
+                             has_qual ? (const uint8_t *)g_map[slot].quals : NULL, g_map[slot].off, packed, &par, 1, &g_map[slot].pout) == SMALTGPU_OK)
       g_map[slot].have_post = 1;
   }
   return ERRCODE_SUCCESS;

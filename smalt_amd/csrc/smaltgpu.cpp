@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/smaltgpu.h"
@@ -48,6 +49,8 @@ struct smaltgpu_index {
   std::vector<std::string> names;  // set by smaltgpu_index_build (what smaltgpu_index_save writes)
   uint32_t maxpos = 0;
   bool built = false;
+  std::vector<uint32_t> packed_host;   // host copy of the packed reference, fetched on first request (smaltgpu_index_packed_host)
+  std::mutex packed_mu;
 };
 
 template <class T>
@@ -236,6 +239,21 @@ extern "C" void smaltgpu_index_free(smaltgpu_index *ix) {
   (void)hipSetDevice(ix->device);
   for (int i = 0; i < ix->nbufs; i++) (void)hipFree(ix->bufs[i]);
   delete ix;
+}
+
+// A host copy of the packed reference (what smaltgpu_postprocess needs to cut alignments at sequence junctions): fetched from
+// the device once, on first request.
+extern "C" const uint32_t *smaltgpu_index_packed_host(const smaltgpu_index *cix) {
+  smaltgpu_index *ix = const_cast<smaltgpu_index *>(cix);
+  if (!ix) return nullptr;
+  std::lock_guard<std::mutex> lk(ix->packed_mu);
+  if (ix->packed_host.empty()) {
+    const size_t nw = (size_t)(ix->d.totlen / 10 + 1);
+    std::vector<uint32_t> h(nw);
+    if (hipSetDevice(ix->device) != hipSuccess || hipMemcpy(h.data(), ix->d.packed, nw * 4, hipMemcpyDeviceToHost) != hipSuccess) { fail(SMALTGPU_ENODEV, "copy of the packed reference to the host failed"); return nullptr; }
+    ix->packed_host.swap(h);
+  }
+  return ix->packed_host.data();
 }
 
 extern "C" int smaltgpu_index_info(const smaltgpu_index *ix, smaltgpu_index_desc *o) {
