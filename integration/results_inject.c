@@ -70,11 +70,28 @@ int resultSetAppendRaw(ResultSet *rsp, unsigned n, const smaltgpu_result *res, c
 /* The state resultSetSortAndAssignSequence (results.c:2022) leaves in a ResultSet, taken from the library's post-processing
  * (smaltgpu_postprocess) instead of being computed here: `pr` are the set's n alignments in array order (the
  * raw alignments were injected before with resultSetInjectRaw), sortr/segsrtr index into them. */
-int resultSetInjectPost(ResultSet *rsp, unsigned n, const smaltgpu_post_result *pr, unsigned nsort, const int32_t *sortr,
+int resultSetInjectPost(ResultSet *rsp, unsigned n, const smaltgpu_post_result *pr, const unsigned char *pdstr, unsigned nsort, const int32_t *sortr,
                         const int32_t *segsrtr, unsigned nsegnor, const int32_t *segnor, int qsegno, unsigned setstatus)
 {
   unsigned i;
-  if (n != (unsigned) ARRLEN(rsp->resr)) return ERRCODE_ASSERT;
+  const unsigned nraw = (unsigned) ARRLEN(rsp->resr);
+  if (n < nraw) return ERRCODE_ASSERT;
+  for (i = nraw; i < n; i++) {             /* fragments of alignments that were cut at sequence junctions (splitMultiSpan, results.c:1570-1600) */
+    Result *hp;
+    DiffStr view;
+    int errcode;
+    ARRNEXTP(hp, rsp->resr);
+    if (!hp) return ERRCODE_NOMEM;
+    BLANK_RESULT(hp);
+    hp->swatscor = pr[i].swatscor;
+    hp->q_start = pr[i].q_start; hp->q_end = pr[i].q_end;
+    hp->stroffs = DIFFSTR_LENGTH(rsp->diffstrp);
+    hp->strlen = (int) pr[i].strlen;
+    memset(&view, 0, sizeof(view));
+    view.dstrp = (DIFFSTR_T *) (pdstr + pr[i].stroffs);
+    view.len = (int) pr[i].strlen;
+    if ((errcode = diffStrAppend(rsp->diffstrp, &view))) return errcode;
+  }
   for (i = 0; i < n; i++) {
     Result *rp = rsp->resr + i;
     rp->serialno = (short) i;

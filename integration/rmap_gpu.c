@@ -27,7 +27,7 @@
 /* results_inject.c (our TU around the reference's results.c) */
 extern int resultSetInjectRaw(ResultSet *rsp, unsigned n, const smaltgpu_result *res, const unsigned char *dstr,
                               int swatscor_max, int swatscor_2ndmax);
-extern int resultSetInjectPost(ResultSet *rsp, unsigned n, const smaltgpu_post_result *pr, unsigned nsort, const int32_t *sortr,
+extern int resultSetInjectPost(ResultSet *rsp, unsigned n, const smaltgpu_post_result *pr, const unsigned char *pdstr, unsigned nsort, const int32_t *sortr,
                                const int32_t *segsrtr, unsigned nsegnor, const int32_t *segnor, int qsegno, unsigned setstatus);
 extern int resultSetAppendRaw(ResultSet *rsp, unsigned n, const smaltgpu_result *res, const unsigned char *dstr,
                               int swatscor_max, int swatscor_2ndmax);
@@ -276,7 +276,7 @@ int rmapGpuFinish(ErrMsg *errmsgp, RMap *rmp, int i, SeqFastq *readp, short max_
   if (o->stat[i].max1scor >= 1) {                       /* mapSingleRead sorts only when the score pass found something (rmap.c:1376) */
     const smaltgpu_post_out *po = &g_map[slot].pout;
     if (g_map[slot].have_post && !po->needs_reference[i]) {      /* N1 from the library */
-      if ((errcode = resultSetInjectPost(rmp->rsrp, (unsigned)(po->res_off[i + 1] - po->res_off[i]), po->res + po->res_off[i],
+      if ((errcode = resultSetInjectPost(rmp->rsrp, (unsigned)(po->res_off[i + 1] - po->res_off[i]), po->res + po->res_off[i], po->diffstr,
                                          (unsigned)(po->sort_off[i + 1] - po->sort_off[i]), po->sortr + po->sort_off[i], po->segsrtr + po->sort_off[i],
                                          (unsigned)(po->seg_off[i + 1] - po->seg_off[i]), po->segnor + po->seg_off[i], po->qsegno[i], po->setstatus[i])))
         ERRMSGNO(errmsgp, errcode);
