@@ -53,6 +53,20 @@ static struct {
 } g_map[GPU_MAXMAPPERS];
 static int g_nmap = 0;
 
+/* SMALTGPU_TIMING=1: seconds per phase of the binding, summed over the worker threads, on stderr at exit */
+#include <time.h>
+static int g_timing = 0;
+enum { TM_STAGE, TM_GPU, TM_POST, TM_INJECT, TM_REFPOST, TM_FILTER, TM_N };
+static double g_tm[GPU_MAXMAPPERS][TM_N], g_t_ready = 0.0;      /* g_t_ready: the index images are on the devices */
+static const char *const TM_NAME[TM_N] = {"stage", "gpu_wait", "lib_post", "inject", "ref_post", "filter"};
+static double tmNow(void) { struct timespec ts; if (!g_timing) return 0.0; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+static void tmReport(void)
+{
+  int i, j;
+  fprintf(stderr, "smaltgpu timing: window    %8.3f s from the index being resident to exit\n", tmNow() - g_t_ready);
+  for (j = 0; j < TM_N; j++) { double t = 0.0; for (i = 0; i < g_nmap; i++) t += g_tm[i][j]; fprintf(stderr, "smaltgpu timing: %-9s %8.3f thread-s over %d workers\n", TM_NAME[j], t, g_nmap); }
+}
+
 /* the environment is read once, before any mapper exists; worker threads never call setenv */
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;
 static void gpuReadConfig(void)
@@ -61,6 +75,7 @@ static void gpuReadConfig(void)
   g_combine = !getenv("SMALTGPU_NO_COMBINE");
   g_libpost = !getenv("SMALTGPU_REF_POST");
   g_prefix = getenv("SMALTGPU_INDEX_PREFIX");
+  if (getenv("SMALTGPU_TIMING")) { g_timing = 1; atexit(tmReport); }
   g_nphys = g_ndev = smaltgpu_device_count();
   if (e && atoi(e) > 0) g_ndev = atoi(e);        /* more than there are GPUs: images share devices (rehearsal of the N-device path on one GPU) */
   if (g_ndev > GPU_MAXDEV) g_ndev = GPU_MAXDEV;
@@ -87,6 +102,7 @@ static int gpuMapperForBatch(const RMap *rmp, uint32_t rlen, uint32_t nreads, si
     if (!g_prefix || smaltgpu_index_load(&g_ixdev[0], g_prefix, 0)) { pthread_mutex_unlock(&g_lock); return -1; }
     for (dv = 1; dv < g_ndev; dv++)
       if (smaltgpu_index_clone(&g_ixdev[dv], g_ixdev[0], dv % g_nphys)) { pthread_mutex_unlock(&g_lock); return -1; }
+    g_t_ready = tmNow();
   }
   pthread_mutex_unlock(&g_lock);
   if (slot < 0) return -1;
@@ -194,6 +210,7 @@ int rmapGpuBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, int n, int 
   pthread_once(&g_once, gpuReadConfig);
   const int combine = g_combine;                             /* default: blocks of all worker threads form one GPU batch */
   if ((slot = gpuMapperForBatch(rmp, maxlen, (uint32_t)n, tot, !combine)) < 0) { fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error()); ERRMSGNO(errmsgp, ERRCODE_FAILURE); }
+  double t0 = tmNow(), t1;
   for (i = 0, tot = 0; i < n; i++) {
     const char *seqp = seqFastqGetConstSequence(reads[i], &rlen, &cod);
     const char *qualp = seqFastqGetConstQualityFactors(reads[i], &qlen, &qcod);
@@ -214,6 +231,7 @@ int rmapGpuBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, int n, int 
   else { par.min_cover = (uint32_t)tupcovmin; par.min_cover_frac = 0.0; }
   g_map[slot].nbatch = 0;
   g_map[slot].use_comb = combine;
+  t1 = tmNow(); g_tm[slot][TM_STAGE] += t1 - t0; t0 = t1;
   if (combine) {
     char emsg[256] = "";
     if (gpuCombineSubmit(g_ndev, (const smaltgpu_index *const *)g_ixdev, g_map[slot].bases, has_qual ? g_map[slot].quals : NULL, g_map[slot].off,
@@ -233,6 +251,7 @@ int rmapGpuBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, int n, int 
     }
   }
   g_map[slot].nbatch = n;
+  t1 = tmNow(); g_tm[slot][TM_GPU] += t1 - t0; t0 = t1;
   /* result post-processing of the whole block by the library (smaltgpu_postprocess: what resultSetSortAndAssignSequence
    * would compute read by read, results.c:2022); SMALTGPU_REF_POST keeps the reference's own routine instead */
   g_map[slot].have_post = 0;
@@ -252,6 +271,7 @@ int rmapGpuBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, int n, int 
                              has_qual ? (const uint8_t *)g_map[slot].quals : NULL, g_map[slot].off, packed, &par, 1, &g_map[slot].pout) == SMALTGPU_OK)
       g_map[slot].have_post = 1;
   }
+  g_tm[slot][TM_POST] += tmNow() - t0;
   return ERRCODE_SUCCESS;
 }
 
@@ -269,10 +289,12 @@ int rmapGpuFinish(ErrMsg *errmsgp, RMap *rmp, int i, SeqFastq *readp, short max_
   (void)seqFastqGetConstSequence(readp, &rlen, NULL);
   if (rlen < hashTableGetKtupLen(htp, NULL)) return ERRCODE_SUCCESS;                      /* ERRCODE_SHORTSEQ is swallowed (rmap.c:1736) */
   if (o->stat[i].errcode) ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+  double t0 = tmNow(), t1;
   if ((errcode = resultSetInjectRaw(rmp->rsrp, (unsigned)(o->res_off[i + 1] - o->res_off[i]), o->res + o->res_off[i], o->diffstr,
                                     o->stat[i].swatscor_max, o->stat[i].swatscor_2ndmax)))
     ERRMSGNO(errmsgp, errcode);
   resultSetAlignmentStats(rmp->rsrp, o->stat[i].n_ali_done, o->stat[i].n_ali_tot, max_depth, o->stat[i].n_hits_used, o->stat[i].n_hits_tot);
+  int tm_kind = TM_INJECT;
   if (o->stat[i].max1scor >= 1) {                       /* mapSingleRead sorts only when the score pass found something (rmap.c:1376) */
     const smaltgpu_post_out *po = &g_map[slot].pout;
     if (g_map[slot].have_post && !po->needs_reference[i]) {      /* N1 from the library */
@@ -280,10 +302,15 @@ int rmapGpuFinish(ErrMsg *errmsgp, RMap *rmp, int i, SeqFastq *readp, short max_
                                          (unsigned)(po->sort_off[i + 1] - po->sort_off[i]), po->sortr + po->sort_off[i], po->segsrtr + po->sort_off[i],
                                          (unsigned)(po->seg_off[i + 1] - po->seg_off[i]), po->segnor + po->seg_off[i], po->qsegno[i], po->setstatus[i])))
         ERRMSGNO(errmsgp, errcode);
-    } else if ((errcode = resultSetSortAndAssignSequence(rmp->rsrp, rmp->bfp->sqbfp, 0, readp, rmp->prp->scorprofp, rmp->prp->scorprofRCp, ssp, codecp)))
-      ERRMSGNO(errmsgp, errcode);                        /* an alignment across a sequence junction (splitMultiSpan), or SMALTGPU_REF_POST */
+    } else {
+      tm_kind = TM_REFPOST;
+      if ((errcode = resultSetSortAndAssignSequence(rmp->rsrp, rmp->bfp->sqbfp, 0, readp, rmp->prp->scorprofp, rmp->prp->scorprofRCp, ssp, codecp)))
+        ERRMSGNO(errmsgp, errcode);                      /* an alignment across a sequence junction (splitMultiSpan), or SMALTGPU_REF_POST */
+    }
   }
+  t1 = tmNow(); g_tm[slot][tm_kind] += t1 - t0; t0 = t1;
   if ((errcode = resultSetFilterResults(rmp->rsrp, rsfp, readp))) ERRMSGNO(errmsgp, errcode);
+  g_tm[slot][TM_FILTER] += tmNow() - t0;
   return ERRCODE_SUCCESS;
 }
 

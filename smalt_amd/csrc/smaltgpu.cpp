@@ -360,7 +360,7 @@ static int dalloc(T **p, size_t n) {
   return 0;
 }
 
-static uint32_t next_pow2(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+static uint64_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v && p < (1ull << 62)) p <<= 1; return p; }
 
 extern "C" int smaltgpu_mapper_create(smaltgpu_mapper **out, const smaltgpu_index *ix, uint32_t max_batch_reads, uint32_t max_read_len) {
   return smaltgpu_mapper_create_ex(out, ix, max_batch_reads, max_read_len, nullptr);
@@ -414,6 +414,7 @@ extern "C" int smaltgpu_mapper_create_ex(smaltgpu_mapper **out, const smaltgpu_i
   if (b.dstrcap > 0xFFFFFFF0ull) b.dstrcap = 0xFFFFFFF0ull;    // smaltgpu_result.stroffs is 32 bits wide: a batch that needs more reports SMALTGPU_ECAP and is re-mapped in parts
   DA(b.dstrpool, b.dstrcap);
   DA(b.align_retry, max_batch_reads);
+  DA(b.cands_retry, max_batch_reads);
   DA(m->d_counters, 512);
   if (!rv) {
     b.rc_count = (uint32_t *)(m->d_counters + 0);
@@ -422,6 +423,7 @@ extern "C" int smaltgpu_mapper_create_ex(smaltgpu_mapper **out, const smaltgpu_i
     b.err_flag = (int32_t *)(m->d_counters + 24);
     b.next_item = (uint32_t *)(m->d_counters + 32);
     b.align_retry_n = (uint32_t *)(m->d_counters + 56);
+    b.cands_retry_n = (uint32_t *)(m->d_counters + 60);
     b.work = (unsigned long long *)(m->d_counters + 64);
   }
   // scratch geometry -------------------------------------------------------------------
@@ -436,7 +438,7 @@ extern "C" int smaltgpu_mapper_create_ex(smaltgpu_mapper **out, const smaltgpu_i
     memset(&m->cg, 0, sizeof(m->cg));
     // A strand gathers at most `alloc` hits per reference sequence (hashhit.c:1497); reads that take
     // the allocation-boundary protocol can therefore exceed `alloc` over all sequences: 4x headroom.
-    m->cg.hcap_strand = next_pow2(4 * alloc);
+    m->cg.hcap_strand = (uint32_t)std::min<uint64_t>(next_pow2(4 * alloc), 1ull << 30);
     m->cg.hcap = 2 * m->cg.hcap_strand;
     m->cg.ngrp = d.nseq < 512 ? (uint32_t)d.nseq : 1u;  // both modes fit: concatenated mode uses group 0
     m->cg.segcap = m->cg.hcap / 2;
@@ -459,19 +461,36 @@ extern "C" int smaltgpu_mapper_create_ex(smaltgpu_mapper **out, const smaltgpu_i
     if (m->cg.lds_hits > 2048) m->cg.lds_hits = 2048;
     m->cg.slot_bytes = m->cand_bytes = cand_slot_bytes(m->cg, m->qmax, d.s);
     memset(&m->cg2, 0, sizeof(m->cg2));
+    // Two passes.  The slots of the first pass hold 4 x the reference's hit-list allocation per strand (long reads, whose
+    // slots would be gigabytes that way: 24 hits per read base and strand); a read that overflows its slot is deferred
+    // (SMG_ERR_RETRY) to a second launch over a few slots that hold what the reference's protocol can gather at most: `alloc`
+    // hits per strand and reference sequence (hashhit.c:1497; 134 k hits on one strand of a 150-base read against 24
+    // sequences were seen at 1 in 2 M reads of the bench's repeat-rich reference), every hit a candidate of its own.
+    auto geom_for = [&](uint64_t hs) { CandGeom g = m->cg; g.hcap_strand = (uint32_t)hs; g.hcap = (uint32_t)(2 * hs); g.segcap = (uint32_t)hs; g.candcap = (uint32_t)(2 * hs);
+                                       g.slot_bytes = cand_slot_bytes(g, m->qmax, d.s); return g; };
+    const CandGeom full = m->cg;
     if (m->cand_bytes > (64ull << 20)) {
-      // Long reads: the worst case (4 x the reference's hit-list allocation per strand, every hit a candidate of its own)
-      // is gigabytes per slot.  The slots of the first pass hold 24 hits per read base and strand; a read that
-      // overflows one is deferred to a second launch over a few worst-case slots.
-      m->cg2 = m->cg; m->cg2.pass = 2; m->cand_bytes2 = m->cand_bytes;
-      uint32_t hs = next_pow2((uint64_t)24 * m->qmax);
+      uint64_t hs = next_pow2((uint64_t)24 * m->qmax);
       if (const char *e = getenv("SMALTGPU_CANDS_HCAP")) { const long v = atol(e); if (v >= 1024) hs = next_pow2((uint64_t)v); }   // test hook
-      if (hs < m->cg.hcap_strand) {
-        m->cg.hcap_strand = hs; m->cg.hcap = 2 * hs; m->cg.segcap = hs; m->cg.candcap = 2 * hs; m->cg.pass = 1;
-        m->cg.slot_bytes = m->cand_bytes = cand_slot_bytes(m->cg, m->qmax, d.s);
-        m->cand_slots2 = max_batch_reads < 8 ? max_batch_reads : 8;
+      if (hs < m->cg.hcap_strand) { m->cg = geom_for(hs); m->cand_bytes = m->cg.slot_bytes; }
+    } else if (const char *e = getenv("SMALTGPU_CANDS_HCAP")) {
+      const long v = atol(e);
+      if (v >= 1024 && next_pow2((uint64_t)v) < m->cg.hcap_strand) { m->cg = geom_for(next_pow2((uint64_t)v)); m->cand_bytes = m->cg.slot_bytes; }
+    }
+    {
+      uint64_t hw = next_pow2((uint64_t)m->cg.ngrp * alloc);
+      if (hw < full.hcap_strand) hw = full.hcap_strand;
+      while (hw > full.hcap_strand && (hw > (1ull << 30) || geom_for(hw).slot_bytes > (4ull << 30))) hw >>= 1;      // at most 4 GB per slot
+      if (hw > m->cg.hcap_strand) {
+        m->cg2 = geom_for(hw); m->cg2.pass = 2; m->cand_bytes2 = m->cg2.slot_bytes;
+        m->cg.pass = 1;
+        uint64_t n2 = (opt_budget ? ((uint64_t)opt_budget << 30) / 4 : (8ull << 30)) / m->cand_bytes2;      // many mappers on one device: a quarter of their slot budget
+        if (n2 > 8) n2 = 8;
+        if (n2 < 1) n2 = 1;
+        if (n2 > max_batch_reads) n2 = max_batch_reads;
+        m->cand_slots2 = (uint32_t)n2;
         DA(m->cand_scr2, m->cand_bytes2 * m->cand_slots2);
-      } else { memset(&m->cg2, 0, sizeof(m->cg2)); m->cand_bytes2 = 0; }
+      }
     }
     uint64_t budget = 64ull << 30;     // of 288 GB: more slots than resident workgroups lets the hardware balance uneven reads
     if (opt_budget) budget = (uint64_t)opt_budget << 30;              // many mappers on one device
@@ -530,7 +549,7 @@ extern "C" void smaltgpu_mapper_free(smaltgpu_mapper *m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   void *ps[] = {m->d_bases, m->d_quals, m->d_codes, m->d_codes_rc, m->d_off, m->b.hi, m->b.seeds, m->b.qmask, m->b.ch, m->b.ctl,
-                m->b.stat, m->b.align_retry, m->b.rcpool, m->b.long_list, m->b.strip_list, m->strip_bnd, m->strip_win, m->b.respool, m->b.dstrpool, m->d_counters, m->seed_scr, m->cand_scr, m->cand_scr2, m->cand_scr_dbg,
+                m->b.stat, m->b.align_retry, m->b.cands_retry, m->b.rcpool, m->b.long_list, m->b.strip_list, m->strip_bnd, m->strip_win, m->b.respool, m->b.dstrpool, m->d_counters, m->seed_scr, m->cand_scr, m->cand_scr2, m->cand_scr_dbg,
                 m->sw_rows, m->align_scr, m->align_scr2};
   for (void *p : ps) if (p) (void)hipFree(p);
   m->h_stat.release(); m->h_res.release(); m->h_dstr.release();

@@ -129,8 +129,10 @@ __global__ void __launch_bounds__(64, 2) k_cands(Batch b, DevIndex ix, MapPar p,
     __syncthreads();
   }
   uint32_t *cursor = b.next_item + (g.pass == 2 ? 4 : 1);
-  for (uint32_t r = next_item(cursor, &qslot); r < b.nreads; r = next_item(cursor, &qslot)) {
-    if (g.pass == 2 && b.ch[r].err != SMG_ERR_RETRY) continue;       // wave-uniform: the first pass finished this read
+  // second pass: only the reads the first pass deferred (usually none: the launch ends at once)
+  const uint32_t nitem = g.pass == 2 ? *b.cands_retry_n : b.nreads;
+  for (uint32_t it = next_item(cursor, &qslot); it < nitem; it = next_item(cursor, &qslot)) {
+    const uint32_t r = g.pass == 2 ? b.cands_retry[it] : it;
     uint8_t *base = gscratch + g.slot_bytes * (g.debug ? r : blockIdx.x);
     const DevIndex rix = read_index(b, ix, r);
     if (cands_v2_applicable(p, rix.k, rix.s, read_len(b, r))) {
@@ -146,6 +148,7 @@ __global__ void __launch_bounds__(64, 2) k_cands(Batch b, DevIndex ix, MapPar p,
       nhit += stage_cands(b, ix, p, r, x);
     }
     __syncthreads();
+    if (g.pass == 1 && threadIdx.x == 0 && b.ch[r].err == SMG_ERR_RETRY) b.cands_retry[atomicAdd(b.cands_retry_n, 1u)] = r;
   }
   if (threadIdx.x == 0) {
     if (nhit) atomicAdd(b.work + WK_HITS, nhit);

@@ -40,6 +40,7 @@ struct Batch {                          // one block of reads resident in HBM
   int32_t *err_flag;                    // batch-wide first error
   uint32_t *next_item;                  // [5] work-queue cursors of the persistent kernels (seed, cands, align, align pass 2, cands pass 2)
   uint32_t *align_retry, *align_retry_n; // reads the first K3 pass deferred to the second one (SMG_ERR_RETRY), and how many
+  uint32_t *cands_retry, *cands_retry_n; // the same for the candidate stage (reads whose hits overflow a first-pass slot)
   unsigned long long *work;             // [WK_NWORK] work counters (WK_*), one atomic per workgroup
   // ---- per-read context of the mapSingleRead calls rmapPair makes (rmap.c:1744-2112); all null for plain batches ----
   const uint32_t *iv_off; const IvRec *iv;   // seeding restricted to intervals iv[iv_off[r] .. iv_off[r+1]) (collectHitsFromInterVal, rmap.c:438-492)

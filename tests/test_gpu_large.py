@@ -24,13 +24,18 @@ def _oracle_map_all(oix, reads, par):
     return out
 
 
-@pytest.mark.parametrize("window", [0, 300], ids=["w-default", "w300"])
+@pytest.mark.parametrize("window", [0, 300, -1024], ids=["w-default", "w300", "deferred-cands"])
 def test_repeat_rich_genome_matches_oracle(window, oracle_built, tmp_path, monkeypatch):
     """window=300 shrinks the LDS window of the candidate stage so that most strands are streamed in
-    several windows and a few fall back to the HBM working set (a hit region larger than the window)."""
+    several windows and a few fall back to the HBM working set (a hit region larger than the window).
+    -1024: first-pass candidate slots of 1024 hits per strand -- every repeat read overflows its slot and is deferred to the
+    second pass over the few worst-case slots (the path a read with more hits than 4 x the reference's hit-list allocation
+    takes: 1 in 2 M reads of the bench's reference)."""
     from smalt_amd import api, synth
-    if window:
+    if window > 0:
         monkeypatch.setenv("SMALTGPU_CANDS_WINDOW", str(window))
+    if window < 0:
+        monkeypatch.setenv("SMALTGPU_CANDS_HCAP", str(-window))
     ch = synth.make_reference(4, 2_500_000, seed=21, repeat_frac=0.15, n_fam=1, cons_len=300, divergence=0.05)
     reads, _ = synth.make_reads(ch, 1500, 100, seed=22, sub_rate=0.01, indel_read_frac=0.05)
     seqs = [synth.codes_to_ascii(c) for c in ch]
