@@ -238,6 +238,59 @@ int smaltgpu_postprocess(smaltgpu_post *p, const uint64_t *sop, int64_t nseq, co
                          const uint8_t *quals, const uint64_t *read_off, const uint32_t *packed_host, const smaltgpu_params *par, int nthreads,
                          smaltgpu_post_out *out);
 
+/* ---- read ingest and report emit (host code, no device; smg_report.cpp) ------------------------------------
+ * The reference reads FASTQ / FASTA through one reader thread (seqFastqRead, sequence.c:1960; readHeader :1056, readSeqFast
+ * :1229) and prints through the main thread (reportWrite, report.c:1758).  Here a text buffer (a whole file or a chunk of it)
+ * becomes the batch layout of smaltgpu_map_batch in one call, and the post-processed results of a batch become the text
+ * `smalt map` prints for these reads (single reads; CIGAR and SAM formats), both with worker threads.
+ *
+ * smaltgpu_reads_parse: `text[0..len)`; is_last = 0: a record that may continue behind the buffer is left (view->consumed
+ * says how far the text was used: call again from there with more text); max_reads = 0: no limit.  Plain four-line FASTQ is
+ * split over `nthreads`; anything else (FASTA, wrapped lines, blank lines) takes the reference's rules on one thread.
+ * The view's arrays belong to `rs` and hold until the next call: bases as the reference's codec prints them (upper case,
+ * U -> T, non-letters N; smaltgpu_map_batch takes them as they are), quality characters as in the file (NULL without any:
+ * a block with a FASTA record has none), names = the first word of each header, NUL-terminated, by name_off. */
+typedef struct smaltgpu_reads smaltgpu_reads;
+typedef struct smaltgpu_reads_view {
+  uint32_t nreads, has_qual;
+  const uint8_t *bases, *quals;
+  const uint64_t *read_off;            /* nreads + 1 */
+  const char *names;
+  const uint64_t *name_off;            /* nreads + 1 */
+  uint64_t consumed;                   /* bytes of text the reads came from */
+} smaltgpu_reads_view;
+smaltgpu_reads *smaltgpu_reads_create(void);
+void smaltgpu_reads_free(smaltgpu_reads *rs);
+int smaltgpu_reads_parse(smaltgpu_reads *rs, const char *text, uint64_t len, int is_last, uint32_t max_reads, int nthreads,
+                         smaltgpu_reads_view *view);
+
+/* Report: which alignments of a read are printed (resultSetFilterResults, results.c:2592; resultSetAddToReport, results.c:2282;
+ * reportAddMap's duplicate test, report.c:545) and the lines themselves (fprintREPALIcigar report.c:711, fprintREPALIsam
+ * report.c:762, writeDiffStrCIGAR diffstr.c:298, SAM header report.c:1266). */
+enum { SMALTGPU_FMT_CIGAR = 0, SMALTGPU_FMT_SAM = 1 };                                   /* -f cigar | sam (REPORTFMT_*, report.h:46-52) */
+enum { SMALTGPU_REP_SOFTCLIP = 0x02, SMALTGPU_REP_HEADER = 0x04, SMALTGPU_REP_XMISMATCH = 0x08 };   /* REPORTMODIF_* (report.h:54-59) */
+enum { SMALTGPU_OUT_BEST = 0x01, SMALTGPU_OUT_SINGLE = 0x02, SMALTGPU_OUT_RANDSEL = 0x08 };         /* RESULTFLG_* (results.h:55-63) */
+typedef struct smaltgpu_report_opts {
+  int32_t format;
+  uint32_t modflags, outflags;
+  int32_t min_swscor;                  /* resultSetFilterData (smalt.c:490): the -m value, 18 without one -- NOT the mapping threshold k+s-1 */
+  int32_t min_swscor_below_max;        /* -d */
+  double min_identity;                 /* -y: fraction of the read length if <= 1, else bases */
+} smaltgpu_report_opts;
+typedef struct smaltgpu_report smaltgpu_report;      /* owns the text it hands out */
+smaltgpu_report *smaltgpu_report_create(void);
+void smaltgpu_report_free(smaltgpu_report *rp);
+/* text in front of the first read (the SAM header; empty for the other formats).  seqnames / sop / nseq: smaltgpu_index_seqnames */
+int smaltgpu_report_header(smaltgpu_report *rp, const char *const *seqnames, const uint64_t *sop, int64_t nseq, const smaltgpu_report_opts *op,
+                           const char *prognam, const char *version, int argc, const char *const *argv, const char **text, uint64_t *len);
+/* the lines of a batch: post = smaltgpu_postprocess of `raw` (raw may be NULL: it only supplies the per-read error codes),
+ * reads = the parsed block the batch was mapped from.  A random choice among equal best alignments (SMALTGPU_OUT_RANDSEL,
+ * -r <seed>) draws from drand48() in read order: seed it with srand48 as RANSEED does (randef.h:19). */
+int smaltgpu_report_emit(smaltgpu_report *rp, const smaltgpu_post_out *post, const smaltgpu_batch_out *raw, const smaltgpu_reads_view *reads,
+                         const char *const *seqnames, int64_t nseq, const smaltgpu_report_opts *op, int nthreads, const char **text, uint64_t *len);
+/* names and offsets of the reference sequences of an index (for the two calls above); the arrays belong to the index */
+int smaltgpu_index_seqnames(const smaltgpu_index *ix, const char *const **names, const uint64_t **sop, int64_t *nseq);
+
 /* Per-kernel device time (ms, HIP events on the mapper's stream) and work counters of the last
  * batch: names in smaltgpu_timer_name().  For bench.py's roofline object. */
 int smaltgpu_timers(const smaltgpu_mapper *m, double *ms, uint64_t *work, int n);

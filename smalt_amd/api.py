@@ -72,6 +72,21 @@ class PostOut(C.Structure):
                 ("setstatus", C.POINTER(C.c_uint32)), ("needs_reference", C.POINTER(C.c_int32))]
 
 
+class ReadsView(C.Structure):          # smaltgpu_reads_view
+    _fields_ = [("nreads", C.c_uint32), ("has_qual", C.c_uint32), ("bases", C.POINTER(C.c_uint8)), ("quals", C.POINTER(C.c_uint8)),
+                ("read_off", C.POINTER(C.c_uint64)), ("names", C.POINTER(C.c_char)), ("name_off", C.POINTER(C.c_uint64)), ("consumed", C.c_uint64)]
+
+
+class ReportOpts(C.Structure):         # smaltgpu_report_opts
+    _fields_ = [("format", C.c_int32), ("modflags", C.c_uint32), ("outflags", C.c_uint32), ("min_swscor", C.c_int32),
+                ("min_swscor_below_max", C.c_int32), ("min_identity", C.c_double)]
+
+
+FMT_CIGAR, FMT_SAM = 0, 1
+REP_SOFTCLIP, REP_HEADER, REP_XMISMATCH = 0x02, 0x04, 0x08
+OUT_BEST, OUT_SINGLE, OUT_RANDSEL = 0x01, 0x02, 0x08
+
+
 class MapperOpts(C.Structure):
     _fields_ = [("cands_per_read", C.c_uint32), ("slot_budget_gb", C.c_uint32)]
 
@@ -120,6 +135,16 @@ def lib():
         L.smaltgpu_post_free.argtypes = [C.c_void_p]
         L.smaltgpu_postprocess.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64, C.POINTER(BatchOut), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64),
                                            C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(PostOut)]
+        L.smaltgpu_reads_create.restype = C.c_void_p
+        L.smaltgpu_reads_free.argtypes = [C.c_void_p]
+        L.smaltgpu_reads_parse.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_int, C.c_uint32, C.c_int, C.POINTER(ReadsView)]
+        L.smaltgpu_report_create.restype = C.c_void_p
+        L.smaltgpu_report_free.argtypes = [C.c_void_p]
+        L.smaltgpu_report_header.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.c_int64, C.POINTER(ReportOpts), C.c_char_p, C.c_char_p,
+                                             C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.smaltgpu_report_emit.argtypes = [C.c_void_p, C.POINTER(PostOut), C.POINTER(BatchOut), C.POINTER(ReadsView), C.POINTER(C.c_char_p), C.c_int64,
+                                           C.POINTER(ReportOpts), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.smaltgpu_index_seqnames.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_int64)]
         L.smaltgpu_map_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
                                                 C.POINTER(Params)]
         L.smaltgpu_fetch_results.argtypes = [C.c_void_p, C.POINTER(BatchOut)]

@@ -32,6 +32,7 @@ static int fail(int code, const char *fmt, ...) {
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(SMALTGPU_ENODEV, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
 
 extern "C" const char *smaltgpu_last_error(void) { return g_err.c_str(); }
+extern "C" int smaltgpu_set_error(int code, const char *msg) { return fail(code, "%s", msg ? msg : ""); }   // for the library's other translation units
 extern "C" int smaltgpu_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -49,6 +50,7 @@ struct smaltgpu_index {
   std::vector<std::string> names;  // set by smaltgpu_index_build (what smaltgpu_index_save writes)
   uint32_t maxpos = 0;
   bool built = false;
+  std::vector<const char *> name_ptrs;  // smaltgpu_index_seqnames
   std::vector<uint32_t> packed_host;   // host copy of the packed reference, fetched on first request (smaltgpu_index_packed_host)
   std::mutex packed_mu;
 };
@@ -108,7 +110,19 @@ extern "C" int smaltgpu_index_load(smaltgpu_index **out, const char *prefix, int
   ds.k = h.k; ds.s = h.s; ds.typ = h.typ; ds.nbits_key = h.nbits_key; ds.nbits_lo = h.nbits_lo; ds.npos = h.npos; ds.nwords = h.nwords;
   ds.idx = h.idx.data(); ds.pos = h.pos.data(); ds.wordidx = h.wordidx.data(); ds.posidx = h.posidx.data();
   ds.nseq = h.nseq; ds.sop = h.sop.data(); ds.packed = h.packed.data(); ds.on_device = 0;
-  return smaltgpu_index_create(out, &ds, device);
+  const int rv = smaltgpu_index_create(out, &ds, device);
+  if (!rv) (*out)->names = h.names;
+  return rv;
+}
+
+extern "C" int smaltgpu_index_seqnames(const smaltgpu_index *cix, const char *const **names, const uint64_t **sop, int64_t *nseq) {
+  smaltgpu_index *ix = const_cast<smaltgpu_index *>(cix);
+  if (!ix || !names || !sop || !nseq) return fail(SMALTGPU_EARG, "null argument");
+  if ((int64_t)ix->names.size() != ix->d.nseq) return fail(SMALTGPU_EARG, "the index was adopted from arrays without sequence names");
+  std::lock_guard<std::mutex> lk(ix->packed_mu);
+  if (ix->name_ptrs.empty()) for (const std::string &x : ix->names) ix->name_ptrs.push_back(x.c_str());
+  *names = ix->name_ptrs.data(); *sop = ix->sop.data(); *nseq = ix->d.nseq;
+  return SMALTGPU_OK;
 }
 
 // A second image of an index on another device, copied device to device (xGMI between the GPUs of a node) instead of being

@@ -1,0 +1,290 @@
+// smaltgpu-map -- `smalt map` for single reads on top of the C ABI of include/smaltgpu.h, file to file:
+//   FASTQ/FASTA text --smaltgpu_reads_parse--> batch --smaltgpu_map_batch (GPU)--> raw alignments
+//   --smaltgpu_postprocess--> mapping qualities, order --smaltgpu_report_emit--> CIGAR / SAM text.
+// The option letters, defaults and derived flags follow the reference's `smalt map` (menu.c:1147-1160 defaults,
+// :1340-1345 -d, :1487-1497 -r; smalt.c:209-245 output formats, :490-503 result flags, :608-615 default -m) so that the
+// same command line prints the same lines (tests/test_gpu_report.py).  Host code only: it needs libsmaltgpu.so, not hipcc.
+//
+// Three stages run side by side: one thread parses the next block of the (memory-mapped) input, two threads own a
+// mapper each and take blocks in turn (host copies of one block overlap the kernels of the other), the main thread
+// formats and writes the blocks in input order.
+#include <fcntl.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/smaltgpu.h"
+
+namespace {
+
+const char VERSION[] = "0.2";
+
+[[noreturn]] void die(const char *what, const char *detail = nullptr) {
+  fprintf(stderr, "smaltgpu-map: %s%s%s\n", what, detail ? ": " : "", detail ? detail : "");
+  exit(1);
+}
+
+void usage() {
+  fprintf(stderr,
+          "usage: smaltgpu-map [options] <index prefix> <reads.fq|reads.fa>\n"
+          "  -f <fmt>   cigar (default) | sam | samsoft, SAM modifiers behind a colon: nohead, clip, x (e.g. sam:nohead,x)\n"
+          "  -o <file>  output file (default: standard output)\n"
+          "  -m <int>   minimum Smith-Waterman score (default: word length + step - 1)\n"
+          "  -d <int>   report alignments within <int> of the best score; -1: all (default 0: best only)\n"
+          "  -r <int>   seed for the random choice among equally good alignments; < 0: such reads are reported unmapped;\n"
+          "             0 (default): seeded by the clock\n"
+          "  -y <num>   minimum identity (fraction of the read if <= 1, else bases)\n"
+          "  -c <num>   minimum k-mer cover (fraction of the read if <= 1, else bases)\n"
+          "  -x         more sensitive search (all seeds, deeper candidate lists)\n"
+          "  -q <int>   base quality threshold for k-mer words\n"
+          "  -n <int>   host threads for parsing, post-processing and formatting (default: up to 16)\n"
+          "  -B <int>   reads per GPU batch (default 262144)\n"
+          "  -g <int>   device (default 0)\n"
+          "single reads only; paired reads (-i -j -l -p), split reads (-p) and -w go through the bound reference program (INTEGRATION.md)\n");
+  exit(2);
+}
+
+struct Block {                                  // one block of reads on its way through the stages
+  smaltgpu_reads *rs = nullptr;
+  smaltgpu_reads_view v;
+  uint32_t maxlen = 0;
+  int state = 0;                                // 0 free, 1 parsed, 2 mapped + post-processed, 3 end of input
+  int worker = -1;
+  smaltgpu_batch_out raw;
+  smaltgpu_post_out post;
+  std::string err;
+};
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  const char *fmt = "cigar", *oufil = nullptr;
+  int m = -1, d = 0, seed = 0, q = 0, nthreads = 0, device = 0;
+  bool d_given = false, randrepeat = true, exhaustive = false;
+  double minid = 0.0, mincover = 0.0;
+  long batch = 262144;
+  int a = 1;
+  for (; a < argc && argv[a][0] == '-' && argv[a][1]; a++) {
+    const char o = argv[a][1];
+    if (o == 'x' && !argv[a][2]) { exhaustive = true; continue; }
+    if (argv[a][2] || !strchr("fomdrycqnBg", o)) {
+      if (strchr("ijlpwSTFa", o) && !argv[a][2]) die("option not supported by this program (use the bound `smalt map`, INTEGRATION.md)", argv[a]);
+      usage();
+    }
+    if (a + 1 >= argc) usage();
+    const char *val = argv[++a];
+    switch (o) {
+      case 'f': fmt = val; break;
+      case 'o': oufil = val; break;
+      case 'm': m = atoi(val); if (m < 0) die("-m out of range"); break;
+      case 'd': d = atoi(val); d_given = true; break;                                   // MENUFLAG_RELSCOR (menu.c:1343)
+      case 'r': seed = atoi(val); randrepeat = seed >= 0; break;                        // menu.c:1487-1497
+      case 'y': minid = atof(val); if (minid < 0) die("-y out of range"); break;
+      case 'c': mincover = atof(val); if (mincover < 0) die("-c out of range"); break;
+      case 'q': q = atoi(val); break;
+      case 'n': nthreads = atoi(val); break;
+      case 'B': batch = atol(val); if (batch < 1 || batch > (1L << 22)) die("-B out of range"); break;
+      case 'g': device = atoi(val); break;
+    }
+  }
+  if (argc - a != 2) usage();
+  const char *prefix = argv[a], *readfil = argv[a + 1];
+  if (nthreads < 1) { nthreads = (int)std::thread::hardware_concurrency(); if (nthreads > 16) nthreads = 16; if (nthreads < 1) nthreads = 1; }
+
+  smaltgpu_report_opts ro;
+  memset(&ro, 0, sizeof(ro));
+  {                                                                                      // smalt.c:209-245, menu.c:940-1010
+    std::string f(fmt), key = f.substr(0, f.find(':'));
+    if (key == "cigar") ro.format = SMALTGPU_FMT_CIGAR;
+    else if (key == "sam" || key == "samsoft") { ro.format = SMALTGPU_FMT_SAM; ro.modflags = SMALTGPU_REP_HEADER | SMALTGPU_REP_SOFTCLIP; }
+    else die("output format not supported here (cigar, sam, samsoft)", fmt);
+    size_t p = f.find(':');
+    while (p != std::string::npos && ro.format == SMALTGPU_FMT_SAM) {
+      const size_t e = f.find(',', p + 1);
+      const std::string mod = f.substr(p + 1, e == std::string::npos ? std::string::npos : e - p - 1);
+      if (mod == "nohead") ro.modflags &= ~(uint32_t)SMALTGPU_REP_HEADER;
+      else if (mod == "clip") ro.modflags &= ~(uint32_t)SMALTGPU_REP_SOFTCLIP;
+      else if (mod == "x" || mod == "X") ro.modflags |= SMALTGPU_REP_XMISMATCH;
+      else if (!mod.empty()) die("unknown SAM modifier", mod.c_str());
+      p = e;
+    }
+  }
+  ro.min_swscor = m >= 0 ? m : 18;                                                       // resultSetFilterData gets the menu's value (smalt.c:490, menu.c:599)
+  ro.min_swscor_below_max = d;
+  ro.min_identity = minid;
+  if (!d) {                                                                              // smalt.c:495-504
+    ro.outflags |= SMALTGPU_OUT_BEST;
+    if (!d_given) { ro.outflags |= SMALTGPU_OUT_SINGLE; if (randrepeat) ro.outflags |= SMALTGPU_OUT_RANDSEL; }
+  }
+  if (ro.outflags & SMALTGPU_OUT_RANDSEL) srand48(seed <= 0 ? (long)time(nullptr) : (long)seed);     // RANSEED (randef.h:19)
+
+  // input: the whole file mapped read-only
+  const int fd = open(readfil, O_RDONLY);
+  if (fd < 0) die("cannot open", readfil);
+  struct stat sb;
+  if (fstat(fd, &sb)) die("cannot stat", readfil);
+  const uint64_t flen = (uint64_t)sb.st_size;
+  const char *ftext = flen ? (const char *)mmap(nullptr, flen, PROT_READ, MAP_PRIVATE, fd, 0) : "";
+  if (flen && ftext == (const char *)MAP_FAILED) die("cannot map", readfil);
+  if (flen) (void)madvise((void *)ftext, flen, MADV_SEQUENTIAL);
+  FILE *ou = oufil ? fopen(oufil, "w") : stdout;
+  if (!ou) die("cannot write", oufil);
+  static char oubuf[1 << 22];
+  setvbuf(ou, oubuf, _IOFBF, sizeof(oubuf));
+
+  const auto t_start = std::chrono::steady_clock::now();
+  smaltgpu_index *ix = nullptr;
+  if (smaltgpu_index_load(&ix, prefix, device)) die("index", smaltgpu_last_error());
+  const auto t_index = std::chrono::steady_clock::now();
+  const char *const *seqnames; const uint64_t *sop; int64_t nseq;
+  if (smaltgpu_index_seqnames(ix, &seqnames, &sop, &nseq)) die("index", smaltgpu_last_error());
+  smaltgpu_params par;
+  smaltgpu_params_default(&par, ix);
+  if (m >= 0) par.min_swatscor = m;
+  par.min_swatscor_below_max = d;
+  if (d) par.rmapflg &= ~(uint32_t)SMALTGPU_FLG_BEST;
+  if (exhaustive) par.rmapflg |= SMALTGPU_FLG_NOSHRTINFO | SMALTGPU_FLG_SENSITIVE;      // smalt.c:531-533
+  par.min_basqval = (uint8_t)q;
+  if (mincover < 1.01) { par.min_cover = 0; par.min_cover_frac = mincover; } else { par.min_cover = (uint32_t)mincover; par.min_cover_frac = 0.0; }   // smalt.c:1113-1126
+  const uint32_t *packed = (par.rmapflg & SMALTGPU_FLG_SEQBYSEQ) ? nullptr : smaltgpu_index_packed_host(ix);    // concatenated mode: alignments across junctions are cut
+  if (!(par.rmapflg & SMALTGPU_FLG_SEQBYSEQ) && !packed) die("index", smaltgpu_last_error());
+
+  smaltgpu_report *rep = smaltgpu_report_create();
+  {
+    const char *htxt; uint64_t hlen;
+    if (smaltgpu_report_header(rep, seqnames, sop, nseq, &ro, "smaltgpu-map", VERSION, argc, (const char *const *)argv, &htxt, &hlen)) die("header", smaltgpu_last_error());
+    if (hlen && fwrite(htxt, 1, hlen, ou) != hlen) die("write error");
+  }
+
+  enum { NBLK = 4, NWORK = 2 };
+  Block blk[NBLK];
+  for (Block &b : blk) b.rs = smaltgpu_reads_create();
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t n_parsed = 0, n_taken = 0, n_written = 0;      // block serial numbers: block k lives in blk[k % NBLK]
+  bool input_done = false, failed = false;
+  uint64_t n_blocks_total = ~0ull;
+  double t_parse = 0, t_create[2] = {0, 0}, t_map[2] = {0, 0}, t_post[2] = {0, 0};          // seconds per stage (SMALTGPU_MAP_VERBOSE)
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+
+  std::thread parser([&] {
+    uint64_t pos = 0;
+    double bytes_per_read = 0.0;
+    for (uint64_t k = 0;; k++) {
+      Block &b = blk[k % NBLK];
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return failed || k < n_written + NBLK; }); if (failed) return; }
+      if (pos >= flen) { std::lock_guard<std::mutex> lk(mu); n_blocks_total = k; input_done = true; cv.notify_all(); return; }
+      uint64_t win = bytes_per_read > 0 ? (uint64_t)(bytes_per_read * (double)batch * 1.05) + 65536 : (1u << 20);
+      const double tp0 = now();
+      for (;;) {
+        if (win > flen - pos) win = flen - pos;
+        const int last = pos + win >= flen;
+        if (smaltgpu_reads_parse(b.rs, ftext + pos, win, last, (uint32_t)batch, nthreads, &b.v)) {
+          std::lock_guard<std::mutex> lk(mu); b.err = smaltgpu_last_error(); failed = true; cv.notify_all(); return;
+        }
+        if (b.v.nreads || last) break;
+        win *= 4;                                          // not one complete record in the window
+      }
+      if (!b.v.nreads) { std::lock_guard<std::mutex> lk(mu); n_blocks_total = k; input_done = true; cv.notify_all(); return; }
+      t_parse += now() - tp0;
+      bytes_per_read = (double)b.v.consumed / (double)b.v.nreads;
+      pos += b.v.consumed;
+      b.maxlen = 1;
+      for (uint32_t i = 0; i < b.v.nreads; i++) { const uint32_t l = (uint32_t)(b.v.read_off[i + 1] - b.v.read_off[i]); if (l > b.maxlen) b.maxlen = l; }
+      { std::lock_guard<std::mutex> lk(mu); b.state = 1; n_parsed = k + 1; cv.notify_all(); }
+    }
+  });
+
+  struct Worker { smaltgpu_mapper *mp = nullptr; smaltgpu_post *post = nullptr; uint32_t cap_reads = 0, cap_len = 0; bool busy = false; };
+  Worker wk[NWORK];
+  auto work = [&](int w) {
+    Worker &W = wk[w];
+    W.post = smaltgpu_post_create();
+    for (;;) {
+      uint64_t k;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return failed || (!W.busy && (n_taken < n_parsed || (input_done && n_taken >= n_blocks_total))); });
+        if (failed || (input_done && n_taken >= n_blocks_total)) return;
+        k = n_taken++;
+        W.busy = true;                                     // until the main thread has formatted this block (it reads the mapper's buffers)
+      }
+      Block &b = blk[k % NBLK];
+      std::string err;
+      double t0 = now(), t1;
+      if (!W.mp || W.cap_reads < b.v.nreads || W.cap_len < b.maxlen) {
+        if (W.mp) smaltgpu_mapper_free(W.mp);
+        W.mp = nullptr;
+        const uint32_t cr = b.v.nreads > (uint32_t)batch ? b.v.nreads : (uint32_t)batch, cl = (b.maxlen + 31u) & ~31u;
+        smaltgpu_mapper_opts mo = {0, 28};                 // two mappers share the device: 28 GB of candidate slots each
+        if (smaltgpu_mapper_create_ex(&W.mp, ix, cr, cl > W.cap_len ? cl : W.cap_len, &mo)) err = smaltgpu_last_error();
+        else { W.cap_reads = cr; W.cap_len = cl > W.cap_len ? cl : W.cap_len; }
+      }
+      t1 = now(); t_create[w] += t1 - t0; t0 = t1;
+      if (err.empty()) {
+        const int rv = smaltgpu_map_batch(W.mp, b.v.bases, b.v.has_qual ? b.v.quals : nullptr, b.v.read_off, b.v.nreads, &par, &b.raw);
+        if (rv && !((rv == SMALTGPU_ECAP || rv == SMALTGPU_EINTERNAL) && b.raw.nreads == b.v.nreads)) err = smaltgpu_last_error();
+      }
+      t1 = now(); t_map[w] += t1 - t0; t0 = t1;
+      if (err.empty() && smaltgpu_postprocess(W.post, sop, nseq, &b.raw, b.v.bases, b.v.has_qual ? b.v.quals : nullptr, b.v.read_off, packed, &par,
+                                              nthreads > 2 ? nthreads / 2 : 1, &b.post)) err = smaltgpu_last_error();
+      t_post[w] += now() - t0;
+      { std::lock_guard<std::mutex> lk(mu); b.worker = w; if (!err.empty()) { b.err = err; failed = true; } b.state = 2; cv.notify_all(); }
+    }
+  };
+  std::thread workers[NWORK];
+  for (int w = 0; w < NWORK; w++) workers[w] = std::thread(work, w);
+
+  std::string failure;
+  uint64_t nreads_total = 0;
+  double t_emit = 0, t_write = 0, t_wait = 0;
+  for (uint64_t k = 0;; k++) {
+    Block &b = blk[k % NBLK];
+    double t0 = now(), t1;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return failed || (input_done && k >= n_blocks_total) || (n_parsed > k && b.state == 2); });
+      if (failed) { for (Block &x : blk) if (!x.err.empty()) failure = x.err; break; }
+      if (input_done && k >= n_blocks_total) break;
+    }
+    const char *txt; uint64_t tl;
+    t1 = now(); t_wait += t1 - t0; t0 = t1;
+    if (smaltgpu_report_emit(rep, &b.post, &b.raw, &b.v, seqnames, nseq, &ro, nthreads, &txt, &tl)) failure = smaltgpu_last_error();
+    t1 = now(); t_emit += t1 - t0; t0 = t1;
+    if (failure.empty() && tl && fwrite(txt, 1, tl, ou) != tl) failure = "write error";
+    t_write += now() - t0;
+    nreads_total += b.v.nreads;
+    { std::lock_guard<std::mutex> lk(mu); b.state = 0; wk[b.worker].busy = false; n_written = k + 1; if (!failure.empty()) failed = true; cv.notify_all(); }
+    if (!failure.empty()) break;
+  }
+  { std::lock_guard<std::mutex> lk(mu); if (!failure.empty()) failed = true; cv.notify_all(); }
+  parser.join();
+  for (std::thread &t : workers) t.join();
+  if (failed && failure.empty()) for (Block &x : blk) if (!x.err.empty()) failure = x.err;
+  for (Worker &W : wk) { if (W.mp) smaltgpu_mapper_free(W.mp); if (W.post) smaltgpu_post_free(W.post); }
+  for (Block &b : blk) smaltgpu_reads_free(b.rs);
+  smaltgpu_report_free(rep);
+  smaltgpu_index_free(ix);
+  if (ou != stdout) { if (fclose(ou)) failure = "write error"; } else fflush(ou);
+  if (failed || !failure.empty()) die("failed", failure.c_str());
+  if (getenv("SMALTGPU_MAP_VERBOSE")) {
+    const double ti = std::chrono::duration<double>(t_index - t_start).count(), tm = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_index).count();
+    fprintf(stderr, "smaltgpu-map: %llu reads, index load %.3f s, reads in to lines out %.3f s (%.0f reads/s)\n", (unsigned long long)nreads_total, ti, tm,
+            tm > 0 ? (double)nreads_total / tm : 0.0);
+    fprintf(stderr, "smaltgpu-map: stages [s]: parse %.3f | mapper set-up %.3f %.3f  map %.3f %.3f  post %.3f %.3f | wait %.3f emit %.3f write %.3f\n", t_parse, t_create[0],
+            t_create[1], t_map[0], t_map[1], t_post[0], t_post[1], t_wait, t_emit, t_write);
+  }
+  return 0;
+}

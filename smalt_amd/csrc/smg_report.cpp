@@ -1,0 +1,615 @@
+// smg_report.cpp -- SURVEY 8f N4: read ingest (FASTQ / FASTA text -> the batch layout of smaltgpu_map_batch) and report
+// emit (post-processed alignments -> the CIGAR / SAM lines `smalt map` prints) on the host side of libsmaltgpu.
+//
+// Our restatement of what the reference does around the hot path for single reads:
+//   ingest   readHeader / readSeqFast / seqFastqRead   (sequence.c:1056-1140, 1229-1290, 1960-1990): a header is the text
+//            behind the prompt up to the end of the line (the name is its first word), a sequence or quality string is
+//            every non-blank character up to the next prompt at the start of a line (quality: only once as many characters
+//            as the sequence has were read); letters are kept upper case with U -> T, anything else reads as N
+//            (make3BitMangledCodec, sequence.c:287-318)
+//   select   resultSetFilterResults (results.c:2592-2626) and resultSetAddToReport (results.c:2282-2345): output filters,
+//            the choice among several best alignments (-r: drand48, randef.h:19-20), reportAddMap's duplicate test
+//            (report.c:545-578)
+//   print    fprintREPALIcigar / fprintREPALIsam (report.c:711-906), the CIGAR strings of writeDiffStrCIGAR
+//            (diffstr.c:298-363), the SAM header (report.c:1266-1300)
+// Host code only: nothing here touches the device, so the parity tests of this file run without a GPU
+// (tests/test_report.py against output of the reference program committed under tests/golden/).
+#include <ctype.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/smaltgpu.h"
+
+extern "C" int smaltgpu_set_error(int code, const char *msg);   // smaltgpu.cpp: the per-thread message of smaltgpu_last_error()
+
+namespace {
+
+inline bool is_prompt(int c) { return c == '>' || c == '@' || c == '+'; }
+
+// one symbol as the reads' codec stores and prints it (codtab -> decodtab, sequence.c:298-313)
+inline uint8_t canon_base(uint8_t c) {
+  int cu = toupper(c);
+  if (cu == 'U') cu = 'T';
+  const int offs = cu - 'A' + 1;
+  return (offs > 0 && offs < 32) ? (uint8_t)cu : (uint8_t)'N';
+}
+
+struct ReadBlock {                       // what one parser thread produced
+  std::vector<uint8_t> bases, quals;
+  std::vector<uint64_t> off, name_off, rec_end;      // rec_end: offset in the text behind each record
+  std::vector<char> names;
+  bool has_qual = true, fasta_seen = false;
+  void clear() { bases.clear(); quals.clear(); off.assign(1, 0); name_off.assign(1, 0); names.clear(); rec_end.clear(); has_qual = true; fasta_seen = false; }
+};
+
+// ---- the plain four-line FASTQ record, one memchr per line --------------------------------------------------------
+// Returns the number of bytes of the record at p, 0 if the text at p is not such a record (the general parser decides then),
+// or -1 when the record is not complete inside [p, end) (a later chunk holds the rest).
+long strict_record(const char *p, const char *end, bool is_last, ReadBlock &o) {
+  if (p >= end || *p != '@') return 0;
+  const char *l1e = (const char *)memchr(p, '\n', (size_t)(end - p));
+  if (!l1e) return -1;
+  const char *l2 = l1e + 1, *l2e = l2 < end ? (const char *)memchr(l2, '\n', (size_t)(end - l2)) : nullptr;
+  if (!l2e) return -1;
+  const char *l3 = l2e + 1, *l3e = l3 < end ? (const char *)memchr(l3, '\n', (size_t)(end - l3)) : nullptr;
+  if (!l3e) return -1;
+  if (*l3 != '+') return 0;
+  const char *l4 = l3e + 1, *l4e = l4 < end ? (const char *)memchr(l4, '\n', (size_t)(end - l4)) : nullptr;
+  const char *next;
+  if (!l4e) { if (!is_last) return -1; l4e = end; next = end; }
+  else next = l4e + 1;
+  if (next < end) { if (*next != '@') return 0; }       // anything else behind the quality line: the general rules apply
+  else if (!is_last) return -1;                           // the next line decides whether the quality string goes on
+  size_t sl = (size_t)(l2e - l2), ql = (size_t)(l4e - l4);
+  if (sl && l2[sl - 1] == '\r') sl--;
+  if (ql && l4[ql - 1] == '\r') ql--;
+  if (sl != ql || sl == 0) return 0;
+  if (l4[0] == '@' || l4[0] == '>' || l4[0] == '+') { /* a prompt character opens the quality line: only safe because the length matches */ }
+  const char *nm = p + 1, *nme = l1e;
+  while (nm < nme && isspace((unsigned char)*nm)) nm++;
+  const char *t = nm;
+  while (t < nme && !isspace((unsigned char)*t)) t++;
+  const size_t b0 = o.bases.size();
+  o.bases.resize(b0 + sl); o.quals.resize(b0 + sl);
+  for (size_t i = 0; i < sl; i++) {
+    const unsigned char c = (unsigned char)l2[i], q = (unsigned char)l4[i];
+    if (isspace(c) || isspace(q)) { o.bases.resize(b0); o.quals.resize(b0); return 0; }
+    o.bases[b0 + i] = canon_base(c); o.quals[b0 + i] = q;
+  }
+  o.names.insert(o.names.end(), nm, t); o.names.push_back('\0');
+  o.off.push_back(o.bases.size()); o.name_off.push_back(o.names.size());
+  return (long)(next - p);
+}
+
+// ---- the general rules (sequential) ---------------------------------------------------------------------------------
+struct Stream { const char *p, *end; };
+
+// header line: -> 0 ok, 1 end of text before any prompt, -2 not a prompt.  name = first word behind the prompt.
+int read_header(Stream &s, int *prompt, std::string &name, bool *saw_eol) {
+  bool was_space = true, in_name = true, eol = false;
+  *prompt = 0; name.clear();
+  while (s.p < s.end && !eol) {
+    const unsigned char c = (unsigned char)*s.p++;
+    if (was_space) {
+      if (isspace(c)) { eol = (c == '\n' && *prompt); continue; }
+      if (!*prompt) { if (!is_prompt(c)) return -2; *prompt = c; continue; }
+      was_space = false;
+    } else if (isspace(c)) {
+      if (c == '\n' && *prompt) { eol = true; continue; }
+      was_space = true;
+      in_name = false;
+      continue;
+    }
+    if (in_name) name.push_back((char)c);                // later words of the header are not used
+  }
+  *saw_eol = eol;
+  if (!*prompt) return 1;
+  return 0;
+}
+
+// sequence or quality characters up to the next prompt at the start of a line (left in place); minlen as in readSeqFast
+void read_symbols(Stream &s, std::vector<uint8_t> &out, size_t minlen, int *prompt, bool bases) {
+  bool was_newline = false;
+  size_t n = 0;
+  *prompt = 0;
+  while (s.p < s.end) {
+    const unsigned char c = (unsigned char)*s.p;
+    if (isspace(c)) { was_newline = (c == '\n'); s.p++; continue; }
+    if (was_newline) {
+      if (n >= minlen && is_prompt(c)) { *prompt = c; return; }
+      was_newline = false;
+    }
+    out.push_back(bases ? canon_base(c) : c);
+    n++; s.p++;
+  }
+}
+
+// -> 0, or -1 with msg.  Stops (without consuming) at a record that may go on behind `end` unless is_last.
+int general_parse(const char *text, const char *end, bool is_last, uint32_t max_reads, ReadBlock &o, std::string &msg, bool *reached_end) {
+  Stream s{text, end};
+  std::string name;
+  while (s.p < s.end && (!max_reads || o.off.size() - 1 < max_reads)) {
+    const char *rec0 = s.p;
+    const size_t b0 = o.bases.size(), n0 = o.names.size();
+    int this_prompt = '+', next_prompt = 0;
+    bool eol = false, eof = false;
+    while (this_prompt == '+') {                               // seqFastqRead skips stray quality blocks (sequence.c:1968-1977)
+      const int rv = read_header(s, &this_prompt, name, &eol);
+      if (rv == 1) { eof = true; break; }
+      if (rv < 0) { msg = "not in FASTA/FASTQ format (a header line was expected)"; return -1; }
+      o.bases.resize(b0);
+      read_symbols(s, o.bases, 0, &next_prompt, true);
+    }
+    if (eof) { o.bases.resize(b0); break; }
+    bool fastq = false;
+    if (next_prompt == '+') {
+      int qp = 0;
+      std::string qname;
+      std::vector<uint8_t> q;
+      const int rv = read_header(s, &qp, qname, &eol);
+      if (rv || qp != '+') { msg = "not in FASTA/FASTQ format (quality header)"; return -1; }
+      int p2 = 0;
+      read_symbols(s, q, o.bases.size() - b0, &p2, false);
+      if (!p2 && !is_last) { o.bases.resize(b0); o.names.resize(n0); s.p = rec0; break; }     // may go on in the next chunk
+      if (q.size() != o.bases.size() - b0) { msg = "sequence and quality string differ in length (read '" + name + "')"; return -1; }
+      if (o.has_qual) { o.quals.resize(b0); o.quals.insert(o.quals.end(), q.begin(), q.end()); }
+      fastq = true;
+    } else if (!next_prompt && !is_last) { o.bases.resize(b0); o.names.resize(n0); s.p = rec0; break; }
+    if (!fastq) { o.has_qual = false; o.fasta_seen = true; }
+    o.names.insert(o.names.end(), name.begin(), name.end()); o.names.push_back('\0');
+    o.off.push_back(o.bases.size()); o.name_off.push_back(o.names.size());
+    o.rec_end.push_back((uint64_t)(s.p - text));
+  }
+  if (!o.has_qual) o.quals.clear();
+  *reached_end = s.p >= s.end;
+  return 0;
+}
+
+inline bool only_blank(const char *p, const char *end) { for (; p < end; p++) if (!isspace((unsigned char)*p)) return false; return true; }
+
+}  // namespace
+
+struct smaltgpu_reads {
+  ReadBlock all;
+  std::vector<ReadBlock> part;
+};
+
+extern "C" smaltgpu_reads *smaltgpu_reads_create(void) { smaltgpu_reads *r = new smaltgpu_reads(); r->all.clear(); return r; }
+extern "C" void smaltgpu_reads_free(smaltgpu_reads *r) { delete r; }
+
+extern "C" int smaltgpu_reads_parse(smaltgpu_reads *rs, const char *text, uint64_t len, int is_last, uint32_t max_reads, int nthreads,
+                                    smaltgpu_reads_view *view) {
+  if (!rs || !view || (!text && len)) return smaltgpu_set_error(SMALTGPU_EARG, "null argument");
+  memset(view, 0, sizeof(*view));
+  const char *end = text + len;
+  ReadBlock &A = rs->all;
+  A.clear();
+  if (nthreads < 1) nthreads = 1;
+  if ((uint64_t)nthreads > len / (1u << 20) + 1) nthreads = (int)(len / (1u << 20) + 1);
+  // plain four-line FASTQ: byte ranges in parallel, each from the first record that starts in it
+  std::vector<const char *> start((size_t)nthreads + 1, end);
+  start[0] = text;
+  bool strict = len > 0 && text[0] == '@';
+  const char *stop_last = nullptr;
+  for (int t = 1; t < nthreads && strict; t++) {
+    const char *p = text + len * (uint64_t)t / (uint64_t)nthreads;
+    if (p < start[t - 1]) p = start[t - 1];
+    const char *found = nullptr;
+    // a record starts at a line that opens with '@' whose next-but-one line opens with '+' and whose sequence and quality
+    // lines have the same length (a quality line may open with '@' too, but the line two below it is then a sequence)
+    for (int tries = 0; tries < 64 && p < end; tries++) {
+      const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+      if (!nl) break;
+      const char *l = nl + 1;
+      if (l < end && *l == '@') {
+        ReadBlock probe; probe.clear();
+        const long n = strict_record(l, end, is_last != 0, probe);
+        if (n > 0 || n < 0) { found = l; break; }
+      }
+      p = l;
+    }
+    if (!found) { strict = false; break; }
+    start[t] = found;
+  }
+  if (strict) {
+    rs->part.resize((size_t)nthreads);
+    std::vector<int> bad((size_t)nthreads, 0);
+    std::vector<const char *> stop((size_t)nthreads, nullptr);
+    auto work = [&](int t) {
+      ReadBlock &o = rs->part[(size_t)t];
+      o.clear();
+      const char *p = start[t], *lim = start[t + 1];
+      while (p < lim) {
+        const long n = strict_record(p, end, is_last != 0, o);
+        if (n == 0 && lim == end && only_blank(p, end)) { p = end; break; }      // blank lines behind the last record
+        if (n == 0) { bad[(size_t)t] = 1; break; }
+        if (n < 0) break;                                  // incomplete: only at the end of the text
+        p += n;
+        o.rec_end.push_back((uint64_t)(p - text));
+      }
+      stop[(size_t)t] = p;
+    };
+    if (nthreads == 1) work(0);
+    else { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t); for (auto &x : th) x.join(); }
+    for (int t = 0; t < nthreads && strict; t++) {
+      if (bad[(size_t)t]) strict = false;
+      else if (t + 1 < nthreads && stop[(size_t)t] != start[t + 1]) strict = false;      // a range must end where the next one starts
+    }
+    if (strict) {
+      stop_last = stop[(size_t)nthreads - 1];
+      for (int t = 0; t < nthreads; t++) {
+        const ReadBlock &o = rs->part[(size_t)t];
+        const uint64_t b0 = A.bases.size(), n0 = A.names.size();
+        A.bases.insert(A.bases.end(), o.bases.begin(), o.bases.end());
+        A.quals.insert(A.quals.end(), o.quals.begin(), o.quals.end());
+        A.names.insert(A.names.end(), o.names.begin(), o.names.end());
+        for (size_t i = 1; i < o.off.size(); i++) { A.off.push_back(b0 + o.off[i]); A.name_off.push_back(n0 + o.name_off[i]); }
+        A.rec_end.insert(A.rec_end.end(), o.rec_end.begin(), o.rec_end.end());
+      }
+    }
+  }
+  bool reached_end = strict && stop_last == end;
+  if (!strict) {
+    A.clear();
+    std::string msg;
+    if (general_parse(text, end, is_last != 0, max_reads, A, msg, &reached_end)) return smaltgpu_set_error(SMALTGPU_EFILE, msg.c_str());
+  }
+  size_t n = A.off.size() - 1;
+  if (max_reads && n > max_reads) {
+    reached_end = false;
+    n = max_reads;
+    A.off.resize(n + 1); A.name_off.resize(n + 1); A.rec_end.resize(n);
+    A.bases.resize(A.off[n]); if (A.has_qual) A.quals.resize(A.off[n]); A.names.resize(A.name_off[n]);
+  }
+  if (A.bases.empty()) A.bases.push_back(0);
+  if (A.names.empty()) A.names.push_back(0);
+  view->nreads = (uint32_t)n;
+  view->has_qual = (A.has_qual && n) ? 1u : 0u;
+  view->bases = A.bases.data();
+  view->quals = view->has_qual ? A.quals.data() : nullptr;
+  view->read_off = A.off.data();
+  view->names = A.names.data();
+  view->name_off = A.name_off.data();
+  view->consumed = (is_last && reached_end) ? len : (n ? A.rec_end[n - 1] : 0);
+  return SMALTGPU_OK;
+}
+
+// =====================================================================================================================
+// report
+// =====================================================================================================================
+namespace {
+
+enum : uint32_t { RF_SELECT = 0x01, RF_REVERSE = 0x04, RF_NOOUTPUT = 0x10, RF_BELOWRELSW = 0x20, RF_REPORTED = 0x200 };   // results.h:67-82
+enum : uint32_t { MF_MAPPED = 0x01, MF_REVERSE = 0x02, MF_2NDMATE = 0x08, MF_PRIMARY = 0x10, MF_PARTIAL = 0x20, MF_MULTI = 0x40 };   // report.h:66-74
+enum { MAPSCOR_MAX_RANDOM = 3, SAMPLESIZ_MAPQ_RANDOM = 9, QUALSCOR_SCAL = 10, CIGAR_MAXTAG = 99 };   // results.c:57,73,80; report.c:73
+
+struct Ali {                              // REPALI (report.c:130-145)
+  uint32_t status;
+  int swatscor, mapscor;
+  uint32_t qs, qe;
+  uint64_t ss, se;
+  int32_t sidx;
+  const uint8_t *dstr;
+};
+
+inline void dget(uint8_t b, unsigned *count, unsigned *typ) { *count = b & 0x3f; *typ = b >> 6; }   // diffstr.h:28-76: 0 M, 1 D, 2 I, 3 S
+
+int diff_matches(const uint8_t *d) {                       // diffStrCalcAliLen's match count (diffstr.c:932-952)
+  int m = 0;
+  for (; *d; d++) { unsigned c, t; dget(*d, &c, &t); m += (int)c + (t == 0 ? 1 : 0); }
+  return m;
+}
+
+int diff_edit_distance(const uint8_t *d) {                 // diffStrGetLevenshteinDistance (diffstr.c:1496-1510)
+  int ed = 0;
+  unsigned t = 0, c;
+  for (; *d; d++) { dget(*d, &c, &t); if (t != 0) ed++; }
+  if (ed > 0 && t == 3) ed--;
+  return ed;
+}
+
+// writeDiffStrCIGAR (diffstr.c:298-363).  ext: "<n><op>" units with clipping, else "<op> <n> " units; silent: mismatches
+// count as matches ('M') instead of 'X'.  A run of matches absorbs the matches in front of the next operation; equal gap
+// operations that follow each other directly are counted together; the string ends with the terminating S.
+bool put_cigar(std::string &o, const uint8_t *d, bool ext, bool silent, int clip_start, int clip_end, char clipchar) {
+  static const char SYM[] = "MDIX";
+  char buf[32];
+  auto unit = [&](char ch, unsigned n) {
+    if (n > 0) { if (ext) snprintf(buf, sizeof(buf), "%d%c", (int)n, ch); else snprintf(buf, sizeof(buf), "%c %d ", ch, (int)n); o += buf; }
+    else o.push_back(ch);
+  };
+  if (!d) { unit('*', 0); return true; }
+  if (!*d) return false;
+  if (clip_start > 0 && ext) unit(clipchar, (unsigned)clip_start);
+  unsigned run = 0, run_typ = 0, typ = 0, count;
+  for (; *d; d++) {
+    dget(*d, &count, &typ);
+    const bool like_match = typ == 0 || (typ == 3 && silent);
+    if (run_typ == 0) {
+      run += count;
+      if (like_match) { run++; continue; }
+    } else if (typ == run_typ && count < 1) { run++; continue; }
+    if (run > 0) unit(SYM[run_typ], run);
+    if (like_match) { run = count + 1; run_typ = 0; }
+    else {
+      if (count > 0 && run_typ != 0) unit('M', count);
+      run = 1; run_typ = typ;
+    }
+  }
+  if (typ != 3) return false;
+  if (run > 1) unit(silent ? 'M' : 'X', run - 1);
+  if (clip_end > 0 && ext) unit(clipchar, (unsigned)clip_end);
+  return true;
+}
+
+inline void first_word(std::string &o, const char *s, bool strip_mate) {        // copyReadNamStrToREPSTR (report.c:434-461)
+  const size_t b = o.size();
+  while (*s && !isspace((unsigned char)*s)) o.push_back(*s++);
+  const size_t n = o.size() - b;
+  if (strip_mate && n > 2 && o[o.size() - 2] == '/' && (o.back() == '1' || o.back() == '2')) o.resize(o.size() - 2);
+}
+
+int mapq_of_random_draw(int n) {                            // assignPhredScaledMappingScoreToRandomDraw (results.c:214-230)
+  if (n < 1 || n > SAMPLESIZ_MAPQ_RANDOM) return 0;
+  if (n == 1) return MAPSCOR_MAX_RANDOM + 1;
+  int q = (int)(-QUALSCOR_SCAL * log10(((double)(n - 1)) / n) + .499);
+  if (q > MAPSCOR_MAX_RANDOM) q = MAPSCOR_MAX_RANDOM;
+  else if (q < 0) q = 0;
+  return q;
+}
+
+struct ReadCtx {
+  const smaltgpu_post_out *po;
+  const smaltgpu_reads_view *rv;
+  const smaltgpu_report_opts *op;
+  const char *const *seqnames;
+  int64_t nseq;
+};
+
+// the alignments of read i in the order the reference's report holds them; draw: the pre-drawn index for a random choice
+// among equal best alignments (-1: no draw was due).  -> false on an inconsistency
+bool select_read(const ReadCtx &cx, uint32_t i, int draw, std::vector<Ali> &out, std::vector<uint32_t> &st) {
+  const smaltgpu_post_out &po = *cx.po;
+  const smaltgpu_report_opts &op = *cx.op;
+  const smaltgpu_post_result *res = po.res + po.res_off[i];
+  const int32_t *sortr = po.sortr + po.sort_off[i];
+  const int n = (int)(po.sort_off[i + 1] - po.sort_off[i]);
+  const uint32_t nres = (uint32_t)(po.res_off[i + 1] - po.res_off[i]);
+  const uint32_t rlen = (uint32_t)(cx.rv->read_off[i + 1] - cx.rv->read_off[i]);
+  out.clear();
+  st.assign(nres, 0);
+  for (uint32_t j = 0; j < nres; j++) st[j] = res[j].status;
+  // resultSetFilterResults (results.c:2592-2626)
+  if (n > 0) {
+    const double idt = op.min_identity <= 1.0 ? op.min_identity * rlen : op.min_identity;
+    const int minid = (int)(uint32_t)idt;
+    const int maxsw = res[sortr[0]].swatscor, minabs = op.min_swscor;
+    int minrel = 0;
+    if (op.min_swscor_below_max >= 0 && minabs + op.min_swscor_below_max < maxsw) minrel = maxsw - op.min_swscor_below_max;
+    for (int k = 0; k < n; k++) {
+      const smaltgpu_post_result &r = res[sortr[k]];
+      if (r.swatscor < minabs || diff_matches(po.diffstr + r.stroffs) < minid) st[(size_t)sortr[k]] |= RF_NOOUTPUT;
+      else if (r.swatscor < minrel) st[(size_t)sortr[k]] |= RF_BELOWRELSW;
+    }
+  }
+  auto add = [&](int ridx, int mapscor_override, uint32_t mateflg) {     // resultSetAddResultToReport + reportAddMap for a single read
+    Ali a;
+    memset(&a, 0, sizeof(a));
+    if (ridx < 0 || (st[(size_t)ridx] & RF_NOOUTPUT) || res[ridx].strlen < 1) a.status = mateflg & ~(uint32_t)MF_MAPPED;
+    else {
+      const smaltgpu_post_result &r = res[ridx];
+      a.status = mateflg | MF_MAPPED | ((st[(size_t)ridx] & RF_REVERSE) ? (uint32_t)MF_REVERSE : 0u);
+      a.swatscor = r.swatscor; a.mapscor = mapscor_override >= 0 ? mapscor_override : r.mapscor;
+      a.qs = r.q_start; a.qe = r.q_end; a.ss = r.s_start; a.se = r.s_end; a.sidx = r.sidx; a.dstr = po.diffstr + r.stroffs;
+    }
+    for (size_t k = out.size(); k-- > 0;) {                              // findREPALI (report.c:545-578): known already -> ignored
+      const Ali &b = out[k];
+      if (a.ss == b.ss && a.se == b.se && a.sidx == b.sidx && a.qs == b.qs && a.qe == b.qe &&
+          (a.status & (MF_REVERSE | MF_2NDMATE)) == (b.status & (MF_REVERSE | MF_2NDMATE))) return;
+    }
+    out.push_back(a);
+  };
+  // resultSetAddToReport (results.c:2282-2345)
+  int top = n < 1 ? -1 : sortr[0], top_mapscor = -1;
+  uint32_t mateflg = 0;
+  if (top >= 0) {
+    // getNumberOfTopSwatRESULTs (results.c:839-869)
+    const bool is_single = n < 2 || res[sortr[1]].swatscor != res[sortr[0]].swatscor;
+    int ns = n;
+    if (n > 2) { const int thr = res[sortr[1]].swatscor; int k = 2; while (k < n && res[sortr[k]].swatscor == thr) k++; ns = k; }
+    if (res[top].mapscor == 0 && !is_single && ns > 1 && (op.outflags & SMALTGPU_OUT_BEST)) {
+      mateflg |= MF_MULTI;
+      if (op.outflags & SMALTGPU_OUT_RANDSEL) {
+        if (draw < 0 || draw >= n) return false;
+        top = sortr[draw];
+        top_mapscor = mapq_of_random_draw(ns);
+      } else if (op.outflags & SMALTGPU_OUT_SINGLE) top = -1;
+    }
+  }
+  add(top, top_mapscor, mateflg | MF_PRIMARY);
+  if (top >= 0) st[(size_t)top] |= RF_REPORTED;
+  if (op.outflags & SMALTGPU_OUT_SINGLE) return true;
+  for (int k = 1; k < n; k++) {
+    const int r = sortr[k];
+    if ((op.outflags & SMALTGPU_OUT_BEST) && res[r].swatscor < res[sortr[k - 1]].swatscor) break;
+    if (!(st[(size_t)r] & (RF_NOOUTPUT | RF_BELOWRELSW))) { add(r, (r == top) ? top_mapscor : -1, mateflg); st[(size_t)r] |= RF_REPORTED; }
+  }
+  return true;
+}
+
+// does read i need a random draw, and among how many (resultSetAddToReport, results.c:2293-2301)
+int draw_range(const ReadCtx &cx, uint32_t i) {
+  const smaltgpu_post_out &po = *cx.po;
+  const smaltgpu_report_opts &op = *cx.op;
+  if (!(op.outflags & SMALTGPU_OUT_RANDSEL) || !(op.outflags & SMALTGPU_OUT_BEST)) return 0;
+  const smaltgpu_post_result *res = po.res + po.res_off[i];
+  const int32_t *sortr = po.sortr + po.sort_off[i];
+  const int n = (int)(po.sort_off[i + 1] - po.sort_off[i]);
+  if (n < 2 || res[sortr[1]].swatscor != res[sortr[0]].swatscor || res[sortr[0]].mapscor != 0) return 0;
+  int ns = n;
+  if (n > 2) { const int thr = res[sortr[1]].swatscor; int k = 2; while (k < n && res[sortr[k]].swatscor == thr) k++; ns = k; }
+  return ns > 1 ? ns : 0;
+}
+
+bool print_cigar_line(std::string &o, const ReadCtx &cx, uint32_t i, const Ali &a) {      // fprintREPALIcigar (report.c:711-760)
+  char buf[96];
+  const bool mapped = (a.status & MF_MAPPED) != 0;
+  char flagchr;
+  if (mapped) flagchr = (a.status & MF_PARTIAL) ? 'P' : 'S';              // getMapLabelFromFlag (report.c:217-246), no pair flags
+  else flagchr = (a.status & MF_MULTI) ? 'R' : 'N';
+  const int mq = mapped ? (a.mapscor > CIGAR_MAXTAG ? CIGAR_MAXTAG : a.mapscor) : 0;
+  snprintf(buf, sizeof(buf), "cigar:%c:%2.2d ", flagchr, mq);
+  o += buf;
+  first_word(o, cx.rv->names + cx.rv->name_off[i], false);
+  uint32_t qs = 0, qe = 0;
+  char sense = '*';
+  if (mapped) { if (a.status & MF_REVERSE) { qs = a.qe; qe = a.qs; sense = '-'; } else { qs = a.qs; qe = a.qe; sense = '+'; } }
+  snprintf(buf, sizeof(buf), " %u %u %c ", qs, qe, sense);
+  o += buf;
+  if (mapped) { if (a.sidx < 0 || a.sidx >= cx.nseq) return false; first_word(o, cx.seqnames[a.sidx], false); }
+  else o.push_back('*');
+  snprintf(buf, sizeof(buf), " %u %u + %d ", mapped ? (unsigned)a.ss : 0u, mapped ? (unsigned)a.se : 0u, mapped ? a.swatscor : 0);
+  o += buf;
+  if (!put_cigar(o, mapped ? a.dstr : nullptr, false, true, 0, 0, 'H')) return false;
+  o.push_back('\n');
+  return true;
+}
+
+bool print_sam_line(std::string &o, const ReadCtx &cx, uint32_t i, const Ali &a) {        // fprintREPALIsam (report.c:762-906), single reads
+  char buf[96];
+  const smaltgpu_report_opts &op = *cx.op;
+  const bool mapped = (a.status & MF_MAPPED) != 0, soft = (op.modflags & SMALTGPU_REP_SOFTCLIP) != 0;
+  const uint64_t r0 = cx.rv->read_off[i];
+  const uint32_t qlen = (uint32_t)(cx.rv->read_off[i + 1] - r0);
+  const uint8_t *seq = cx.rv->bases + r0, *qual = cx.rv->has_qual ? cx.rv->quals + r0 : nullptr;
+  unsigned flag = 0;
+  first_word(o, cx.rv->names + cx.rv->name_off[i], true);
+  int clip_start = 0, clip_end = 0;
+  uint32_t seg0 = 0, segn = 0;
+  bool rev = false;
+  if (mapped) {
+    rev = (a.status & MF_REVERSE) != 0;
+    if (soft) { seg0 = 0; segn = qlen; } else { seg0 = a.qs - 1; segn = a.qe - a.qs + 1; }
+    if (a.qe > qlen || seg0 > qlen) return false;
+    if (!segn || seg0 + segn > qlen) segn = qlen - seg0;                 // appendSeqSegment (sequence.c:865-867)
+    if (rev) { flag |= 0x10; clip_start = (int)(qlen - a.qe); clip_end = (int)a.qs - 1; }
+    else { clip_start = (int)a.qs - 1; clip_end = (int)(qlen - a.qe); }
+    if (a.status & MF_PARTIAL) flag |= 0x100;
+  } else flag |= 0x4;
+  snprintf(buf, sizeof(buf), "\t%hu\t", (unsigned short)flag);
+  o += buf;
+  if (mapped) { if (a.sidx < 0 || a.sidx >= cx.nseq) return false; first_word(o, cx.seqnames[a.sidx], false); }
+  else o.push_back('*');
+  snprintf(buf, sizeof(buf), "\t%i\t%hi\t", mapped ? (int)(uint32_t)a.ss : 0, (short)(mapped ? a.mapscor : 0));
+  o += buf;
+  int nm = 0;
+  if (mapped) {
+    if (!put_cigar(o, a.dstr, true, !(op.modflags & SMALTGPU_REP_XMISMATCH), clip_start, clip_end, soft ? 'S' : 'H')) return false;
+    nm = diff_edit_distance(a.dstr);
+  } else o.push_back('*');
+  o += "\t*\t0\t0\t";
+  if (mapped || soft) {
+    if (!mapped) { seg0 = 0; segn = qlen; }
+    const size_t b = o.size();
+    o.resize(b + segn);
+    if (rev) {
+      // reverse complement: the four standard letters are complemented, any other letter stays (appendSeqSegment, sequence.c:881-893)
+      for (uint32_t k = 0; k < segn; k++) {
+        const uint8_t c = seq[seg0 + segn - 1 - k];
+        o[b + k] = (char)(c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c);
+      }
+    } else memcpy(&o[b], seq + seg0, segn);
+    o.push_back('\t');
+    if (qual && segn) {
+      const size_t q = o.size();
+      o.resize(q + segn);
+      if (rev) for (uint32_t k = 0; k < segn; k++) o[q + k] = (char)qual[seg0 + segn - 1 - k];
+      else memcpy(&o[q], qual + seg0, segn);
+    } else o.push_back('*');
+  } else o += "*\t*";
+  snprintf(buf, sizeof(buf), "\tNM:i:%i\tAS:i:%i\n", nm, mapped ? a.swatscor : 0);
+  o += buf;
+  return true;
+}
+
+}  // namespace
+
+struct smaltgpu_report { std::string text; std::vector<std::string> part; std::vector<int> draw; };
+
+extern "C" smaltgpu_report *smaltgpu_report_create(void) { return new smaltgpu_report(); }
+extern "C" void smaltgpu_report_free(smaltgpu_report *r) { delete r; }
+
+extern "C" int smaltgpu_report_header(smaltgpu_report *rp, const char *const *seqnames, const uint64_t *sop, int64_t nseq, const smaltgpu_report_opts *op,
+                                      const char *prognam, const char *version, int argc, const char *const *argv, const char **text, uint64_t *len) {
+  if (!rp || !seqnames || !sop || !op || !text || !len || nseq < 1) return smaltgpu_set_error(SMALTGPU_EARG, "null argument");
+  std::string &o = rp->text;
+  o.clear();
+  if (op->format == SMALTGPU_FMT_SAM && (op->modflags & SMALTGPU_REP_HEADER)) {       // writeSAMHeaderf (report.c:1266-1300)
+    char buf[64];
+    o += "@HD\tVN:1.3\tSO:unknown\n";
+    for (int64_t s = 0; s < nseq; s++) {
+      o += "@SQ\tSN:";
+      const char *n = seqnames[s];
+      for (int k = 0; k < 511 && n[k] && !isspace((unsigned char)n[k]); k++) o.push_back(n[k]);
+      snprintf(buf, sizeof(buf), "\tLN:%u\n", (unsigned)(sop[s + 1] - sop[s]));
+      o += buf;
+    }
+    o += "@PG\tID:"; o += prognam ? prognam : "smaltgpu"; o += "\tPN:"; o += prognam ? prognam : "smaltgpu"; o += "\tVN:"; o += version ? version : "0"; o += "\tCL:";
+    if (argc > 0 && argv) { for (int k = 0; k < argc; k++) { if (k) o.push_back(' '); o += argv[k]; } o.push_back('\n'); }
+  }
+  *text = o.data(); *len = o.size();
+  return SMALTGPU_OK;
+}
+
+extern "C" int smaltgpu_report_emit(smaltgpu_report *rp, const smaltgpu_post_out *post, const smaltgpu_batch_out *raw, const smaltgpu_reads_view *reads,
+                                    const char *const *seqnames, int64_t nseq, const smaltgpu_report_opts *op, int nthreads, const char **text, uint64_t *len) {
+  if (!rp || !post || !reads || !seqnames || !op || !text || !len) return smaltgpu_set_error(SMALTGPU_EARG, "null argument");
+  if (post->nreads != reads->nreads) return smaltgpu_set_error(SMALTGPU_EARG, "results and reads differ in number");
+  if (op->format != SMALTGPU_FMT_CIGAR && op->format != SMALTGPU_FMT_SAM) return smaltgpu_set_error(SMALTGPU_EARG, "unknown output format");
+  const uint32_t n = post->nreads;
+  ReadCtx cx{post, reads, op, seqnames, nseq};
+  for (uint32_t i = 0; i < n; i++) {
+    if (post->needs_reference[i]) return smaltgpu_set_error(SMALTGPU_EARG, "a read was left to the caller by smaltgpu_postprocess (needs_reference): give it the packed reference");
+    if (raw && raw->stat[i].errcode) { char m[96]; snprintf(m, sizeof(m), "read %u carries error code %d", i, raw->stat[i].errcode); return smaltgpu_set_error(SMALTGPU_EINTERNAL, m); }
+  }
+  // the random choices in read order, as one thread of the reference makes them (drand48 is the C library's shared sequence)
+  rp->draw.assign(n ? n : 1, -1);
+  for (uint32_t i = 0; i < n; i++) { const int ns = draw_range(cx, i); if (ns) rp->draw[i] = (int)(short)(drand48() * ns); }
+  if (nthreads < 1) nthreads = 1;
+  if ((uint32_t)nthreads > n / 512 + 1) nthreads = (int)(n / 512 + 1);
+  rp->part.resize((size_t)nthreads);
+  std::vector<int> bad((size_t)nthreads, -1);
+  auto work = [&](int t) {
+    std::string &o = rp->part[(size_t)t];
+    o.clear();
+    std::vector<Ali> alis;
+    std::vector<uint32_t> st;
+    const uint32_t lo = (uint32_t)((uint64_t)n * (uint64_t)t / (uint64_t)nthreads), hi = (uint32_t)((uint64_t)n * (uint64_t)(t + 1) / (uint64_t)nthreads);
+    o.reserve((size_t)(hi - lo) * (op->format == SMALTGPU_FMT_SAM ? 420 : 96));
+    for (uint32_t i = lo; i < hi; i++) {
+      if (!select_read(cx, i, rp->draw[i], alis, st)) { bad[(size_t)t] = (int)i; return; }
+      for (const Ali &a : alis) {
+        const bool ok = op->format == SMALTGPU_FMT_SAM ? print_sam_line(o, cx, i, a) : print_cigar_line(o, cx, i, a);
+        if (!ok) { bad[(size_t)t] = (int)i; return; }
+      }
+    }
+  };
+  if (nthreads == 1) work(0);
+  else { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t); for (auto &x : th) x.join(); }
+  for (int t = 0; t < nthreads; t++) if (bad[(size_t)t] >= 0) { char m[96]; snprintf(m, sizeof(m), "inconsistent alignment of read %d (alignment string or sequence number)", bad[(size_t)t]); return smaltgpu_set_error(SMALTGPU_EINTERNAL, m); }
+  if (nthreads == 1) { *text = rp->part[0].data(); *len = rp->part[0].size(); return SMALTGPU_OK; }
+  rp->text.clear();
+  size_t tot = 0;
+  for (const std::string &s : rp->part) tot += s.size();
+  rp->text.reserve(tot);
+  for (const std::string &s : rp->part) rp->text += s;
+  *text = rp->text.data(); *len = rp->text.size();
+  return SMALTGPU_OK;
+}

@@ -36,6 +36,9 @@ CONFIGS = [
     # >= 512 reference sequences: concatenated mode (assignSequenceIndex places the alignments, results.c:1695)
     # (post_only: in this mode the reference's RS lines show the alignments AFTER assignSequenceIndex, the stage dumps of the
     #  path show them before -- the fixture serves tests/test_postprocess.py, which is about exactly that step)
+    # exact repeat copies (equal best alignments: the choice among them, reads reported for multiple placements) and reads of
+    # random bases (unmapped) -- for the report tests (tests/test_report.py)
+    dict(tag="g_k13s6_ties", nchr=2, chrlen=80000, k=13, s=6, nreads=220, rlen=100, rep=0.3, opts="", div=0.0, junk=0.08),
     dict(tag="g_k11s4_cat", nchr=600, chrlen=1500, k=11, s=4, nreads=200, rlen=100, rep=0.0, opts="-d -1", qualmix=True, post_only=True, junction=0.3),
 ]
 
@@ -48,7 +51,8 @@ def make(cfg, tmp):
     tag = cfg["tag"]
     seed = int(hashlib.md5(tag.encode()).hexdigest()[:6], 16)
     rng = np.random.default_rng(seed + 77)
-    ch = synth.make_reference(cfg["nchr"], cfg["chrlen"], seed=seed, repeat_frac=cfg["rep"], n_fam=5, cons_len=300)
+    extra = {"divergence": cfg["div"]} if "div" in cfg else {}
+    ch = synth.make_reference(cfg["nchr"], cfg["chrlen"], seed=seed, repeat_frac=cfg["rep"], n_fam=5, cons_len=300, **extra)
     fa = os.path.join(tmp, tag + ".fa")
     fq = os.path.join(tmp, tag + ".fq")
     synth.write_fasta(fa, ch)
@@ -73,6 +77,10 @@ def make(cfg, tmp):
                     p_ = min(len(r) - 2, max(1, cut + int(rng.integers(-6, 7))))
                     r = np.concatenate([r[:p_], r[p_ + 1:], rng.integers(0, 4, size=1, dtype=np.uint8)])
                 reads[i] = synth.revcomp_codes(r) if rng.random() < 0.5 else r
+    if cfg.get("junk"):                 # reads that are not from the reference
+        for i in range(len(reads)):
+            if rng.random() < cfg["junk"]:
+                reads[i] = rng.integers(0, 4, size=cfg["rlen"], dtype=np.uint8)
     with open(fq, "wb") as f:
         for i, r in enumerate(reads):
             b = bytearray(synth.codes_to_ascii(r))

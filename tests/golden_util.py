@@ -63,3 +63,28 @@ def unpack(entry, tmpdir):
 
 def md5(path):
     return hashlib.md5(open(path, "rb").read()).hexdigest()
+
+
+def reshape_reads(fq_path, style, out_path):
+    """The reads of a FASTQ fixture in another legal spelling (for the ingest tests):
+    'wrapped' = FASTQ with header comments, tabs, sequence and quality lines wrapped at 60, lower-case bases, blank lines and
+    CRLF line ends here and there; 'fasta' = FASTA wrapped at 70 without qualities."""
+    recs = read_fastq(fq_path)
+    with open(out_path, "wb") as f:
+        for i, (nm, sq, ql) in enumerate(recs):
+            eol = b"\r\n" if i % 3 == 1 else b"\n"
+            if style == "fasta":
+                f.write(b">" + nm.encode() + b" len=%d" % len(sq) + eol)
+                for o in range(0, len(sq), 70):
+                    f.write(sq[o:o + 70] + eol)
+            else:
+                f.write(b"@" + (b"  " if i % 4 == 2 else b"") + nm.encode() + b"\tcomment %d  x" % i + eol)
+                body = sq.lower() if i % 5 == 0 else sq
+                for o in range(0, len(sq), 60):
+                    f.write(body[o:o + 60] + eol)
+                f.write(b"+" + (nm.encode() if i % 2 else b"") + eol)
+                for o in range(0, len(ql), 60):
+                    f.write(ql[o:o + 60] + eol)
+                if i % 7 == 3:
+                    f.write(eol)
+    return out_path

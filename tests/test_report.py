@@ -1,0 +1,140 @@
+"""Read ingest and report emit of libsmaltgpu against the reference program: the committed
+`<tag>.<variant>.out.gz` files are what `smalt map` (oracle/_ref/smalt) printed for the golden inputs with the options of
+tests/golden/manifest_report.json (tests/golden/make_golden_report.py).  Host code, no GPU needed: the raw alignments of the
+`*.post.txt.gz` fixtures (what the GPU path delivers, test_postprocess.py) go through smaltgpu_postprocess and
+smaltgpu_report_emit, the reads through smaltgpu_reads_parse; the text must equal the reference's line for line -- CIGAR and SAM
+lines, soft and hard clipping, X operations, mapping qualities, the random choice among equal best alignments (-r <seed>:
+drand48 in read order), reads reported unmapped for multiple placements (-r -1), output filters (-m, -y), SAM header."""
+import ctypes as C
+import gzip
+import json
+import os
+
+import pytest
+
+import golden_util as gu
+from test_postprocess import _blocks
+
+REPORT_ALL = json.load(open(os.path.join(gu.GOLD, "manifest_report.json")))
+REPORT = [c for c in REPORT_ALL if not c.get("remap")]       # remap: the options change the mapping itself (tests/test_gpu_report.py)
+
+
+def report_opts(api, opts):
+    """command line of `smalt map` -> smaltgpu_report_opts + seed, as smaltgpu-map derives them (smalt.c:209-245, 490-503)"""
+    ro = api.ReportOpts()
+    o = {}
+    it = iter([x for x in opts if x != "-x"])
+    for k in it:
+        o[k] = next(it)
+    fmt = o.get("-f", "cigar")
+    key, _, mods = fmt.partition(":")
+    if key == "cigar":
+        ro.format = api.FMT_CIGAR
+    else:
+        ro.format = api.FMT_SAM
+        ro.modflags = api.REP_HEADER | api.REP_SOFTCLIP
+        for m in [x for x in mods.split(",") if x]:
+            if m == "nohead":
+                ro.modflags &= ~api.REP_HEADER
+            elif m == "clip":
+                ro.modflags &= ~api.REP_SOFTCLIP
+            elif m == "x":
+                ro.modflags |= api.REP_XMISMATCH
+    d = int(o.get("-d", 0))
+    seed = int(o.get("-r", 0))
+    ro.min_swscor = int(o["-m"]) if "-m" in o else 18
+    ro.min_swscor_below_max = d
+    ro.min_identity = float(o.get("-y", 0.0))
+    if d == 0:
+        ro.outflags |= api.OUT_BEST
+        if "-d" not in o:
+            ro.outflags |= api.OUT_SINGLE
+            if seed >= 0:
+                ro.outflags |= api.OUT_RANDSEL
+    return ro, seed
+
+
+def raw_batch(api, blocks, view):
+    """BatchOut of the fixture's raw alignments (RW lines), reads in the order of `view`."""
+    n = len(blocks)
+    nres = sum(len(b["rs"]) for b in blocks)
+    res = (api.Result * max(1, nres))()
+    stat = (api.ReadStat * n)()
+    res_off = (C.c_uint64 * (n + 1))()
+    dstr = bytearray()
+    j = 0
+    for i, b in enumerate(blocks):
+        res_off[i] = j
+        for f in b["rs"]:
+            r = res[j]
+            r.reverse = 1 if f[2] == "R" else 0
+            r.swatscor, r.q_start, r.q_end, r.s_start, r.s_end, r.sidx = int(f[3]), int(f[4]), int(f[5]), int(f[6]), int(f[7]), int(f[8])
+            d = bytes.fromhex(f[9])
+            r.stroffs, r.strlen = len(dstr), len(d)
+            dstr += d
+            j += 1
+        st = stat[i]
+        st.swatscor_max, st.swatscor_2ndmax, st.n_ali_done, st.n_ali_tot, st.n_hits_used, st.n_hits_tot = b["rx"][1:7]
+        st.nres = len(b["rs"])
+        st.max1scor = max(b["rc"]) if b["rc"] else 0
+    res_off[n] = j
+    dbuf = (C.c_uint8 * max(1, len(dstr))).from_buffer_copy(bytes(dstr) or b"\0")
+    return api.BatchOut(n, res_off, res, dbuf, stat), (res, stat, res_off, dbuf)
+
+
+@pytest.mark.parametrize("case", REPORT, ids=["%s-%s" % (c["tag"], c["variant"]) for c in REPORT])
+def test_report_matches_reference_program(case, oracle_built, tmp_path):
+    from smalt_amd import api
+    import oracle_lib as ol
+    L = api.lib()
+    entry = [e for e in gu.MANIFEST_ALL if e["tag"] == case["tag"]][0]
+    fx = gu.unpack(entry, tmp_path)
+    style = case.get("input")                 # the same reads as FASTA / as wrapped FASTQ with blank lines, CRLF, lower case
+    text = open(gu.reshape_reads(fx["fq"], style, str(tmp_path / "reshaped.txt")) if style else fx["fq"], "rb").read()
+    rs = L.smaltgpu_reads_create()
+    post = L.smaltgpu_post_create()
+    rep = L.smaltgpu_report_create()
+    oix = ol.lib().or_index_read(fx["prefix"].encode())
+    try:
+        view = api.ReadsView()
+        assert L.smaltgpu_reads_parse(rs, text, len(text), 1, 0, 3, C.byref(view)) == 0, L.smaltgpu_last_error()
+        blocks = list(_blocks(case["tag"]))
+        assert view.nreads == len(blocks) and view.consumed == len(text)
+        ref_reads = gu.read_fastq(fx["fq"])
+        for i, (nm, sq, ql) in enumerate(ref_reads):
+            a, b = view.read_off[i], view.read_off[i + 1]
+            assert bytes(view.bases[a:b]) == sq.upper()
+            assert (not view.has_qual and style == "fasta") or bytes(view.quals[a:b]) == ql
+            assert C.string_at(C.addressof(view.names.contents) + view.name_off[i]) == nm.encode() == blocks[i]["name"].encode()
+        raw, keep = raw_batch(api, blocks, view)
+        seqs, names = fx["seqs"], fx["names"]
+        sop = (C.c_uint64 * (len(seqs) + 1))()
+        for i, s_ in enumerate(seqs):
+            sop[i + 1] = sop[i] + len(s_)
+        par = api.Params()
+        par.match, par.mismatch, par.gap_init, par.gap_ext = 1, -2, -4, -3
+        pout = api.PostOut()
+        assert L.smaltgpu_postprocess(post, sop, len(seqs), C.byref(raw), view.bases, view.quals if view.has_qual else None, view.read_off,
+                                      C.cast(oix.contents.packed, C.c_void_p), C.byref(par), 2, C.byref(pout)) == 0
+        ro, seed = report_opts(api, case["opts"])
+        if ro.outflags & api.OUT_RANDSEL:
+            C.CDLL(None).srand48(C.c_long(seed))
+        nm_arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        got = b""
+        txt, ln = C.c_void_p(), C.c_uint64()
+        assert L.smaltgpu_report_header(rep, nm_arr, sop, len(seqs), C.byref(ro), b"smalt", b"0.7.6", 1, (C.c_char_p * 1)(b"test_report"), C.byref(txt), C.byref(ln)) == 0
+        got += C.string_at(txt, ln.value)
+        assert L.smaltgpu_report_emit(rep, C.byref(pout), C.byref(raw), C.byref(view), nm_arr, len(seqs), C.byref(ro), 3, C.byref(txt), C.byref(ln)) == 0, L.smaltgpu_last_error()
+        got += C.string_at(txt, ln.value)
+    finally:
+        L.smaltgpu_reads_free(rs)
+        L.smaltgpu_post_free(post)
+        L.smaltgpu_report_free(rep)
+        ol.lib().or_index_free(oix)
+    with gzip.open(os.path.join(gu.GOLD, "%s.%s.out.gz" % (case["tag"], case["variant"])), "rb") as g:
+        exp = g.read()
+    gl = [x for x in got.split(b"\n") if not x.startswith(b"@PG")]          # the program line names the program and its command line
+    el = [x for x in exp.split(b"\n") if not x.startswith(b"@PG")]
+    assert len(gl) == len(el)
+    for i, (x, y) in enumerate(zip(gl, el)):
+        assert x == y, (i, x, y)

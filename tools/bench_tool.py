@@ -92,6 +92,20 @@ def main():
         t_c1 = run(smalt, a.threads, cpu_fq, os.path.join(tmp, "c1.cig"))
         t_g0 = min(run(smalt_gpu, gthreads, small, os.path.join(tmp, "g0.cig"), env) for _ in range(3))     # start-up (index load, device init) varies: best of three
         t_g1 = run(smalt_gpu, gthreads, gpu_fq, os.path.join(tmp, "g1.cig"), env)
+        native = None
+        if not a.paired:
+            # the same job by smaltgpu-map: libsmaltgpu only (read ingest, GPU path, post-processing, report) -- no reference code
+            prog = os.path.join(ROOT, "smalt_amd", "smaltgpu-map")
+            r = subprocess.run([prog, "-r", "-1", "-f", "cigar", "-n", str(a.threads), "-o", os.path.join(tmp, "n1.cig"), prefix, gpu_fq], capture_output=True,
+                               env=dict(os.environ, SMALTGPU_MAP_VERBOSE="1"))
+            if r.returncode:
+                raise SystemExit("smaltgpu-map failed: %s" % r.stderr.decode()[-1500:])
+            ln = [x for x in r.stderr.decode().split("\n") if "reads in to lines out" in x][-1]
+            sys.stderr.write("".join(x + "\n" for x in r.stderr.decode().split("\n") if x.startswith("smaltgpu-map:")))
+            secs = float(ln.split("lines out")[1].split()[0])
+            nat = open(os.path.join(tmp, "n1.cig")).read().split("\n")
+            native = {"reads_per_s": a.reads / secs, "window_s": secs, "index_load_s": float(ln.split("index load")[1].split()[0]), "host_threads": a.threads,
+                      "identical_to_bound_program": nat == open(os.path.join(tmp, "g1.cig")).read().split("\n")}
         # same lines for the reads both programs mapped (the CPU run covers a prefix of the GPU run's reads)
         c = open(os.path.join(tmp, "c1.cig")).read().split("\n")
         g = open(os.path.join(tmp, "g1.cig")).read().split("\n")
@@ -104,7 +118,7 @@ def main():
                           # the binding's own clock from "index resident" to exit (FASTQ input, mapping, output): free of the start-up noise
                           # that the difference of two program runs above carries
                           "gpu_bound_window_s": windows.get(gpu_fq), "gpu_bound_reads_per_s_window": (a.reads / windows[gpu_fq]) if windows.get(gpu_fq) else None,
-                          "outputs_identical_on_common_reads": identical, "lines_compared": ncmp,
+                          "outputs_identical_on_common_reads": identical, "lines_compared": ncmp, "native_program": native,
                           "wall_s": {"cpu_small": t_c0, "cpu": t_c1, "gpu_small": t_g0, "gpu": t_g1}, "reads": {"cpu": a.cpu_reads, "gpu": a.reads}}))
 
 
