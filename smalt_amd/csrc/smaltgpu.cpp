@@ -1007,7 +1007,8 @@ extern "C" long smaltgpu_dump_read(smaltgpu_mapper *m, uint32_t i, const char *n
   v.qlen = (uint32_t)(m->h_off[i + 1] - m->h_off[i]); v.qmax = m->qmax; v.k = dk;
   for (int s2 = 0; s2 < 2; s2++) { v.hi[s2] = hi[s2]; v.seeds[s2] = seeds.data() + (size_t)s2 * m->qmax; v.qmask[s2] = qmask.data() + (size_t)s2 * m->qmax; }
   v.ch = ch[0]; v.rc = rc.data(); v.ctl = ctl[0]; v.st = st[0]; v.res = res.data(); v.dstr = dstr.data(); v.ngrp = ngrp;
-  if (v2) { v.cand = c2.cand; v.sort_idx = c2.sort_idx; v.sort_keys = c2.sort_keys; v.hitwords = c2.dbg_words; v.grp_first = c2.dbg_first; v.grp_cnt = c2.dbg_cnt; }
+  std::vector<SegCand> crec;
+  if (v2) { cands_v2_records(crec, c2, ch[0].ncand <= m->cg.candcap ? ch[0].ncand : 0, m->qmax > 255); v.cand = crec.data(); v.sort_idx = c2.sort_idx; v.sort_keys = c2.sort_keys; v.hitwords = c2.dbg_words; v.grp_first = c2.dbg_first; v.grp_cnt = c2.dbg_cnt; }
   else { v.cand = cx.cand; v.sort_idx = cx.sort_idx; v.sort_keys = cx.sort_keys; v.hitwords = cx.keys; v.grp_first = cx.grp_first; v.grp_cnt = cx.grp_cnt; }
   std::string o;
   dump_read(o, v, i, name, m->debug >= 2);

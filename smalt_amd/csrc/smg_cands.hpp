@@ -146,6 +146,7 @@ struct LongWork {
   // Early drop of candidates the cover filter of S6 can never keep: its threshold only grows with the largest and second
   // largest cover seen so far, and its allowance is at most the cover deficit of strand [0] (prune_cdf0).
   int prune_on; uint32_t prune_mcbm, prune_cdf0;
+  uint16_t *dbg_nseg; int32_t *dbg_seq;      // debug slots only: what the packed records of short reads leave out (dumps)
 };
 
 // bits [q, q + len) of a mask in memory; returns how many were clear (addCandsFast's cover_new, segment.c:1185-1200)
@@ -344,12 +345,23 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
     if (f) {
       uint32_t lo = 0, hi = nreg;                // hit region of segment m
       while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)w.reg_first[mid] <= m) lo = mid; else hi = mid; }
-      int32_t seqidx = seqbyseq ? (int32_t)(key_grp(w.dat[w.seed_first[w.segm_first[m]]]) & ((1u << KEY_SEQBITS) - 1)) : -1;
+      const uint32_t grp = seqbyseq ? (key_grp(w.dat[w.seed_first[w.segm_first[m]]]) & ((1u << KEY_SEQBITS) - 1)) : 0u;
+      int32_t seqidx = seqbyseq ? (int32_t)grp : -1;
       if (ivmap) seqidx = ivmap[seqidx].sx;       // interval-restricted call: the key's group is the interval number (rmap.c:486-490)
       SegCand c;
       const uint32_t ccover = LONG ? lw.ccov[m] : (uint32_t)w.cflag[m];
       if (derive_cand_c(c, w, m, (int)(uint32_t)w.reg_num[m], k, smg, ccover, mincover, reg_base + lo, is_reverse, seqidx)) err = SMG_ERR_ASSERT;
-      if (slot < candcap) { cand[slot] = c; if (!LONG) cover8[slot] = w.cflag[m]; } else ovf = true;     // covers again as a byte array: the S6 filter reads only these
+      if (slot >= candcap) ovf = true;
+      else if (LONG) cand[slot] = c;
+      else {
+        // 16-byte record (the group as in the key: S7 translates interval numbers again) + the cover as a byte array,
+        // which is all the S6 filter reads
+        SegCandP pc;
+        if (!segcand_pack(pc, c, grp, seqbyseq)) err = SMG_ERR_ASSERT;
+        ((SegCandP *)cand)[slot] = pc;
+        cover8[slot] = w.cflag[m];
+        if (lw.dbg_nseg) { lw.dbg_nseg[slot] = (uint16_t)c.nseg; lw.dbg_seq[slot] = c.seqidx; }
+      }
     }
   }
   *ncand_io = nc;
@@ -469,6 +481,11 @@ SMG_HD inline CandsV2Scratch cands_v2_carve(uint8_t *lds, size_t lds_bytes, uint
   x.pass = 0;
   x.lw.ccov = x.lw.mlist = x.lw.mask = nullptr;
   x.lw.prune_on = 0; x.lw.prune_mcbm = x.lw.prune_cdf0 = 0;
+  x.lw.dbg_nseg = nullptr; x.lw.dbg_seq = nullptr;
+  if (debug) {        // short reads write 16-byte records into the candidate array: its tail holds what the dumps print beside them
+    x.lw.dbg_nseg = (uint16_t *)((uint8_t *)x.cand + (size_t)candcap * sizeof(SegCandP));
+    x.lw.dbg_seq = (int32_t *)((uint8_t *)x.cand + (size_t)candcap * (sizeof(SegCandP) + 4));
+  }
   if (qmax > 255) {
     b = (uint8_t *)(((uintptr_t)b + 15) & ~(uintptr_t)15);
     if (debug) b += (size_t)ngrp * 2 * 4;
@@ -1143,7 +1160,14 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     uint32_t i = base + SMG_LANE;
     if (i < n_sort) {
       RCand c;
-      if (cand_offsets(c, x.cand[x.sort_idx[i]], ix, qlen)) { c.flags |= RCF_ERR; c.rs = c.re = 0; c.qs = c.qe = 0; c.band_l = c.band_r = 0; }
+      SegCand sc;
+      if (LONG) sc = x.cand[x.sort_idx[i]];
+      else {
+        const uint32_t ci = x.sort_idx[i];
+        segcand_unpack(sc, ((const SegCandP *)x.cand)[ci], (uint32_t)x.cover8[ci]);
+        if (ivmode && sc.seqidx >= 0) sc.seqidx = ivr[sc.seqidx].sx;      // the key's group is the interval number (rmap.c:486-490)
+      }
+      if (cand_offsets(c, sc, ix, qlen)) { c.flags |= RCF_ERR; c.rs = c.re = 0; c.qs = c.qe = 0; c.band_l = c.band_r = 0; }
       if (qn) c.flags |= RCF_QN;
       if (!(c.flags & (RCF_ERR | RCF_BANDED))) {          // K2a task: which instance scores it (smg_kernels.hip)
         const uint32_t wl_ = (uint32_t)(c.re - c.rs + 1);

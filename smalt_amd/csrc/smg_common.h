@@ -89,6 +89,26 @@ struct SegCand {                                                    // segment.c
   int32_t seqidx;
 };
 
+// The same for reads below 256 bases in 16 bytes (the candidate stage writes one record per candidate, 2000 per read on
+// a repeat-rich genome, of which a few hundred are ranked): read offsets fit a byte, the reference range 16 bits
+// (srange <= 32767 is checked), the cover lives in the stage's byte array, nseg / hregix are not needed downstream.
+struct SegCandP { uint32_t rs, w1, w2, w3; };
+SMG_HD inline bool segcand_pack(SegCandP &p, const SegCand &c, uint32_t grp, bool hasgrp) {
+  const uint32_t span = c.re - c.rs;
+  p.rs = c.rs;
+  p.w1 = (span << 16) | ((c.qs & 0xffu) << 8) | (c.qe & 0xffu);
+  p.w2 = (uint32_t)(uint16_t)c.shiftoffs | ((uint32_t)(uint16_t)c.shift2mm << 16);
+  p.w3 = ((uint32_t)c.srange & 0x7fffu) | ((uint32_t)((c.flag & CANDFLG_REVERSE) ? 1u : 0u) << 15) | ((uint32_t)((c.flag & CANDFLG_MMALI) ? 1u : 0u) << 16) | (hasgrp ? (1u << 17) : 0u) | ((grp & 0x3ffu) << 18);
+  return span <= 0xffffu && c.qs <= 0xffu && c.qe <= 0xffu && c.srange >= 0 && !(c.flag & ~(uint8_t)(CANDFLG_REVERSE | CANDFLG_MMALI));
+}
+SMG_HD inline void segcand_unpack(SegCand &c, const SegCandP &p, uint32_t cover) {
+  c.rs = p.rs; c.re = p.rs + (p.w1 >> 16); c.qs = (p.w1 >> 8) & 0xffu; c.qe = p.w1 & 0xffu;
+  c.shiftoffs = (int16_t)(uint16_t)(p.w2 & 0xffffu); c.shift2mm = (int16_t)(uint16_t)(p.w2 >> 16);
+  c.srange = (int16_t)(p.w3 & 0x7fffu); c.flag = (uint8_t)(((p.w3 >> 15) & 1u ? CANDFLG_REVERSE : 0) | ((p.w3 >> 16) & 1u ? CANDFLG_MMALI : 0)); c.pad = 0;
+  c.cover = cover; c.nseg = 0; c.hregix = 0;
+  c.seqidx = (p.w3 & (1u << 17)) ? (int32_t)((p.w3 >> 18) & 0x3ffu) : -1;
+}
+
 struct RCand {                                                      // rmap.c:111-126
   uint64_t rs, re;          // window in sequence sqidx (or concatenated set if sqidx < 0)
   uint32_t qs, qe;

@@ -5,7 +5,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 #include "smg_stages.hpp"
+#include "smg_cands.hpp"
 
 namespace smg {
 
@@ -36,6 +38,17 @@ inline void appendf(std::string &o, const char *fmt, ...) {
   int n = vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
   if (n > 0) o.append(buf, (size_t)(n < (int)sizeof(buf) ? n : (int)sizeof(buf) - 1));
+}
+
+// The candidate records of a wave-parallel slot as SegCand: reads below 256 bases (the lean kernel instance) hold
+// 16-byte records, with the cover in the byte array and, in debug slots, segment count and sequence number beside them.
+inline void cands_v2_records(std::vector<SegCand> &out, const CandsV2Scratch &x, uint32_t ncand, bool long_instance) {
+  out.resize(ncand ? ncand : 1);
+  for (uint32_t i = 0; i < ncand; i++) {
+    if (long_instance) { out[i] = x.cand[i]; continue; }
+    segcand_unpack(out[i], ((const SegCandP *)x.cand)[i], (uint32_t)x.cover8[i]);
+    if (x.lw.dbg_nseg) { out[i].nseg = x.lw.dbg_nseg[i]; out[i].seqidx = x.lw.dbg_seq[i]; }
+  }
 }
 
 inline void dump_read(std::string &o, const DumpView &v, unsigned long long readno, const char *name, bool with_hitlists) {

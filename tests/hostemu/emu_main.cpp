@@ -159,6 +159,7 @@ int main(int argc, char **argv) {
     stage_align(b, ix, p, r, ax);
   }
   std::string out;
+  std::vector<SegCand> crec;
   for (uint32_t r = 0; r < n; r++) {
     CandScratch cx = cand_scratch_carve(cscr.data() + cbytes * r, qmax, ix.s, hcap, ngrp, segcap, candcap);
     DumpView v;
@@ -170,7 +171,7 @@ int main(int argc, char **argv) {
     v.ctl = ctl[r]; v.st = stat[r]; v.res = respool.data() + stat[r].res_off; v.dstr = dstrpool.data() + stat[r].dstr_off; v.ngrp = ngrp;
     if (cands_v2_applicable(p, ix.k, ix.s, v.qlen) && !(force && !strcmp(force, "v1"))) {
       CandsV2Scratch c2 = cands_v2_carve(nullptr, 0, cscr.data() + cbytes * r, qmax, ix.s, hcap_strand, ngrp, candcap, true);
-      v.cand = c2.cand; v.sort_idx = c2.sort_idx; v.sort_keys = c2.sort_keys; v.hitwords = c2.dbg_words; v.grp_first = c2.dbg_first; v.grp_cnt = c2.dbg_cnt;
+      cands_v2_records(crec, c2, v.ch.ncand <= candcap ? v.ch.ncand : 0, v.qlen > 255); v.cand = crec.data(); v.sort_idx = c2.sort_idx; v.sort_keys = c2.sort_keys; v.hitwords = c2.dbg_words; v.grp_first = c2.dbg_first; v.grp_cnt = c2.dbg_cnt;
     } else { v.cand = cx.cand; v.sort_idx = cx.sort_idx; v.sort_keys = cx.sort_keys; v.hitwords = cx.keys; v.grp_first = cx.grp_first; v.grp_cnt = cx.grp_cnt; }
     out.clear();
     dump_read(out, v, r, names[r].c_str(), with_hl != 0);
