@@ -174,6 +174,8 @@ __global__ void __launch_bounds__(64) k_align(Batch b, DevIndex ix, MapPar p, ui
   extern __shared__ __align__(16) uint8_t lds[];
   uint8_t *base = gscratch + gbytes * blockIdx.x;
   AlignScratch x = align_scratch_carve_lds(lds_bytes ? lds + LDS_GUARD : nullptr, lds_bytes, base, b.qmax, wincap, dircap, rescap, dstrcap);
+  x.rows_form = !(pass & 0x100);          // bit 8 of the launch's pass word: anti-diagonal form for narrow bands (test hook)
+  pass &= 0xff;
   x.pass = pass;
   __shared__ int2 strip_ring[WIDE ? 256 : 1];
   x.ring = WIDE ? (void *)strip_ring : nullptr;
@@ -1266,6 +1268,8 @@ int launch_align(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar
   uint32_t kb = lds_kb;
   if (b.qmax > 256 && small + 4096 > (size_t)kb * 1024 && small + 8192 <= 64 * 1024) kb = (uint32_t)((small + 8192 + 1023) / 1024);   // long reads: read, window and traceback string stay in LDS
   uint32_t lds_bytes = small + 4096 <= (size_t)kb * 1024 ? kb * 1024 - LDS_GUARD : 0;      // rows + window + direction bytes
+  static const int antidiag = getenv("SMALTGPU_ALIGN_ANTIDIAG") ? 0x100 : 0;      // test hook: narrow bands in the anti-diagonal form (band_track_wave)
+  pass |= antidiag;
   if (b.qmax > 256) hipLaunchKernelGGL(k_align<true>, dim3(grid), dim3(64), lds_bytes ? lds_bytes + LDS_GUARD : 0, s, b, ix, p, scratch, sbytes, wincap, dircap, rescap, dstrcap, lds_bytes, pass);
   else hipLaunchKernelGGL(k_align<false>, dim3(grid), dim3(64), lds_bytes ? lds_bytes + LDS_GUARD : 0, s, b, ix, p, scratch, sbytes, wincap, dircap, rescap, dstrcap, lds_bytes, pass);
   SMG_LAUNCH_CHECK();

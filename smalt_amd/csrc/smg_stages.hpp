@@ -730,6 +730,7 @@ struct AlignScratch {
   uint8_t *qcodes; uint32_t qstride;   // [2][qstride] the read in both orientations
   uint8_t *win_lds, *dtmp_lds; uint32_t win_lds_cap;   // LDS copies for windows of ordinary length (else the HBM arrays)
   int pass;                   // 0: only pass; 1: first of two (a band that does not fit defers the read); 2: second (deferred reads only)
+  int rows_form;              // 1: bands of up to 64 diagonals row by row (band_track_rows); 0: anti-diagonal form (SMALTGPU_ALIGN_ANTIDIAG, tests)
   void *ring;                 // LDS [256] (H, F) pairs of band_track_strip (set by k_align<true>)
   void *bnd; uint32_t bndcap; // [2 * bndcap] (H, F) pairs: hand-over between the strips of band_track_strip (long reads only)
 };
@@ -742,6 +743,7 @@ SMG_HD inline size_t align_scratch_bytes(uint32_t qmax, uint32_t wincap, uint64_
 
 SMG_HD inline AlignScratch align_scratch_carve(uint8_t *base, uint32_t qmax, uint32_t wincap, uint64_t dircap, uint32_t rescap, uint32_t dstrcap) {
   AlignScratch x;
+  x.rows_form = 0;
   x.res = (Result *)base; base += (size_t)rescap * sizeof(Result); x.rescap = rescap;
   x.Hp = (int *)base; base += ((size_t)qmax + 2) * 4;
   x.Ep = (int *)base; base += ((size_t)qmax + 2) * 4;
@@ -1084,6 +1086,67 @@ __device__ inline int band_track_wave(const Band &bp, PW q, PW win, int match, i
   return best;
 }
 
+// Bands of up to 64 diagonals, row by row: lane c owns band diagonal l + c, i.e. cell (i', j = l + c + i') of row i'.
+// The diagonal predecessor (i'-1, j-1) lies on the same diagonal (own register), the cell above (i'-1, j) on diagonal
+// c + 1 (one DPP shift), and the horizontal gap score reaches a cell through a prefix maximum over the lanes to its left:
+// in a row F only ever comes from cells whose diagonal won with H > gi (cell_update raises F to H - gi there and nowhere
+// else), decays by ge per column while positive, and is used as max(F, 0) -- so F_in(c) = max(0, max_{i<c} (H_i - gi
+// + ge i) - ge (c - 1)), exact as long as gi >= ge (a cell that loses to F cannot raise it: H - gi <= F - ge).  One step
+// per row (16 VALU for the scan) instead of two anti-diagonal steps with half the lanes idle: 2.4 x fewer instructions
+// per band cell than band_track_wave.  Results (scores, direction bytes, first maximum) are those of band_track_wave.
+__device__ inline int dpp_scan_max_excl(int x, int neg) {
+  int t;
+  t = __builtin_amdgcn_update_dpp(neg, x, 0x111 /* row_shr:1 */, 0xf, 0xf, false); x = x > t ? x : t;
+  t = __builtin_amdgcn_update_dpp(neg, x, 0x112 /* row_shr:2 */, 0xf, 0xf, false); x = x > t ? x : t;
+  t = __builtin_amdgcn_update_dpp(neg, x, 0x114 /* row_shr:4 */, 0xf, 0xf, false); x = x > t ? x : t;
+  t = __builtin_amdgcn_update_dpp(neg, x, 0x118 /* row_shr:8 */, 0xf, 0xf, false); x = x > t ? x : t;
+  t = __builtin_amdgcn_update_dpp(neg, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false); x = x > t ? x : t;
+  t = __builtin_amdgcn_update_dpp(neg, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false); x = x > t ? x : t;
+  return __builtin_amdgcn_update_dpp(neg, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+template <class PW = const uint8_t *>
+__device__ inline int band_track_rows(const Band &bp, PW q, PW win, int match, int mismatch, int gi, int ge,
+                                      uint8_t *dir, int *max_i, int *max_j) {
+  const int lane = (int)threadIdx.x;
+  const int nrows = __builtin_amdgcn_readfirstlane(bp.s_len - bp.s_left), l = bp.l_edge, bw = bp.band_width;
+  const int d = l + lane;
+  const bool inband = lane < bw;
+  const int NEG = -(1 << 28);
+  const int gel = ge * lane, gel1 = ge * (lane - 1);
+  int Hd = 0, Eown = 0;
+  int best = 0, bi = 0, bj = 0;
+  for (int ip = 0; ip < nrows; ip++) {
+    const int j = d + ip;
+    const bool act = inband && j >= bp.q_left && j <= bp.q_len - 1;
+    const int Ein = __builtin_amdgcn_update_dpp(0, Eown, 0x130 /* wave_shl:1: the lane above */, 0xf, 0xf, false);
+    const int rb = win[bp.s_left + ip] & 7;
+    const int qc = act ? (q[j] & 7) : 5;
+    const int w = (rb >= 4 || qc >= 4) ? 0 : (rb == qc ? match : mismatch);      // score.c:138-173 (codes 0-3, 5 = N)
+    const int Hin = Hd + w;
+    const int e = Ein > 0 ? Ein : 0;
+    const int src = (act && Hin > e && Hin > gi) ? Hin - gi + gel : NEG;
+    const int px = dpp_scan_max_excl(src, NEG);
+    int F = px - gel1;
+    if (F < 0) F = 0;
+    int Hnew, E = Ein;
+    bool cand;
+    const int dc = cell_update(Hnew, E, F, Hin, gi, ge, cand);
+    if (act) {
+      dir[(size_t)ip * (size_t)bw + (size_t)lane] = (uint8_t)dc;
+      if (cand && Hin > best) { best = Hin; bi = ip; bj = j; }
+    }
+    Hd = act ? Hnew : 0;
+    Eown = act ? E : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const int ob = __shfl_xor(best, o), oi = __shfl_xor(bi, o), oj = __shfl_xor(bj, o);
+    if (ob > best || (ob == best && (oi < bi || (oi == bi && oj < bj)))) { best = ob; bi = oi; bj = oj; }
+  }
+  *max_i = best > 0 ? bp.s_left + bi : 0;
+  *max_j = best > 0 ? bj : 0;
+  return best;
+}
+
 // The same for wider bands.  Columns jmin + c + 64m of lane c that are inside the band at step t differ by 128
 // diagonals, so a lane has at most (r - l) / 128 + 1 live columns; column m keeps its state in register slot m % NS.
 // The left neighbour of (lane c, slot s) is (lane c - 1, slot s), for lane 0 (lane 63, slot s - 1).
@@ -1255,7 +1318,9 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
       }
       int max_i = 0, max_j = 0, max_scor = 0, tW = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-      if (!nerr && !skip && dirm == x.dir && band.band_width >= 1 && (band.band_width <= 64 || (WIDE && (band.r_edge - band.l_edge) / 128 + 1 <= 12))) {
+      // bands of up to 64 diagonals take the row form (band_track_rows; its horizontal gap scan needs gi >= ge), row-major directions
+      const bool rows_form = gi >= ge && ge >= 0 && band.band_width <= 64 && x.rows_form;
+      if (!nerr && !skip && dirm == x.dir && band.band_width >= 1 && !rows_form && (band.band_width <= 64 || (WIDE && (band.r_edge - band.l_edge) / 128 + 1 <= 12))) {
         // direction matrix in HBM and a wave form: anti-diagonal-major layout (dir_index) if it fits
         const int jmin = band.q_left > band.l_edge ? band.q_left : band.l_edge;
         int jlast = band.r_edge + (band.s_len - band.s_left) - 1; if (jlast > band.q_len - 1) jlast = band.q_len - 1;
@@ -1286,6 +1351,9 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
             if (in_lds) max_scor = band_track_strip<PL, 16>(band, sg, (PL)q, (PL)win, p.match, p.mismatch, gi, ge, (uint32_t *)dirm, (int2 *)x.bnd, x.bndcap, (int2 *)x.ring, &max_i, &max_j);
             else max_scor = band_track_strip<const uint8_t *, 16>(band, sg, q, win, p.match, p.mismatch, gi, ge, (uint32_t *)dirm, (int2 *)x.bnd, x.bndcap, (int2 *)x.ring, &max_i, &max_j);
           }
+        } else if (band.band_width >= 1 && band.band_width <= 64 && rows_form) {
+          if (in_lds) max_scor = band_track_rows<PL>(band, (PL)q, (PL)win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j);
+          else max_scor = band_track_rows<const uint8_t *>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j);
         } else if (band.band_width >= 1 && band.band_width <= 64) {
           if (in_lds) max_scor = band_track_wave<PL>(band, (PL)q, (PL)win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j, tW);
           else max_scor = band_track_wave<const uint8_t *>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j, tW);
