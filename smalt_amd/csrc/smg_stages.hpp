@@ -1094,14 +1094,15 @@ __device__ inline int band_track_wave(const Band &bp, PW q, PW win, int match, i
 // + ge i) - ge (c - 1)), exact as long as gi >= ge (a cell that loses to F cannot raise it: H - gi <= F - ge).  One step
 // per row (16 VALU for the scan) instead of two anti-diagonal steps with half the lanes idle: 2.4 x fewer instructions
 // per band cell than band_track_wave.  Results (scores, direction bytes, first maximum) are those of band_track_wave.
-__device__ inline int dpp_scan_max_excl(int x, int neg) {
-  int t;
-  t = __builtin_amdgcn_update_dpp(neg, x, 0x111 /* row_shr:1 */, 0xf, 0xf, false); x = x > t ? x : t;
-  t = __builtin_amdgcn_update_dpp(neg, x, 0x112 /* row_shr:2 */, 0xf, 0xf, false); x = x > t ? x : t;
-  t = __builtin_amdgcn_update_dpp(neg, x, 0x114 /* row_shr:4 */, 0xf, 0xf, false); x = x > t ? x : t;
-  t = __builtin_amdgcn_update_dpp(neg, x, 0x118 /* row_shr:8 */, 0xf, 0xf, false); x = x > t ? x : t;
-  t = __builtin_amdgcn_update_dpp(neg, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false); x = x > t ? x : t;
-  t = __builtin_amdgcn_update_dpp(neg, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false); x = x > t ? x : t;
+// exclusive prefix maximum over the wave; INT_MIN is the identity, so the DPP moves fold into the v_max instructions
+__device__ inline int dpp_scan_max_excl(int x) {
+  const int neg = (int)0x80000000;
+  x = max(x, __builtin_amdgcn_update_dpp(neg, x, 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(neg, x, 0x112 /* row_shr:2 */, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(neg, x, 0x114 /* row_shr:4 */, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(neg, x, 0x118 /* row_shr:8 */, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(neg, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(neg, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
   return __builtin_amdgcn_update_dpp(neg, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 template <class PW = const uint8_t *>
@@ -1109,32 +1110,40 @@ __device__ inline int band_track_rows(const Band &bp, PW q, PW win, int match, i
                                       uint8_t *dir, int *max_i, int *max_j) {
   const int lane = (int)threadIdx.x;
   const int nrows = __builtin_amdgcn_readfirstlane(bp.s_len - bp.s_left), l = bp.l_edge, bw = bp.band_width;
-  const int d = l + lane;
+  const int d = l + lane, qhi = bp.q_len - 1;
   const bool inband = lane < bw;
   const int NEG = -(1 << 28);
-  const int gel = ge * lane, gel1 = ge * (lane - 1);
+  const int gel = ge * lane - gi, gel1 = ge * (lane - 1);
   int Hd = 0, Eown = 0;
   int best = 0, bi = 0, bj = 0;
-  for (int ip = 0; ip < nrows; ip++) {
+  // codes of the next row are loaded a row ahead (the read offset clamped into the read: inactive cells do not use it)
+  int rbn = win[bp.s_left] & 7;
+  int qn = q[d < 0 ? 0 : (d > qhi ? qhi : d)] & 7;
+  uint8_t *dp = dir + lane;
+  for (int ip = 0; ip < nrows; ip++, dp += bw) {
     const int j = d + ip;
-    const bool act = inband && j >= bp.q_left && j <= bp.q_len - 1;
+    const bool act = inband && j >= bp.q_left && j <= qhi;
+    const int rb = rbn, qc = qn;
+    {
+      const int jn = j + 1, in = ip + 1 < nrows ? ip + 1 : ip;
+      rbn = win[bp.s_left + in] & 7;
+      qn = q[jn < 0 ? 0 : (jn > qhi ? qhi : jn)] & 7;
+    }
     const int Ein = __builtin_amdgcn_update_dpp(0, Eown, 0x130 /* wave_shl:1: the lane above */, 0xf, 0xf, false);
-    const int rb = win[bp.s_left + ip] & 7;
-    const int qc = act ? (q[j] & 7) : 5;
     const int w = (rb >= 4 || qc >= 4) ? 0 : (rb == qc ? match : mismatch);      // score.c:138-173 (codes 0-3, 5 = N)
     const int Hin = Hd + w;
     const int e = Ein > 0 ? Ein : 0;
-    const int src = (act && Hin > e && Hin > gi) ? Hin - gi + gel : NEG;
-    const int px = dpp_scan_max_excl(src, NEG);
+    const int src = (act && Hin > e && Hin > gi) ? Hin + gel : (int)0x80000000;
+    int px = dpp_scan_max_excl(src);
+    px = px > NEG ? px : NEG;
     int F = px - gel1;
-    if (F < 0) F = 0;
+    F = F > 0 ? F : 0;
     int Hnew, E = Ein;
     bool cand;
     const int dc = cell_update(Hnew, E, F, Hin, gi, ge, cand);
-    if (act) {
-      dir[(size_t)ip * (size_t)bw + (size_t)lane] = (uint8_t)dc;
-      if (cand && Hin > best) { best = Hin; bi = ip; bj = j; }
-    }
+    if (act) *dp = (uint8_t)dc;
+    const bool better = act && cand && Hin > best;
+    best = better ? Hin : best; bi = better ? ip : bi; bj = better ? j : bj;
     Hd = act ? Hnew : 0;
     Eown = act ? E : 0;
   }
