@@ -852,11 +852,22 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
                   plim = plim < slo ? slo : (plim > shi ? shi : plim);
                 }
               } else if (bound == ~0ull) plim = (int64_t)1 << 33;
+              // eight-way search: the seven pivots of a round are independent index reads (one round trip to HBM
+              // instead of three); invariant: positions below lo are below the limit, those from hi on are not
               while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if ((int64_t)pp[mid] < plim) lo = mid + 1; else hi = mid;
+                const uint32_t n = hi - lo, step = (n + 7) >> 3;
+                uint32_t pv[7];
+#pragma unroll
+                for (int u = 0; u < 7; u++) { const uint32_t ip_ = lo + (uint32_t)(u + 1) * step - 1; pv[u] = ip_ < hi ? pp[ip_] : 0xffffffffu; }
+                uint32_t c = 0;
+#pragma unroll
+                for (int u = 0; u < 7; u++) c += ((lo + (uint32_t)(u + 1) * step - 1 < hi) && (int64_t)pv[u] < plim) ? 1u : 0u;
+                const uint32_t nlo = lo + c * step, piv = nlo + step - 1;      // piv: the first pivot that is not below the limit
+                if (c < 7 && piv < hi) hi = piv;
+                lo = nlo;
+                if (step == 1 && c < 7) break;                                 // every element of [lo, hi) was a pivot
               }
-              cnt = lo;
+              cnt = lo < hi ? lo : hi;
             }
           }
           uint32_t incl = cnt;
