@@ -17,6 +17,7 @@
 #include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <chrono>
 #include <condition_variable>
@@ -38,7 +39,7 @@ const char VERSION[] = "0.2";
 
 void usage() {
   fprintf(stderr,
-          "usage: smaltgpu-map [options] <index prefix> <reads.fq|reads.fa>\n"
+          "usage: smaltgpu-map [options] <index prefix> <reads.fq|reads.fa>[.gz]\n"
           "  -f <fmt>   cigar (default) | sam | samsoft, SAM modifiers behind a colon: nohead, clip, x (e.g. sam:nohead,x)\n"
           "  -o <file>  output file (default: standard output)\n"
           "  -m <int>   minimum Smith-Waterman score (default: word length + step - 1)\n"
@@ -65,6 +66,59 @@ struct Block {                                  // one block of reads on its way
   smaltgpu_batch_out raw;
   smaltgpu_post_out post;
   std::string err;
+};
+
+// The text of the input: a memory-mapped file, or the inflated stream of a gzip file (the reference reads FASTQ through
+// zlib's gzgets when it is built with it, sequence.c:1108).  window() hands out at least `want` bytes of text that has not
+// been consumed yet (less at the end of the input).
+struct Source {
+  const char *map = nullptr; uint64_t maplen = 0, pos = 0;      // plain file
+  bool gz = false, gz_end = false;
+  z_stream zs;
+  std::vector<char> buf; uint64_t boff = 0;                     // inflated text not consumed yet: buf[boff..)
+  void open(const char *path) {
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) die("cannot open", path);
+    struct stat sb;
+    if (fstat(fd, &sb)) die("cannot stat", path);
+    maplen = (uint64_t)sb.st_size;
+    map = maplen ? (const char *)mmap(nullptr, maplen, PROT_READ, MAP_PRIVATE, fd, 0) : "";
+    if (maplen && map == (const char *)MAP_FAILED) die("cannot map", path);
+    if (maplen) (void)madvise((void *)map, maplen, MADV_SEQUENTIAL);
+    gz = maplen >= 2 && (unsigned char)map[0] == 0x1f && (unsigned char)map[1] == 0x8b;
+    if (gz) {
+      memset(&zs, 0, sizeof(zs));
+      if (inflateInit2(&zs, 15 + 32) != Z_OK) die("zlib");          // + 32: gzip or zlib header
+      zs.next_in = (Bytef *)map; zs.avail_in = 0;
+    }
+  }
+  const char *window(uint64_t want, uint64_t *got, bool *last) {
+    if (!gz) { *got = want < maplen - pos ? want : maplen - pos; *last = pos + *got >= maplen; return map + pos; }
+    if (boff > (64u << 20) || (boff && boff == buf.size())) { buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)boff); boff = 0; }
+    while (!gz_end && buf.size() - boff < want) {
+      const size_t old = buf.size(), add = want > (8u << 20) ? (size_t)want : (size_t)(8u << 20);
+      buf.resize(old + add);
+      zs.next_out = (Bytef *)buf.data() + old; zs.avail_out = (uInt)add;
+      while (zs.avail_out && !gz_end) {
+        if (!zs.avail_in) {
+          const uint64_t left = maplen - pos;
+          if (!left) { gz_end = true; break; }
+          zs.avail_in = (uInt)(left < (1u << 30) ? left : (1u << 30)); zs.next_in = (Bytef *)map + pos; pos += zs.avail_in;
+        }
+        const int rv = inflate(&zs, Z_NO_FLUSH);
+        if (rv == Z_STREAM_END) {                                 // a gzip file may hold several members
+          if (!zs.avail_in && pos >= maplen) gz_end = true; else if (inflateReset(&zs) != Z_OK) die("zlib");
+        } else if (rv != Z_OK && rv != Z_BUF_ERROR) die("corrupt gzip input");
+        else if (rv == Z_BUF_ERROR && !zs.avail_in && pos >= maplen) gz_end = true;
+      }
+      buf.resize(old + add - zs.avail_out);
+    }
+    *got = want < buf.size() - boff ? want : buf.size() - boff;
+    *last = gz_end && *got == buf.size() - boff;
+    return buf.data() + boff;
+  }
+  void consume(uint64_t n) { if (gz) boff += n; else pos += n; }
+  bool done() const { return gz ? (gz_end && boff >= buf.size()) : pos >= maplen; }
 };
 
 }  // namespace
@@ -130,15 +184,8 @@ int main(int argc, char **argv) {
   }
   if (ro.outflags & SMALTGPU_OUT_RANDSEL) srand48(seed <= 0 ? (long)time(nullptr) : (long)seed);     // RANSEED (randef.h:19)
 
-  // input: the whole file mapped read-only
-  const int fd = open(readfil, O_RDONLY);
-  if (fd < 0) die("cannot open", readfil);
-  struct stat sb;
-  if (fstat(fd, &sb)) die("cannot stat", readfil);
-  const uint64_t flen = (uint64_t)sb.st_size;
-  const char *ftext = flen ? (const char *)mmap(nullptr, flen, PROT_READ, MAP_PRIVATE, fd, 0) : "";
-  if (flen && ftext == (const char *)MAP_FAILED) die("cannot map", readfil);
-  if (flen) (void)madvise((void *)ftext, flen, MADV_SEQUENTIAL);
+  Source src;                                                                            // input: plain or gzip text
+  src.open(readfil);
   FILE *ou = oufil ? fopen(oufil, "w") : stdout;
   if (!ou) die("cannot write", oufil);
   static char oubuf[1 << 22];
@@ -180,18 +227,18 @@ int main(int argc, char **argv) {
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 
   std::thread parser([&] {
-    uint64_t pos = 0;
     double bytes_per_read = 0.0;
     for (uint64_t k = 0;; k++) {
       Block &b = blk[k % NBLK];
       { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return failed || k < n_written + NBLK; }); if (failed) return; }
-      if (pos >= flen) { std::lock_guard<std::mutex> lk(mu); n_blocks_total = k; input_done = true; cv.notify_all(); return; }
       uint64_t win = bytes_per_read > 0 ? (uint64_t)(bytes_per_read * (double)batch * 1.05) + 65536 : (1u << 20);
       const double tp0 = now();
+      bool last = false;
       for (;;) {
-        if (win > flen - pos) win = flen - pos;
-        const int last = pos + win >= flen;
-        if (smaltgpu_reads_parse(b.rs, ftext + pos, win, last, (uint32_t)batch, nthreads, &b.v)) {
+        uint64_t got = 0;
+        const char *text = src.window(win, &got, &last);
+        if (!got) { b.v.nreads = 0; break; }
+        if (smaltgpu_reads_parse(b.rs, text, got, last ? 1 : 0, (uint32_t)batch, nthreads, &b.v)) {
           std::lock_guard<std::mutex> lk(mu); b.err = smaltgpu_last_error(); failed = true; cv.notify_all(); return;
         }
         if (b.v.nreads || last) break;
@@ -200,7 +247,7 @@ int main(int argc, char **argv) {
       if (!b.v.nreads) { std::lock_guard<std::mutex> lk(mu); n_blocks_total = k; input_done = true; cv.notify_all(); return; }
       t_parse += now() - tp0;
       bytes_per_read = (double)b.v.consumed / (double)b.v.nreads;
-      pos += b.v.consumed;
+      src.consume(b.v.consumed);
       b.maxlen = 1;
       for (uint32_t i = 0; i < b.v.nreads; i++) { const uint32_t l = (uint32_t)(b.v.read_off[i + 1] - b.v.read_off[i]); if (l > b.maxlen) b.maxlen = l; }
       { std::lock_guard<std::mutex> lk(mu); b.state = 1; n_parsed = k + 1; cv.notify_all(); }

@@ -52,3 +52,22 @@ def test_program_large_batch_equals_small_batches(fixtures):
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         outs.append(open(out, "rb").read())
     assert outs[0] == outs[1] and outs[0].count(b"\n") >= 220
+
+
+def test_program_reads_gzip_input(fixtures):
+    """the reference reads gzip-compressed FASTQ through zlib (sequence.c:1108); smaltgpu-map inflates the stream itself"""
+    fxs, tmp = fixtures
+    fx = fxs["g_k13s6_hash"]
+    gz = str(tmp / "reads.fq.gz")
+    raw = open(fx["fq"], "rb").read()
+    half = len(raw) // 2
+    half = raw.index(b"\n@r", half) + 1
+    with open(gz, "wb") as f:                       # two gzip members, as `cat a.gz b.gz` gives
+        f.write(gzip.compress(raw[:half]) + gzip.compress(raw[half:]))
+    outs = []
+    for inp in (fx["fq"], gz):
+        out = str(tmp / "gz.txt")
+        r = subprocess.run([PROG, "-r", "3", "-f", "sam:nohead", "-B", "100", "-o", out, fx["prefix"], inp], capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] and outs[0].count(b"\n") == 250
