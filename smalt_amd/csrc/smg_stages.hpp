@@ -1156,6 +1156,54 @@ __device__ inline int band_track_rows(const Band &bp, PW q, PW win, int match, i
   return best;
 }
 
+// The traceback of traceback_scalar (row-major directions) run by the whole wave in lock step: every value it walks
+// on is the same in all lanes and is handed to the scalar unit (readfirstlane), so the walk costs a few vector
+// instructions per step (the loads) instead of forty on a single lane; the alignment string is written by lane 0.
+__device__ inline int traceback_uniform(uint8_t *ds, uint32_t dscap, int *qs, int *rs, const Band &bp, const uint8_t *dir,
+                                        int max_i, int max_j, int max_scor, const uint8_t *q, const uint8_t *win,
+                                        int tb_match, int tb_mismatch, int gi, int ge) {
+#define SMG_U(v) __builtin_amdgcn_readfirstlane((int)(v))
+  const int bw = SMG_U(bp.band_width), s_left = SMG_U(bp.s_left), q_left = SMG_U(bp.q_left);
+  int i = SMG_U(max_i), j = SMG_U(max_j);
+  int off = (i - s_left) * (bw - 1) + (j - SMG_U(bp.l_edge));       // dir_index with tW == 0
+  int n = 0, checksum = 0, nmatch = 0, rv = 0;
+  bool gap_open = false;
+  const bool writer = threadIdx.x == 0;
+  const int cap = (int)dscap;
+#define SMG_PUTU(cnt, typ) { if (n + 2 >= cap) { rv = -2; break; } if (writer) ds[n] = (uint8_t)((cnt) + ((typ) << DIFF_TYPSHIFT)); n++; }
+  do {
+    while (i >= s_left && j >= q_left) {
+      const uint8_t dv = dir[off], wv = win[i], qv = q[j];     // three independent loads, one wait
+      const int d = SMG_U(dv);
+      if (!d) break;
+      if (d == (int)DIR_DIA) {
+        const int rbc = SMG_U(wv) & 7, qcc = SMG_U(qv) & 7;
+        const int sc = (rbc >= 4 || qcc >= 4) ? 0 : (rbc == qcc ? tb_match : tb_mismatch);
+        if (sc > 0) {
+          if (nmatch > (int)DIFF_MAXMISMATCH) { SMG_PUTU(DIFF_MAXMISMATCH, DIFF_M) nmatch -= DIFF_MAXMISMATCH; }
+          else nmatch++;
+        } else { SMG_PUTU(nmatch, DIFF_S) nmatch = 0; }
+        checksum += sc;
+        gap_open = false;
+        off -= bw; i--; j--;
+        continue;
+      }
+      if (gap_open) checksum -= ge; else { checksum -= gi; gap_open = true; }
+      if (d & (int)DIR_COL) { SMG_PUTU(nmatch, DIFF_D) nmatch = 0; off -= bw - 1; i--; continue; }
+      if (!(d & (int)DIR_ROW)) { rv = -1; break; }
+      SMG_PUTU(nmatch, DIFF_I) nmatch = 0; off--; j--;
+    }
+    if (rv) break;
+    SMG_PUTU(nmatch, DIFF_S)
+    SMG_PUTU(0, DIFF_M)
+  } while (0);
+#undef SMG_PUTU
+#undef SMG_U
+  if (rv) return rv;
+  *rs = i + 1; *qs = j + 1;
+  return (checksum != max_scor) ? -1 : n;
+}
+
 // The same for wider bands.  Columns jmin + c + 64m of lane c that are inside the band at step t differ by 128
 // diagonals, so a lane has at most (r - l) / 128 + 1 live columns; column m keeps its state in register slot m % NS.
 // The left neighbour of (lane c, slot s) is (lane c - 1, slot s), for lane 0 (lane 63, slot s - 1).
@@ -1390,12 +1438,22 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
       }
       SMG_SYNC();
       tq1 = phase_clock(); aph[1] += tq1 - tq0; tq0 = tq1;
+      int tb_dn = 0, tb_qs = 0, tb_rs = 0;
+      bool tb_done = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (!nerr && !skip && max_scor >= minscore && tW == 0 && x.rows_form) {      // row-major directions: traceback by the wave, on the scalar unit
+        tb_dn = traceback_uniform(dtmp, dtmpcap, &tb_qs, &tb_rs, band, dirm, max_i, max_j, max_scor, q, win, (int)M[0], (int)M[1], gi, ge);
+        tb_done = true;
+      }
+#else
+      (void)tb_dn; (void)tb_done;
+#endif
       SMG_LANE0 {
         int nsp = sp - 1, err = nerr;
         if (!err && !skip && max_scor >= minscore) {
-          int qs, rs;
+          int qs = tb_qs, rs = tb_rs;
           #if defined(__HIP_DEVICE_COMPILE__)
-          const int dn = traceback_scalar(dtmp, dtmpcap, &qs, &rs, band, dirm, max_i, max_j, max_scor, q, win, M, gi, ge, tW, &sg);
+          const int dn = tb_done ? tb_dn : traceback_scalar(dtmp, dtmpcap, &qs, &rs, band, dirm, max_i, max_j, max_scor, q, win, M, gi, ge, tW, &sg);
 #else
           const int dn = traceback_scalar(dtmp, dtmpcap, &qs, &rs, band, dirm, max_i, max_j, max_scor, q, win, M, gi, ge, tW);
 #endif
