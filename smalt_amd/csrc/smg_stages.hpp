@@ -1105,9 +1105,9 @@ __device__ inline int dpp_scan_max_excl(int x) {
   x = max(x, __builtin_amdgcn_update_dpp(neg, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
   return __builtin_amdgcn_update_dpp(neg, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
-template <class PW = const uint8_t *>
+template <class PW = const uint8_t *, class PD = uint8_t *>
 __device__ inline int band_track_rows(const Band &bp, PW q, PW win, int match, int mismatch, int gi, int ge,
-                                      uint8_t *dir, int *max_i, int *max_j) {
+                                      PD dir, int *max_i, int *max_j) {
   const int lane = (int)threadIdx.x;
   const int nrows = __builtin_amdgcn_readfirstlane(bp.s_len - bp.s_left), l = bp.l_edge, bw = bp.band_width;
   const int d = l + lane, qhi = bp.q_len - 1;
@@ -1119,7 +1119,7 @@ __device__ inline int band_track_rows(const Band &bp, PW q, PW win, int match, i
   // codes of the next row are loaded a row ahead (the read offset clamped into the read: inactive cells do not use it)
   int rbn = win[bp.s_left] & 7;
   int qn = q[d < 0 ? 0 : (d > qhi ? qhi : d)] & 7;
-  uint8_t *dp = dir + lane;
+  PD dp = dir + lane;
   for (int ip = 0; ip < nrows; ip++, dp += bw) {
     const int j = d + ip;
     const bool act = inband && j >= bp.q_left && j <= qhi;
@@ -1409,8 +1409,13 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
             else max_scor = band_track_strip<const uint8_t *, 16>(band, sg, q, win, p.match, p.mismatch, gi, ge, (uint32_t *)dirm, (int2 *)x.bnd, x.bndcap, (int2 *)x.ring, &max_i, &max_j);
           }
         } else if (band.band_width >= 1 && band.band_width <= 64 && rows_form) {
-          if (in_lds) max_scor = band_track_rows<PL>(band, (PL)q, (PL)win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j);
-          else max_scor = band_track_rows<const uint8_t *>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j);
+          // read, window and (usually) the direction bytes live in the LDS block: LDS-typed pointers (ds_read / ds_write with
+          // 32-bit addresses instead of flat accesses with 64-bit address arithmetic)
+          typedef SMG_LDSQ uint8_t *PLD;
+          const bool codes_lds = x.win_lds && win == x.win_lds;
+          if (codes_lds && dirm == x.dir_lds) max_scor = band_track_rows<PL, PLD>(band, (PL)q, (PL)win, p.match, p.mismatch, gi, ge, (PLD)dirm, &max_i, &max_j);
+          else if (codes_lds) max_scor = band_track_rows<PL, uint8_t *>(band, (PL)q, (PL)win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j);
+          else max_scor = band_track_rows<const uint8_t *, uint8_t *>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j);
         } else if (band.band_width >= 1 && band.band_width <= 64) {
           if (in_lds) max_scor = band_track_wave<PL>(band, (PL)q, (PL)win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j, tW);
           else max_scor = band_track_wave<const uint8_t *>(band, q, win, p.match, p.mismatch, gi, ge, dirm, &max_i, &max_j, tW);
