@@ -96,6 +96,9 @@ def main():
         if not a.paired:
             # the same job by smaltgpu-map: libsmaltgpu only (read ingest, GPU path, post-processing, report) -- no reference code
             prog = os.path.join(ROOT, "smalt_amd", "smaltgpu-map")
+            # once on the small file first: the first large device allocations after this script freed its 3 Gbp arrays are slow
+            # (2 s per mapper, against 15 ms in a run of the program on its own: tools/run_native.sh)
+            subprocess.run([prog, "-r", "-1", "-f", "cigar", "-n", str(a.threads), "-o", os.path.join(tmp, "n0.cig"), prefix, small], capture_output=True)
             r = subprocess.run([prog, "-r", "-1", "-f", "cigar", "-n", str(a.threads), "-o", os.path.join(tmp, "n1.cig"), prefix, gpu_fq], capture_output=True,
                                env=dict(os.environ, SMALTGPU_MAP_VERBOSE="1"))
             if r.returncode:
