@@ -138,3 +138,62 @@ def test_report_matches_reference_program(case, oracle_built, tmp_path):
     assert len(gl) == len(el)
     for i, (x, y) in enumerate(zip(gl, el)):
         assert x == y, (i, x, y)
+
+
+@pytest.mark.parametrize("style", [None, "wrapped", "fasta"])
+@pytest.mark.parametrize("window", [700, 4096, 50000])
+def test_reads_parse_in_windows_equals_whole_file(style, window, oracle_built, tmp_path):
+    """smaltgpu-map hands the parser one window of the input after the other (is_last = 0: a record that may go on behind
+    the window is left for the next call, `consumed` says where that one starts); every window size must give the reads of the
+    whole file -- plain FASTQ (parallel ranges), wrapped FASTQ with blank lines and CRLF, FASTA."""
+    from smalt_amd import api
+    L = api.lib()
+    entry = [e for e in gu.MANIFEST_ALL if e["tag"] == "g_k13s6_nq"][0]          # variable read lengths, Ns
+    fx = gu.unpack(entry, tmp_path)
+    text = open(gu.reshape_reads(fx["fq"], style, str(tmp_path / "r.txt")) if style else fx["fq"], "rb").read()
+    rs = L.smaltgpu_reads_create()
+
+    def collect(view):
+        out = []
+        for i in range(view.nreads):
+            a, b = view.read_off[i], view.read_off[i + 1]
+            out.append((C.string_at(C.addressof(view.names.contents) + view.name_off[i]), bytes(view.bases[a:b]),
+                        bytes(view.quals[a:b]) if view.has_qual else None))
+        return out
+    try:
+        view = api.ReadsView()
+        assert L.smaltgpu_reads_parse(rs, text, len(text), 1, 0, 2, C.byref(view)) == 0
+        whole = collect(view)
+        assert len(whole) == 200 and view.consumed == len(text)
+        got, pos, win = [], 0, window
+        while pos < len(text):
+            chunk = text[pos:pos + win]
+            last = pos + win >= len(text)
+            assert L.smaltgpu_reads_parse(rs, chunk, len(chunk), 1 if last else 0, 37, 3, C.byref(view)) == 0, L.smaltgpu_last_error()
+            if view.nreads == 0 and not last:
+                win *= 2                                    # not one complete record in the window
+                continue
+            assert view.nreads <= 37 and (view.nreads > 0 or last)
+            got += collect(view)
+            assert view.consumed > 0 or last
+            pos += view.consumed if view.nreads else len(chunk)
+            win = window
+        assert got == whole
+    finally:
+        L.smaltgpu_reads_free(rs)
+
+
+def test_reads_parse_rejects_broken_input(oracle_built):
+    from smalt_amd import api
+    L = api.lib()
+    rs = L.smaltgpu_reads_create()
+    view = api.ReadsView()
+    try:
+        for bad in (b"ACGT\nACGT\n", b"@r1\nACGT\n+\nII\n@r2\nAC\n+\nII\n"):
+            assert L.smaltgpu_reads_parse(rs, bad, len(bad), 1, 0, 1, C.byref(view)) != 0
+        assert L.smaltgpu_reads_parse(rs, b"", 0, 1, 0, 1, C.byref(view)) == 0 and view.nreads == 0
+        ok = b">s1 x\nacgu\nNN-\n>s2\nRYK\n"                   # FASTA: lower case, U, a non-letter, IUPAC letters
+        assert L.smaltgpu_reads_parse(rs, ok, len(ok), 1, 0, 1, C.byref(view)) == 0 and view.nreads == 2 and not view.has_qual
+        assert bytes(view.bases[0:view.read_off[2]]) == b"ACGTNNNRYK"
+    finally:
+        L.smaltgpu_reads_free(rs)
