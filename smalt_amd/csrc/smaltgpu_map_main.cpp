@@ -52,7 +52,8 @@ void usage() {
           "  -q <int>   base quality threshold for k-mer words\n"
           "  -n <int>   host threads for parsing, post-processing and formatting (default: up to 16)\n"
           "  -B <int>   reads per GPU batch (default 262144)\n"
-          "  -g <int>   device (default 0)\n"
+          "  -g <list>  devices, e.g. 0 or 0,1,2,3 (default 0): the index is read once and copied device to device, every device gets\n"
+          "             two mappers, blocks go to whichever is free\n"
           "single reads only; paired reads (-i -j -l -p), split reads (-p) and -w go through the bound reference program (INTEGRATION.md)\n");
   exit(2);
 }
@@ -125,7 +126,8 @@ struct Source {
 
 int main(int argc, char **argv) {
   const char *fmt = "cigar", *oufil = nullptr;
-  int m = -1, d = 0, seed = 0, q = 0, nthreads = 0, device = 0;
+  int m = -1, d = 0, seed = 0, q = 0, nthreads = 0;
+  std::vector<int> devices;
   bool d_given = false, randrepeat = true, exhaustive = false;
   double minid = 0.0, mincover = 0.0;
   long batch = 262144;
@@ -150,7 +152,7 @@ int main(int argc, char **argv) {
       case 'q': q = atoi(val); break;
       case 'n': nthreads = atoi(val); break;
       case 'B': batch = atol(val); if (batch < 1 || batch > (1L << 22)) die("-B out of range"); break;
-      case 'g': device = atoi(val); break;
+      case 'g': for (const char *c = val; *c;) { devices.push_back(atoi(c)); while (*c && *c != ',') c++; if (*c) c++; } break;
     }
   }
   if (argc - a != 2) usage();
@@ -192,8 +194,14 @@ int main(int argc, char **argv) {
   setvbuf(ou, oubuf, _IOFBF, sizeof(oubuf));
 
   const auto t_start = std::chrono::steady_clock::now();
-  smaltgpu_index *ix = nullptr;
-  if (smaltgpu_index_load(&ix, prefix, device)) die("index", smaltgpu_last_error());
+  if (devices.empty()) devices.push_back(0);
+  if (devices.size() > 16) die("-g: at most 16 devices");
+  const int ndev = (int)devices.size();
+  std::vector<smaltgpu_index *> ixs((size_t)ndev, nullptr);
+  if (smaltgpu_index_load(&ixs[0], prefix, devices[0])) die("index", smaltgpu_last_error());
+  for (int dv = 1; dv < ndev; dv++)                       // the reference's workers share one read-only index; here every device gets an image of it
+    if (smaltgpu_index_clone(&ixs[(size_t)dv], ixs[0], devices[(size_t)dv])) die("index copy", smaltgpu_last_error());
+  smaltgpu_index *ix = ixs[0];
   const auto t_index = std::chrono::steady_clock::now();
   const char *const *seqnames; const uint64_t *sop; int64_t nseq;
   if (smaltgpu_index_seqnames(ix, &seqnames, &sop, &nseq)) die("index", smaltgpu_last_error());
@@ -215,15 +223,16 @@ int main(int argc, char **argv) {
     if (hlen && fwrite(htxt, 1, hlen, ou) != hlen) die("write error");
   }
 
-  enum { NBLK = 4, NWORK = 2 };
-  Block blk[NBLK];
+  enum { MAXWORK = 32 };
+  const int NWORK = 2 * ndev, NBLK = NWORK + 2;
+  std::vector<Block> blk((size_t)NBLK);
   for (Block &b : blk) b.rs = smaltgpu_reads_create();
   std::mutex mu;
   std::condition_variable cv;
   uint64_t n_parsed = 0, n_taken = 0, n_written = 0;      // block serial numbers: block k lives in blk[k % NBLK]
   bool input_done = false, failed = false;
   uint64_t n_blocks_total = ~0ull;
-  double t_parse = 0, t_create[2] = {0, 0}, t_map[2] = {0, 0}, t_post[2] = {0, 0};          // seconds per stage (SMALTGPU_MAP_VERBOSE)
+  double t_parse = 0, t_create[MAXWORK] = {0}, t_map[MAXWORK] = {0}, t_post[MAXWORK] = {0};          // seconds per stage (SMALTGPU_MAP_VERBOSE)
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 
   std::thread parser([&] {
@@ -255,7 +264,7 @@ int main(int argc, char **argv) {
   });
 
   struct Worker { smaltgpu_mapper *mp = nullptr; smaltgpu_post *post = nullptr; uint32_t cap_reads = 0, cap_len = 0; bool busy = false; };
-  Worker wk[NWORK];
+  Worker wk[MAXWORK];
   auto work = [&](int w) {
     Worker &W = wk[w];
     W.post = smaltgpu_post_create();
@@ -276,7 +285,7 @@ int main(int argc, char **argv) {
         W.mp = nullptr;
         const uint32_t cr = b.v.nreads > (uint32_t)batch ? b.v.nreads : (uint32_t)batch, cl = (b.maxlen + 31u) & ~31u;
         smaltgpu_mapper_opts mo = {0, 28};                 // two mappers share the device: 28 GB of candidate slots each
-        if (smaltgpu_mapper_create_ex(&W.mp, ix, cr, cl > W.cap_len ? cl : W.cap_len, &mo)) err = smaltgpu_last_error();
+        if (smaltgpu_mapper_create_ex(&W.mp, ixs[(size_t)(w % ndev)], cr, cl > W.cap_len ? cl : W.cap_len, &mo)) err = smaltgpu_last_error();
         else { W.cap_reads = cr; W.cap_len = cl > W.cap_len ? cl : W.cap_len; }
       }
       t1 = now(); t_create[w] += t1 - t0; t0 = t1;
@@ -291,8 +300,8 @@ int main(int argc, char **argv) {
       { std::lock_guard<std::mutex> lk(mu); b.worker = w; if (!err.empty()) { b.err = err; failed = true; } b.state = 2; cv.notify_all(); }
     }
   };
-  std::thread workers[NWORK];
-  for (int w = 0; w < NWORK; w++) workers[w] = std::thread(work, w);
+  std::vector<std::thread> workers;
+  for (int w = 0; w < NWORK; w++) workers.emplace_back(work, w);
 
   std::string failure;
   uint64_t nreads_total = 0;
@@ -323,15 +332,17 @@ int main(int argc, char **argv) {
   for (Worker &W : wk) { if (W.mp) smaltgpu_mapper_free(W.mp); if (W.post) smaltgpu_post_free(W.post); }
   for (Block &b : blk) smaltgpu_reads_free(b.rs);
   smaltgpu_report_free(rep);
-  smaltgpu_index_free(ix);
+  for (smaltgpu_index *x : ixs) smaltgpu_index_free(x);
   if (ou != stdout) { if (fclose(ou)) failure = "write error"; } else fflush(ou);
   if (failed || !failure.empty()) die("failed", failure.c_str());
   if (getenv("SMALTGPU_MAP_VERBOSE")) {
     const double ti = std::chrono::duration<double>(t_index - t_start).count(), tm = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_index).count();
     fprintf(stderr, "smaltgpu-map: %llu reads, index load %.3f s, reads in to lines out %.3f s (%.0f reads/s)\n", (unsigned long long)nreads_total, ti, tm,
             tm > 0 ? (double)nreads_total / tm : 0.0);
-    fprintf(stderr, "smaltgpu-map: stages [s]: parse %.3f | mapper set-up %.3f %.3f  map %.3f %.3f  post %.3f %.3f | wait %.3f emit %.3f write %.3f\n", t_parse, t_create[0],
-            t_create[1], t_map[0], t_map[1], t_post[0], t_post[1], t_wait, t_emit, t_write);
+    double tc = 0, tm_ = 0, tp = 0;
+    for (int w = 0; w < NWORK; w++) { tc += t_create[w]; tm_ += t_map[w]; tp += t_post[w]; }
+    fprintf(stderr, "smaltgpu-map: stages [s]: parse %.3f | %d workers on %d device(s), mean per worker: mapper set-up %.3f  map %.3f  post %.3f | wait %.3f emit %.3f write %.3f\n",
+            t_parse, NWORK, ndev, tc / NWORK, tm_ / NWORK, tp / NWORK, t_wait, t_emit, t_write);
   }
   return 0;
 }

@@ -46,12 +46,13 @@ def test_program_large_batch_equals_small_batches(fixtures):
     fxs, tmp = fixtures
     fx = fxs["g_k13s6_ties"]
     outs = []
-    for extra in (["-B", "50", "-n", "2"], ["-n", "8"]):
+    # "-g 0,0": two images of the index (the second a device-to-device copy), four mappers -- the N-device path on one GPU
+    for extra in (["-B", "50", "-n", "2"], ["-n", "8"], ["-B", "20", "-g", "0,0"]):
         out = str(tmp / "cmp.txt")
         r = subprocess.run([PROG, "-r", "11", "-f", "sam:nohead"] + extra + ["-o", out, fx["prefix"], fx["fq"]], capture_output=True)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         outs.append(open(out, "rb").read())
-    assert outs[0] == outs[1] and outs[0].count(b"\n") >= 220
+    assert outs[0] == outs[1] == outs[2] and outs[0].count(b"\n") >= 220
 
 
 def test_program_reads_gzip_input(fixtures):

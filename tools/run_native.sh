@@ -1,6 +1,7 @@
 #!/bin/bash
 # Diagnostic: the bench reference + reads on disk once, then smaltgpu-map under several settings (stage times on stderr).
-# usage: tools/run_native.sh <reads> ; settings come from the NATIVE_ENVS variable ("A=1 B=2;C=3")
+# usage: tools/run_native.sh <reads> ; settings come from the NATIVE_ENVS variable ("A=1 B=2;C=3"), extra options from NATIVE_ARGS
+# (run-to-run spread on one box: 410-560 k reads/s for the same binary, mostly in the first device allocations)
 set -e
 N=${1:-2000000}
 T=$(mktemp -d /tmp/native.XXXX)
@@ -31,6 +32,7 @@ PY
 IFS=';' read -ra SETS <<< "${NATIVE_ENVS:-X=1}"
 for e in "${SETS[@]}"; do
   echo "== $e"
-  env $e SMALTGPU_MAP_VERBOSE=1 ./smalt_amd/smaltgpu-map -r -1 -f cigar -n 16 -o $T/out.cig $T/hs $T/r.fq 2>&1 | grep smaltgpu-map
+  env $e SMALTGPU_MAP_VERBOSE=1 ./smalt_amd/smaltgpu-map -r -1 -f cigar -n 16 $NATIVE_ARGS -o $T/out.cig $T/hs $T/r.fq 2>&1 | grep smaltgpu-map
+  rm -f $T/out.cig
 done
 rm -rf $T
