@@ -53,7 +53,7 @@ void usage() {
           "  -n <int>   host threads for parsing, post-processing and formatting (default: up to 16)\n"
           "  -B <int>   reads per GPU batch (default 262144)\n"
           "  -g <list>  devices, e.g. 0 or 0,1,2,3 (default 0): the index is read once and copied device to device, every device gets\n"
-          "             two mappers, blocks go to whichever is free\n"
+          "             two mappers (SMALTGPU_MAP_WORKERS: 1-4), blocks go to whichever is free\n"
           "single reads only; paired reads (-i -j -l -p), split reads (-p) and -w go through the bound reference program (INTEGRATION.md)\n");
   exit(2);
 }
@@ -224,7 +224,11 @@ int main(int argc, char **argv) {
   }
 
   enum { MAXWORK = 32 };
-  const int NWORK = 2 * ndev, NBLK = NWORK + 2;
+  // mappers per device: while one block is post-processed and waits for its turn to be printed, the others keep the GPU busy
+  int per_dev = 2;
+  if (const char *e = getenv("SMALTGPU_MAP_WORKERS")) { const int v = atoi(e); if (v >= 1 && v <= 4) per_dev = v; }
+  if (per_dev * ndev > MAXWORK) per_dev = MAXWORK / ndev;
+  const int NWORK = per_dev * ndev, NBLK = NWORK + 2;
   std::vector<Block> blk((size_t)NBLK);
   for (Block &b : blk) b.rs = smaltgpu_reads_create();
   std::mutex mu;
@@ -284,7 +288,7 @@ int main(int argc, char **argv) {
         if (W.mp) smaltgpu_mapper_free(W.mp);
         W.mp = nullptr;
         const uint32_t cr = b.v.nreads > (uint32_t)batch ? b.v.nreads : (uint32_t)batch, cl = (b.maxlen + 31u) & ~31u;
-        smaltgpu_mapper_opts mo = {0, 28};                 // two mappers share the device: 28 GB of candidate slots each
+        smaltgpu_mapper_opts mo = {0, (uint32_t)(per_dev <= 2 ? 28 : 18)};      // the mappers of a device share its memory: candidate slots of 18-28 GB each
         if (smaltgpu_mapper_create_ex(&W.mp, ixs[(size_t)(w % ndev)], cr, cl > W.cap_len ? cl : W.cap_len, &mo)) err = smaltgpu_last_error();
         else { W.cap_reads = cr; W.cap_len = cl > W.cap_len ? cl : W.cap_len; }
       }
