@@ -27,6 +27,11 @@ CASES = [
     dict(k=13, s=6, nseq=3, seqlen=400_000, rl=(60, 160), par=dict(cov_frac=0.3)),
     dict(k=13, s=6, nseq=2, seqlen=300_000, rl=(250, 2500), par={}),                     # long reads, many hits
     dict(k=13, s=6, nseq=3, seqlen=400_000, rl=(60, 160), par=dict(cov_frac=0.7)),       # min_ktup > 1: sequential candidate stage
+    # K3's row form scans the horizontal gap score, which is exact for gap open >= gap extension: the boundary case ...
+    dict(k=13, s=6, nseq=3, seqlen=400_000, rl=(60, 160), par=dict(match=1, mismatch=-2, gap_init=-3, gap_ext=-3)),
+    # ... and penalties on the other side of it, which keep the anti-diagonal form
+    dict(k=13, s=6, nseq=3, seqlen=400_000, rl=(60, 160), par=dict(match=2, mismatch=-3, gap_init=-2, gap_ext=-4)),
+    dict(k=13, s=6, nseq=3, seqlen=400_000, rl=(40, 250), par=dict(match=3, mismatch=-4, gap_init=-8, gap_ext=-1, best=False, below_max=30)),
 ]
 
 

@@ -72,3 +72,19 @@ def test_program_reads_gzip_input(fixtures):
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         outs.append(open(out, "rb").read())
     assert outs[0] == outs[1] and outs[0].count(b"\n") == 250
+
+
+def test_program_with_the_anti_diagonal_band_form(fixtures):
+    """SMALTGPU_ALIGN_ANTIDIAG=1 keeps K3's older form for narrow bands (band_track_wave + the one-lane traceback) reachable:
+    the program must print the same lines with it (the row form is the default everywhere else)."""
+    fxs, tmp = fixtures
+    for tag, variant in (("g_k13s6_ties", "sam"), ("g_k11s2_d20", "cigar")):
+        case = [c for c in REPORT_ALL if c["tag"] == tag and c["variant"] == variant][0]
+        out = str(tmp / "anti.txt")
+        r = subprocess.run([PROG] + case["opts"] + ["-o", out, fxs[tag]["prefix"], fxs[tag]["fq"]], capture_output=True,
+                           env=dict(os.environ, SMALTGPU_ALIGN_ANTIDIAG="1"))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        with gzip.open(os.path.join(gu.GOLD, "%s.%s.out.gz" % (tag, variant)), "rb") as g:
+            exp = [x for x in g.read().split(b"\n") if not x.startswith(b"@PG")]
+        got = [x for x in open(out, "rb").read().split(b"\n") if not x.startswith(b"@PG")]
+        assert got == exp
