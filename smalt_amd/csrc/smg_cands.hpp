@@ -801,6 +801,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
 
     if (mode == 1) {
       uint32_t *g_cur = gt + 4 * tabn;                 // per-list cursor
+      auto marks = wl.reg_num;                          // [W] list starts among the hits of the window under construction
       SMG_PAR_CHUNKS(base, nlist) { const uint32_t l = base + SMG_LANE; if (l < nlist) g_cur[l] = 0; }
       SMG_SYNC();
       uint32_t carry = 0, remaining = total, reg_base = 0, gproc = 0, last_grp = ~0u;
@@ -827,6 +828,10 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
           }
         }
         bound = wave_min_u64(bound);
+        // marks[h] = 1 + the list whose first hit of this window is hit h (0 elsewhere): a running maximum over the hits
+        // then gives every hit its list without a search (the array is one of the working set's that is idle until S4)
+        SMG_PAR_CHUNKS(base, room + nlist) { const uint32_t i = base + SMG_LANE; if (i < room + nlist) marks[i] = 0; }      // (a window takes at most room + nlist hits)
+        SMG_SYNC();
         // per list: elements below the bound
         uint32_t cnt_tot = 0;
         SMG_PAR_CHUNKS(base, nlist) {
@@ -874,7 +879,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
 #if defined(__HIP_DEVICE_COMPILE__)
           for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if ((int)SMG_LANE >= o) incl += v; }
 #endif
-          if (l < nlist) g_pfx[l] = cnt_tot + incl - cnt;
+          if (l < nlist) { g_pfx[l] = cnt_tot + incl - cnt; if (cnt && cnt_tot + incl - cnt < room + nlist) marks[cnt_tot + incl - cnt] = (uint16_t)(l + 1); }
 #if defined(__HIP_DEVICE_COMPILE__)
           cnt_tot += (uint32_t)__shfl((int)incl, 63);
 #else
@@ -888,14 +893,17 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
         uint32_t sq_hi = seqbyseq ? (uint32_t)(bound >> KEY_DIAGBITS) : 0u;
         if (sq_hi >= (uint32_t)ix.nseq) sq_hi = (uint32_t)ix.nseq - 1;
         prev_bound = bound;
+        uint32_t id_carry = 0;
         for (uint32_t base = 0; base < cnt_tot; base += 4 * SMG_NLANES) {      // four independent index reads in flight per lane
-          uint32_t pos[4], qo[4];
+          uint32_t pos[4], qo[4], mk[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const uint32_t h = base + (uint32_t)u * SMG_NLANES + SMG_LANE; mk[u] = h < cnt_tot ? (uint32_t)marks[h] : 0u; }
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const uint32_t h = base + (uint32_t)u * SMG_NLANES + SMG_LANE;
+            const uint32_t id = wave_scan_max_u32(mk[u], id_carry, &id_carry);
             if (h < cnt_tot) {
-              uint32_t lo = 0, hi = nlist;
-              while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g_pfx[mid] <= h) lo = mid; else hi = mid; }
+              const uint32_t lo = id - 1;
               pos[u] = ix.pos[g_poff[lo] + g_cur[lo] + (h - g_pfx[lo])]; qo[u] = g_qo[lo];
             }
           }

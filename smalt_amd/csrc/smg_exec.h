@@ -101,6 +101,27 @@ SMG_HD inline bool wave_any(bool f) {
 #endif
 }
 
+// inclusive running maximum over the lanes, continued from `carry` (the maximum of everything before lane 0); returns the
+// lane's value, *carry_out = the wave's maximum (wave-uniform)
+SMG_HD inline uint32_t wave_scan_max_u32(uint32_t v, uint32_t carry, uint32_t *carry_out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int x = (int)v;                                  // values are small non-negative numbers: 0 is the identity
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112 /* row_shr:2 */, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114 /* row_shr:4 */, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118 /* row_shr:8 */, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
+  x = max(x, (int)carry);
+  *carry_out = (uint32_t)__builtin_amdgcn_readlane(x, 63);
+  return (uint32_t)x;
+#else
+  const uint32_t r = v > carry ? v : carry;
+  *carry_out = r;
+  return r;
+#endif
+}
+
 SMG_HD inline uint32_t bcast_lane0(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
