@@ -45,8 +45,8 @@ struct ReadBlock {                       // what one parser thread produced
   std::vector<uint8_t> bases, quals;
   std::vector<uint64_t> off, name_off, rec_end;      // rec_end: offset in the text behind each record
   std::vector<char> names;
-  bool has_qual = true, fasta_seen = false;
-  void clear() { bases.clear(); quals.clear(); off.assign(1, 0); name_off.assign(1, 0); names.clear(); rec_end.clear(); has_qual = true; fasta_seen = false; }
+  bool has_qual = true;
+  void clear() { bases.clear(); quals.clear(); off.assign(1, 0); name_off.assign(1, 0); names.clear(); rec_end.clear(); has_qual = true; }
 };
 
 // ---- the plain four-line FASTQ record, one memchr per line --------------------------------------------------------
@@ -71,7 +71,7 @@ long strict_record(const char *p, const char *end, bool is_last, ReadBlock &o) {
   if (sl && l2[sl - 1] == '\r') sl--;
   if (ql && l4[ql - 1] == '\r') ql--;
   if (sl != ql || sl == 0) return 0;
-  if (l4[0] == '@' || l4[0] == '>' || l4[0] == '+') { /* a prompt character opens the quality line: only safe because the length matches */ }
+  // (a quality line may open with a prompt character: the general rules only end a quality string once it has the sequence's length)
   const char *nm = p + 1, *nme = l1e;
   while (nm < nme && isspace((unsigned char)*nm)) nm++;
   const char *t = nm;
@@ -92,7 +92,7 @@ long strict_record(const char *p, const char *end, bool is_last, ReadBlock &o) {
 struct Stream { const char *p, *end; };
 
 // header line: -> 0 ok, 1 end of text before any prompt, -2 not a prompt.  name = first word behind the prompt.
-int read_header(Stream &s, int *prompt, std::string &name, bool *saw_eol) {
+int read_header(Stream &s, int *prompt, std::string &name) {
   bool was_space = true, in_name = true, eol = false;
   *prompt = 0; name.clear();
   while (s.p < s.end && !eol) {
@@ -109,7 +109,6 @@ int read_header(Stream &s, int *prompt, std::string &name, bool *saw_eol) {
     }
     if (in_name) name.push_back((char)c);                // later words of the header are not used
   }
-  *saw_eol = eol;
   if (!*prompt) return 1;
   return 0;
 }
@@ -139,9 +138,9 @@ int general_parse(const char *text, const char *end, bool is_last, uint32_t max_
     const char *rec0 = s.p;
     const size_t b0 = o.bases.size(), n0 = o.names.size();
     int this_prompt = '+', next_prompt = 0;
-    bool eol = false, eof = false;
+    bool eof = false;
     while (this_prompt == '+') {                               // seqFastqRead skips stray quality blocks (sequence.c:1968-1977)
-      const int rv = read_header(s, &this_prompt, name, &eol);
+      const int rv = read_header(s, &this_prompt, name);
       if (rv == 1) { eof = true; break; }
       if (rv < 0) { msg = "not in FASTA/FASTQ format (a header line was expected)"; return -1; }
       o.bases.resize(b0);
@@ -153,7 +152,7 @@ int general_parse(const char *text, const char *end, bool is_last, uint32_t max_
       int qp = 0;
       std::string qname;
       std::vector<uint8_t> q;
-      const int rv = read_header(s, &qp, qname, &eol);
+      const int rv = read_header(s, &qp, qname);
       if (rv || qp != '+') { msg = "not in FASTA/FASTQ format (quality header)"; return -1; }
       int p2 = 0;
       read_symbols(s, q, o.bases.size() - b0, &p2, false);
@@ -162,7 +161,7 @@ int general_parse(const char *text, const char *end, bool is_last, uint32_t max_
       if (o.has_qual) { o.quals.resize(b0); o.quals.insert(o.quals.end(), q.begin(), q.end()); }
       fastq = true;
     } else if (!next_prompt && !is_last) { o.bases.resize(b0); o.names.resize(n0); s.p = rec0; break; }
-    if (!fastq) { o.has_qual = false; o.fasta_seen = true; }
+    if (!fastq) o.has_qual = false;
     o.names.insert(o.names.end(), name.begin(), name.end()); o.names.push_back('\0');
     o.off.push_back(o.bases.size()); o.name_off.push_back(o.names.size());
     o.rec_end.push_back((uint64_t)(s.p - text));
