@@ -343,8 +343,8 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
     if (f && lw.prune_on && (LONG ? lw.ccov[m] : (uint32_t)w.cflag[m]) + lw.prune_cdf0 < pthr) f = false;
     const uint32_t slot = compact_slot(f, nc);
     if (f) {
-      uint32_t lo = 0, hi = nreg;                // hit region of segment m
-      while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)w.reg_first[mid] <= m) lo = mid; else hi = mid; }
+      uint32_t lo = 0, hi = nreg;                // hit region of segment m (kept in the 40-byte record only: short reads skip the search)
+      if (LONG) while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)w.reg_first[mid] <= m) lo = mid; else hi = mid; }
       const uint32_t grp = seqbyseq ? (key_grp(w.dat[w.seed_first[w.segm_first[m]]]) & ((1u << KEY_SEQBITS) - 1)) : 0u;
       int32_t seqidx = seqbyseq ? (int32_t)grp : -1;
       if (ivmap) seqidx = ivmap[seqidx].sx;       // interval-restricted call: the key's group is the interval number (rmap.c:486-490)
