@@ -151,7 +151,7 @@ int main(int argc, char **argv) {
       case 'c': mincover = atof(val); if (mincover < 0) die("-c out of range"); break;
       case 'q': q = atoi(val); break;
       case 'n': nthreads = atoi(val); break;
-      case 'B': batch = atol(val); if (batch < 1 || batch > (1L << 22)) die("-B out of range"); break;
+      case 'B': batch = atol(val); if (batch < 1 || batch > (1L << 20)) die("-B out of range (1 .. 1048576)"); break;
       case 'g': for (const char *c = val; *c;) { devices.push_back(atoi(c)); while (*c && *c != ',') c++; if (*c) c++; } break;
     }
   }
