@@ -78,7 +78,11 @@ def _make(case, seed):
     return seqs, reads, quals
 
 
-@pytest.mark.parametrize("seedoff", [0, 77, 154], ids=["seedA", "seedB", "seedC"])
+# SMALT_FUZZ_SEEDS="1000,2000": extra seeds for a stress run (python -m pytest tests/test_gpu_fuzz.py -m gpu)
+_EXTRA = [int(x) for x in __import__("os").environ.get("SMALT_FUZZ_SEEDS", "").split(",") if x.strip()]
+
+
+@pytest.mark.parametrize("seedoff", [0, 77, 154] + _EXTRA, ids=["seedA", "seedB", "seedC"] + ["seed%d" % x for x in _EXTRA])
 @pytest.mark.parametrize("ci", range(len(CASES)), ids=["c%d-k%ds%d" % (i, c["k"], c["s"]) for i, c in enumerate(CASES)])
 def test_random_workload_matches_oracle(ci, seedoff, oracle_built, tmp_path):
     from smalt_amd import api
