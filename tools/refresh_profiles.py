@@ -9,6 +9,8 @@ tot=sum(float(r['TotalDurationNs']) for r in rows)
 out=["# rocprofv3 --kernel-trace --stats  (round %d)" % RN,
 "# command: rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_main -o bench -- python3 bench.py --steps 1 --warmup 1 --reads 524288 --no-cpu-baseline --no-host-buffers",
 "# 2 passes (warmup + timed) x 2 sub-batches of 262144 reads = 4 launches per kernel; durations in microseconds",
+"# (k_cands and k_align: 8 -- each is followed by its second pass over the reads the first one deferred, a launch that ends at",
+"#  once when there are none: their time per sub-batch is total_us / 4)",
 "# (names shortened; non-smg kernels are torch's reference/index/read generation in setup)",
 "%-62s %6s %14s %14s %7s" % ("kernel","calls","total_us","avg_us","pct")]
 for r in sorted(smg,key=lambda r:-float(r['TotalDurationNs'])):
