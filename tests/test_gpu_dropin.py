@@ -71,6 +71,15 @@ def test_smalt_map_prints_the_same(k, s, nchr, chrlen, rlen, opts, tmp_path):
         assert len(a) == len(b)
         diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
         assert not diff, (extra, diff[:3])
+    # the same command line through smaltgpu-map, the program made of the library alone (ingest, GPU path, post-processing,
+    # report: SURVEY 8f N4 + N1); -O (keep the input order) is what it always does
+    prog = os.path.join(ROOT, "smalt_amd", "smaltgpu-map")
+    r = subprocess.run([prog] + [o for o in opts if o != "-O"] + ["-B", "500", "-o", out_gpu, pre, fq], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    b = [ln for ln in open(out_gpu).read().split("\n") if not ln.startswith("@PG")]
+    assert len(a) == len(b)
+    diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
+    assert not diff, ("smaltgpu-map", diff[:3])
 
 
 @pytest.mark.skipif(not (os.path.exists(SMALT) and os.path.exists(SMALT_GPU)), reason="reference binaries not built (make -C oracle ref ref_gpu)")
