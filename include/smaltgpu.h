@@ -180,6 +180,41 @@ int smaltgpu_map_batch_ctx(smaltgpu_mapper *m, const uint8_t *bases, const uint8
 int smaltgpu_hit_totals(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
                         const smaltgpu_params *par, uint32_t *nhits);
 
+/* ---- paired reads, whole: rmapPair (rmap.h:175-194, rmap.c:1744-2112) for a BLOCK of pairs -------------------
+ * smaltgpu_map_pairs runs the block through the rounds above -- hit totals, first mate, second mate restricted, second mate
+ * again, first mate again over the on-the-fly index; each round one batch of smaltgpu_map_batch_ctx -- and takes the decisions
+ * between them itself: the post-call pass of every call (smaltgpu_postprocess's rules), the proper-pair probe
+ * (resultSetFindProperPairs, resultpairs.c:1162), the search intervals (setupInterValFromResultSet, rmap.c:354).  What comes
+ * back is a `smaltgpu_pairs`: per pair the two alignment sets as rmapPair leaves them in rmp->rsrp / rmp->rsmp and the pair
+ * flags (*pairflgp).  smaltgpu_report_emit_pairs does the rest of the reference's flow for a pair: resultSetFindPairs
+ * (resultpairs.c:1116), the output filters, resultSetAddPairToReport (:1222) and the CIGAR / SAM lines of both mates
+ * (report.c:1758).  `par` as for single reads (rmapPair maps best-only: min_swatscor_below_max is taken as 0); reads and mates
+ * in the batch layout of smaltgpu_map_batch, pair i = (read i of the first, read i of the second batch). */
+enum { SMALTGPU_LIB_PE = 1, SMALTGPU_LIB_MP = 2, SMALTGPU_LIB_PP = 3, SMALTGPU_LIB_ANY = 4 };   /* -l pe | mp | pp (RSLTPAIRLIB_*, resultpairs.h:68-82) */
+typedef struct smaltgpu_pair_opts {
+  int32_t insert_min, insert_max;      /* -j, -i: d_min, d_max of rmapPair */
+  int32_t library;                     /* SMALTGPU_LIB_* */
+  int32_t every_pair;                  /* != 0: the unrestricted round for every pair (-x: RMAPFLG_ALLPAIR, smalt.c:533) */
+  int32_t nthreads;                    /* host threads for the work between the rounds */
+} smaltgpu_pair_opts;
+typedef struct smaltgpu_pair_info {
+  uint8_t pairflg;                     /* RSLTPAIRFLG_* (resultpairs.h:52-66): PAIRED 0x01, RAREMATE 0x02, RESTRICT_1st 0x04, RESTRICT_2nd 0x08 */
+  uint8_t rounds;                      /* bit r: the pair took part in round r (0 first mate, 1 second mate restricted, 2 second mate again, 3 first mate again) */
+  uint16_t nali[2];                    /* alignments that survived the post-call pass, read and mate */
+} smaltgpu_pair_info;
+typedef struct smaltgpu_pairs smaltgpu_pairs;
+smaltgpu_pairs *smaltgpu_pairs_create(void);
+void smaltgpu_pairs_free(smaltgpu_pairs *p);
+int smaltgpu_map_pairs(smaltgpu_mapper *m, const uint8_t *bases1, const uint8_t *quals1, const uint64_t *read_off1, const uint8_t *bases2,
+                       const uint8_t *quals2, const uint64_t *read_off2, uint32_t npairs, const smaltgpu_params *par, const smaltgpu_pair_opts *po,
+                       smaltgpu_pairs *out);
+/* what a block looked like: per pair the flags and counts above; calls[4] (may be NULL) = mapping calls per round; round_ms[4]
+ * (may be NULL) = host wall time of each round's batch incl. its copies */
+int smaltgpu_pairs_info(const smaltgpu_pairs *p, uint32_t *npairs, const smaltgpu_pair_info **info, uint64_t *calls, double *round_ms);
+/* the index a mapper was created on, and the batch it was sized for (smaltgpu_map_pairs takes blocks of up to max_batch_reads pairs) */
+const smaltgpu_index *smaltgpu_mapper_index(const smaltgpu_mapper *m);
+int smaltgpu_mapper_capacity(const smaltgpu_mapper *m, uint32_t *max_batch_reads, uint32_t *max_read_len, uint64_t *max_bases);
+
 /* Same with the inputs already resident in HBM (device pointers); results stay on the device
  * until smaltgpu_fetch_results().  Used by bench.py so that the timed region starts with the
  * reads in HBM. */
@@ -288,6 +323,11 @@ int smaltgpu_report_header(smaltgpu_report *rp, const char *const *seqnames, con
  * -r <seed>) draws from drand48() in read order: seed it with srand48 as RANSEED does (randef.h:19). */
 int smaltgpu_report_emit(smaltgpu_report *rp, const smaltgpu_post_out *post, const smaltgpu_batch_out *raw, const smaltgpu_reads_view *reads,
                          const char *const *seqnames, int64_t nseq, const smaltgpu_report_opts *op, int nthreads, const char **text, uint64_t *len);
+/* the lines of a block of pairs: both mates of pair 0, both mates of pair 1, ... (reportWrite, report.c:1758).  `reads` / `mates` =
+ * the parsed blocks the pairs were mapped from.  Random choices (SMALTGPU_OUT_RANDSEL) draw from drand48() in pair order. */
+int smaltgpu_report_emit_pairs(smaltgpu_report *rp, const smaltgpu_pairs *pairs, const smaltgpu_reads_view *reads, const smaltgpu_reads_view *mates,
+                               const char *const *seqnames, int64_t nseq, const smaltgpu_report_opts *op, const smaltgpu_pair_opts *po, int nthreads,
+                               const char **text, uint64_t *len);
 /* names and offsets of the reference sequences of an index (for the two calls above); the arrays belong to the index */
 int smaltgpu_index_seqnames(const smaltgpu_index *ix, const char *const **names, const uint64_t **sop, int64_t *nseq);
 

@@ -934,6 +934,16 @@ extern "C" int smaltgpu_map_batch(smaltgpu_mapper *m, const uint8_t *bases, cons
   return smaltgpu_map_batch_ctx(m, bases, quals, read_off, nreads, par, nullptr, out);
 }
 
+extern "C" const smaltgpu_index *smaltgpu_mapper_index(const smaltgpu_mapper *m) { return m ? m->ix : nullptr; }
+
+extern "C" int smaltgpu_mapper_capacity(const smaltgpu_mapper *m, uint32_t *max_batch_reads, uint32_t *max_read_len, uint64_t *max_bases) {
+  if (!m) return fail(SMALTGPU_EARG, "null mapper");
+  if (max_batch_reads) *max_batch_reads = m->max_reads;
+  if (max_read_len) *max_read_len = m->max_len;
+  if (max_bases) *max_bases = m->max_bases;
+  return SMALTGPU_OK;
+}
+
 extern "C" int smaltgpu_hit_totals(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
                                     const smaltgpu_params *par, uint32_t *nhits) {
   if (!m || !bases || !read_off || !par || !nhits) return fail(SMALTGPU_EARG, "null argument");

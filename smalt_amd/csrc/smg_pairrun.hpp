@@ -1,0 +1,246 @@
+// smg_pairrun.hpp -- a block of read pairs through the rounds of smg_pairs.hpp (PairPlan): what rmapPair (rmap.c:1744-2112)
+// does pair by pair, done round by round for the whole block so that every round is ONE batch for the device.
+// The mapping itself is behind `Exec` (two calls: k-mer hit totals of reads, one round of mapping calls with per-read
+// context); the product's Exec sends them through smaltgpu_hit_totals / smaltgpu_map_batch_ctx (smg_pairs.cpp), the
+// parity test's Exec replays the calls the reference recorded (tests/hostemu/pair_check.cpp).
+// Between rounds a pair's two alignment tables rest as packed byte runs (Table::pack); worker threads unpack a table,
+// append the round's alignments, run the post-call pass (smg_post.hpp) and pack it again.
+#ifndef SMG_PAIRRUN_HPP
+#define SMG_PAIRRUN_HPP
+#include <stdio.h>
+#include <string>
+#include <thread>
+#include "../../include/smaltgpu.h"
+#include "smg_pairs.hpp"
+
+namespace smgpairs {
+
+struct BlockInput {                         // two batches in the layout of smaltgpu_map_batch: [0] reads, [1] mates
+  const uint8_t *bases[2], *quals[2];       // quals[w] may be null
+  const uint64_t *off[2];
+  uint32_t npairs;
+};
+struct BlockParams {
+  smaltgpu_params map;                      // per-call parameters (best-only mapping is forced, as rmapPair does: rmap.c:1848)
+  int d_min, d_max, lib;
+  bool every_pair;                          // -x: the unrestricted round for every pair (RMAPFLG_ALLPAIR, rmap.c:1965)
+  int k;                                    // word length of the index
+  const uint64_t *sop; int64_t nseq;        // sequence offsets
+  const uint32_t *packed_host;              // host copy of the packed reference, or null when alignments cannot cross sequences
+  int nthreads;
+};
+enum RoundKind { ROUND_PLAIN = 0, ROUND_RESTRICTED = 1, ROUND_APPEND = 2, ROUND_FINE = 3 };
+struct Round {                              // one batch of mapping calls: read ids are 2 * pair + mate
+  int kind;
+  const uint32_t *ids; uint32_t n;
+  const uint64_t *iv_off; const smaltgpu_interval *iv;      // ROUND_RESTRICTED, ROUND_FINE
+  const int32_t *min_score;                                  // ROUND_FINE
+  const int32_t *prev_max;                                   // ROUND_APPEND, ROUND_FINE: (max, second) per call
+};
+
+struct PairBlock {
+  std::vector<std::vector<uint8_t>> packed;   // 2 * npairs tables at rest
+  std::vector<PairPlan> plan;
+  std::vector<uint32_t> nrounds;              // mapping calls per round kind, for the caller's statistics
+  std::string error;
+  uint32_t npairs = 0;
+
+  template <class Fn> static void spread(uint32_t n, int nthreads, Fn fn) {      // fn(lo, hi, thread)
+    if (nthreads < 1) nthreads = 1;
+    if ((uint32_t)nthreads > n / 64 + 1) nthreads = (int)(n / 64 + 1);
+    if (nthreads == 1) { fn(0u, n, 0); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++) th.emplace_back(fn, (uint32_t)((uint64_t)n * t / nthreads), (uint32_t)((uint64_t)n * (t + 1) / nthreads), t);
+    for (std::thread &x : th) x.join();
+  }
+  static uint32_t len_of(const BlockInput &in, uint32_t id) { return (uint32_t)(in.off[id & 1][(id >> 1) + 1] - in.off[id & 1][id >> 1]); }
+
+  // a round's results into the tables of its reads; `after(slot, pair, table)` runs per call with the settled table
+  template <class After> bool take(const Round &rd, const smaltgpu_batch_out &o, const BlockInput &in, const BlockParams &bp, After after) {
+    if (o.nreads != rd.n) { error = "a mapping round returned a different number of reads"; return false; }
+    std::vector<std::string> bad((size_t)(bp.nthreads < 1 ? 1 : bp.nthreads));
+    const smgpost::Reference ref{bp.sop, bp.nseq, bp.packed_host};
+    const smgpost::Penalties pen{bp.map.match, bp.map.mismatch, bp.map.gap_init, bp.map.gap_ext};
+    spread(rd.n, bp.nthreads, [&](uint32_t lo, uint32_t hi, int t) {
+      Table tb;
+      char msg[256];
+      for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t id = rd.ids[i], w = id & 1, pr = id >> 1;
+        const smaltgpu_readstat &st = o.stat[i];
+        if (st.errcode) { snprintf(msg, sizeof(msg), "pair %u, mate %u: the mapping call failed on the device (code %d)", pr, w + 1, st.errcode); if (bad[(size_t)t].empty()) bad[(size_t)t] = msg; continue; }
+        std::vector<uint8_t> &rest = packed[id];
+        tb.unpack(rest.data(), rest.size());
+        tb.n_ali_done = st.n_ali_done; tb.n_ali_tot = st.n_ali_tot; tb.n_hits_used = st.n_hits_used; tb.n_hits_tot = st.n_hits_tot;     // rmap.c:1337
+        tb.take_call(o.res + o.res_off[i], (uint32_t)(o.res_off[i + 1] - o.res_off[i]), o.diffstr, st.swatscor_max, st.swatscor_2ndmax);
+        if (st.max1scor >= 1) {                                        // a call without a score-pass hit returns before the pass (rmap.c:1376)
+          smgpost::Read r;
+          r.len = len_of(in, id);
+          r.bases = in.bases[w] + in.off[w][pr];
+          r.quals = in.quals[w] ? in.quals[w] + in.off[w][pr] : nullptr;
+          const smgpost::Outcome oc = tb.settle(ref, r, bp.packed_host ? &pen : nullptr);
+          if (oc != smgpost::DONE) {
+            snprintf(msg, sizeof(msg), "pair %u, mate %u: %s", pr, w + 1, oc == smgpost::WANTS_REFERENCE ? "an alignment crosses reference sequences and no host copy of the reference was given" : tb.why);
+            if (bad[(size_t)t].empty()) bad[(size_t)t] = msg;
+            continue;
+          }
+        }
+        if (!after(i, pr, tb, t)) { snprintf(msg, sizeof(msg), "pair %u, mate %u: alignment set is inconsistent", pr, w + 1); if (bad[(size_t)t].empty()) bad[(size_t)t] = msg; }
+        tb.pack(rest);
+      }
+    });
+    for (const std::string &b : bad) if (!b.empty()) { error = b; return false; }
+    return true;
+  }
+
+  template <class Exec> bool run(Exec &exec, const BlockInput &in, const BlockParams &bp) {
+    const uint32_t n = in.npairs;
+    npairs = n;
+    error.clear();
+    packed.assign((size_t)2 * n, std::vector<uint8_t>());
+    plan.assign(n, PairPlan());
+    nrounds.assign(4, 0);
+    if (!n) return true;
+    const int nt = bp.nthreads < 1 ? 1 : bp.nthreads;
+    std::vector<uint32_t> ids((size_t)2 * n), hits((size_t)2 * n, 0);
+    smaltgpu_batch_out o;
+
+    // which mate first: k-mer hit totals of all reads (rmap.c:1866-1905)
+    for (uint32_t i = 0; i < 2 * n; i++) ids[i] = i;
+    if (!exec.totals(ids.data(), 2 * n, hits.data(), error)) return false;
+    for (uint32_t p = 0; p < n; p++) plan_start(plan[p], len_of(in, 2 * p), len_of(in, 2 * p + 1), hits[2 * p], hits[2 * p + 1], bp.k);
+
+    // per-thread interval lists of a round, stitched in call order afterwards
+    std::vector<std::vector<smaltgpu_interval>> iv_part((size_t)nt);
+    std::vector<uint32_t> iv_count;
+    std::vector<uint64_t> iv_off;
+    std::vector<smaltgpu_interval> iv;
+    std::vector<int32_t> prev_max, min_score;
+    auto stitch = [&](uint32_t ncalls) {              // iv_count per call + the parts in thread order (threads own ascending call ranges) -> iv_off, iv
+      iv_off.assign((size_t)ncalls + 1, 0);
+      for (uint32_t i = 0; i < ncalls; i++) iv_off[(size_t)i + 1] = iv_off[i] + iv_count[i];
+      iv.clear();
+      for (const auto &part : iv_part) iv.insert(iv.end(), part.begin(), part.end());
+      if (iv.empty()) iv.resize(1);
+    };
+    std::vector<Interval> tmp_iv;
+
+    // ---- round A: the first mate ----
+    uint32_t na = 0;
+    for (uint32_t p = 0; p < n; p++) if (!plan[p].idle && !plan[p].lone) ids[na++] = 2 * p + plan[p].first;
+    std::vector<uint32_t> ids_b(na);
+    if (na) {
+      Round rd{ROUND_PLAIN, ids.data(), na, nullptr, nullptr, nullptr, nullptr};
+      if (!exec.map(rd, &o, error)) return false;
+      nrounds[ROUND_PLAIN] += na;
+      iv_count.assign(na, 0);
+      for (auto &part : iv_part) part.clear();
+      std::vector<std::vector<Interval>> scratch((size_t)nt);
+      if (!take(rd, o, in, bp, [&](uint32_t i, uint32_t p, Table &tb, int t) {
+            plan_after_a(plan[p], tb);
+            const uint32_t me = 2 * p + plan[p].first, other = me ^ 1u;
+            if (!search_intervals(scratch[(size_t)t], tb, len_of(in, me), len_of(in, other), bp.d_min, bp.d_max, bp.k, bp.sop, bp.nseq)) return false;
+            iv_count[i] = (uint32_t)scratch[(size_t)t].size();
+            for (const Interval &v : scratch[(size_t)t]) iv_part[(size_t)t].push_back(smaltgpu_interval{v.seq, v.lo, v.hi});
+            return true;
+          })) return false;
+      // ---- round B: the second mate inside the intervals of the first ----
+      stitch(na);
+      for (uint32_t i = 0; i < na; i++) ids_b[i] = ids[i] ^ 1u;
+      Round rb{ROUND_RESTRICTED, ids_b.data(), na, iv_off.data(), iv.data(), nullptr, nullptr};
+      if (!exec.map(rb, &o, error)) return false;
+      nrounds[ROUND_RESTRICTED] += na;
+      if (!take(rb, o, in, bp, [&](uint32_t, uint32_t, Table &, int) { return true; })) return false;
+      // ---- proper pairs so far; who needs the unrestricted round ----
+      std::vector<int> broken((size_t)nt, 0);
+      spread(na, nt, [&](uint32_t lo, uint32_t hi, int t) {
+        Table A, B;
+        Probe probe;
+        for (uint32_t i = lo; i < hi; i++) {
+          const uint32_t p = ids_b[i] >> 1;
+          A.unpack(packed[2 * p].data(), packed[2 * p].size());
+          B.unpack(packed[2 * p + 1].data(), packed[2 * p + 1].size());
+          if (plan_after_b(plan[p], probe, A, B, len_of(in, 2 * p), len_of(in, 2 * p + 1), bp.d_min, bp.d_max, bp.lib, bp.every_pair) < 0) { broken[(size_t)t] = 1; continue; }
+          if (plan[p].wants_c && plan[p].proper_found < 1) packed[2 * p + (plan[p].first ^ 1u)].clear();
+        }
+      });
+      for (int b : broken) if (b) { error = "a pair's alignment sets are not in order for pairing, or the insert range is empty"; return false; }
+    }
+
+    // ---- round C: the second mate without restriction; lone mates join here ----
+    uint32_t nc = 0;
+    for (uint32_t p = 0; p < n; p++) {
+      const PairPlan &pl = plan[p];
+      if (pl.idle || !(pl.wants_c || pl.lone)) continue;
+      ids[nc++] = 2 * p + (pl.lone ? pl.lone_which : (uint8_t)(pl.first ^ 1u));
+    }
+    if (nc) {
+      prev_max.assign((size_t)2 * nc, 0);
+      spread(nc, nt, [&](uint32_t lo, uint32_t hi, int) {
+        Table tb;
+        for (uint32_t i = lo; i < hi; i++) { const auto &rest = packed[ids[i]]; tb.unpack(rest.data(), rest.size()); prev_max[2 * (size_t)i] = tb.score_max; prev_max[2 * (size_t)i + 1] = tb.score_2nd; }
+      });
+      Round rc{ROUND_APPEND, ids.data(), nc, nullptr, nullptr, nullptr, prev_max.data()};
+      if (!exec.map(rc, &o, error)) return false;
+      nrounds[ROUND_APPEND] += nc;
+      if (!take(rc, o, in, bp, [&](uint32_t, uint32_t, Table &, int) { return true; })) return false;
+      // ---- who maps the first mate again, inside the intervals of the second one's results ----
+      iv_count.assign(nc, 0);
+      for (auto &part : iv_part) part.clear();
+      min_score.assign(nc, 0);
+      std::vector<int32_t> pm((size_t)2 * nc, 0);
+      std::vector<int> broken((size_t)nt, 0);
+      spread(nc, nt, [&](uint32_t lo, uint32_t hi, int t) {
+        Table A, B;
+        std::vector<Interval> mine;
+        for (uint32_t i = lo; i < hi; i++) {
+          const uint32_t p = ids[i] >> 1;
+          PairPlan &pl = plan[p];
+          if (pl.lone) continue;
+          A.unpack(packed[2 * p].data(), packed[2 * p].size());
+          B.unpack(packed[2 * p + 1].data(), packed[2 * p + 1].size());
+          plan_after_c(pl, A, B, len_of(in, 2 * p), len_of(in, 2 * p + 1), bp.k);
+          if (!pl.wants_d) continue;
+          const Table &first = pl.first ? B : A, &second = pl.first ? A : B;
+          const uint32_t id1 = 2 * p + pl.first, id2 = id1 ^ 1u;
+          if (!search_intervals(mine, second, len_of(in, id2), len_of(in, id1), bp.d_min, bp.d_max, bp.k, bp.sop, bp.nseq)) { broken[(size_t)t] = 1; continue; }
+          iv_count[i] = (uint32_t)mine.size();
+          for (const Interval &v : mine) iv_part[(size_t)t].push_back(smaltgpu_interval{v.seq, v.lo, v.hi});
+          min_score[i] = pl.threshold_d;
+          pm[2 * (size_t)i] = first.score_max; pm[2 * (size_t)i + 1] = first.score_2nd;
+        }
+      });
+      for (int b : broken) if (b) { error = "a pair's alignment set is not in order for the search intervals"; return false; }
+      // ---- round D: compact the calls that take part ----
+      uint32_t nd = 0;
+      std::vector<uint32_t> ids_d;
+      std::vector<uint32_t> cnt_d;
+      std::vector<int32_t> ms_d, pm_d;
+      for (uint32_t i = 0; i < nc; i++) {
+        const PairPlan &pl = plan[ids[i] >> 1];
+        if (pl.lone || !pl.wants_d) continue;
+        ids_d.push_back(2 * (ids[i] >> 1) + pl.first); cnt_d.push_back(iv_count[i]); ms_d.push_back(min_score[i]); pm_d.push_back(pm[2 * (size_t)i]); pm_d.push_back(pm[2 * (size_t)i + 1]);
+        nd++;
+      }
+      if (nd) {
+        iv_count = cnt_d;
+        stitch(nd);
+        Round rdd{ROUND_FINE, ids_d.data(), nd, iv_off.data(), iv.data(), ms_d.data(), pm_d.data()};
+        if (!exec.map(rdd, &o, error)) return false;
+        nrounds[ROUND_FINE] += nd;
+        if (!take(rdd, o, in, bp, [&](uint32_t, uint32_t, Table &, int) { return true; })) return false;
+      }
+    }
+    return true;
+  }
+};
+
+}  // namespace smgpairs
+
+// the C ABI's handle on a mapped block (include/smaltgpu.h)
+struct smaltgpu_pairs {
+  smgpairs::PairBlock blk;
+  std::vector<smaltgpu_pair_info> info;
+  uint64_t calls[4] = {0, 0, 0, 0};
+  double round_ms[4] = {0, 0, 0, 0};
+};
+#endif

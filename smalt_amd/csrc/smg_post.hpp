@@ -37,7 +37,7 @@
 namespace smgpost {
 
 // per-alignment bits; the values are ABI (smaltgpu_post_result.status = the reference's RSLTFLAG_*, results.h:67-78)
-enum : uint32_t { LIVE = 0x01, REVERSED = 0x04, UNPLACED = 0x08, PAIRED_PROPER = 0x40, ONLY_ONE = 0x100 };
+enum : uint32_t { LIVE = 0x01, REVERSED = 0x04, UNPLACED = 0x08, WITHHELD = 0x10, BELOW_RELATIVE = 0x20, ONLY_ONE = 0x100, REPORTED = 0x200 };
 // per-table bits (RSLTSETFLG_*, results.c:93-100)
 enum : uint32_t { SET_PLACED = 0x01, SET_NUMBERED = 0x02, SET_ORDERED = 0x04, SET_SEGMENTED = 0x08, SET_QUALIFIED = 0x10 };
 enum { QUALITY_TOP = 60, QUALITY_FLOOR_UNIQUE = 4, ROWS_MAX = 32767 };
@@ -468,6 +468,109 @@ struct Table {
     if (n1 == 1 && n2 == 0) bits[rows_of[0]] |= ONLY_ONE;
     return true;
   }
+
+
+  // ---- what callers above the pass ask of a table ----
+  // quality and score of the best alignment, 0 / 0 for an empty table (resultSetGetMappingScore, results.c:2407)
+  int top_quality(int *top_score) const {
+    if (by_score.empty()) { if (top_score) *top_score = 0; return 0; }
+    if (top_score) *top_score = score[by_score[0]];
+    return quality[by_score[0]];
+  }
+  // How many ordered alignments carry the set's best score, and how many count as second class.  The maxima are the
+  // RUNNING ones of the set (score_max / score_2nd: they have seen alignments that were dropped again), and the second
+  // count is all-or-nothing: everything behind the first class if the first alignment there reaches score_2nd, else 0
+  // (resultSetGetScorStats, results.c:2363-2386, tests element [first] throughout)
+  void score_classes(int *nbest, int *nsecond) const {
+    const int n = (int)by_score.size();
+    int i = 0;
+    while (i < n && score[by_score[i]] >= score_max) i++;
+    if (nbest) *nbest = i;
+    if (nsecond) *nsecond = (i < n && score[by_score[i]] >= score_2nd) ? n - i : 0;
+  }
+  // -> true when exactly one alignment has the best score; *deepest_rank: score ranks that take part in pairing
+  bool rank_depth(int *deepest_rank) const {                      // resultSetGetRankDepth, results.c:2388-2405
+    int nbest, nsecond;
+    score_classes(&nbest, &nsecond);
+    if (deepest_rank) *deepest_rank = nbest < 2 ? 1 : 0;
+    return nbest == 1;
+  }
+  // the top of the order: rows that share the best score when there are several, else the best and the whole second class
+  // (getNumberOfTopSwatRESULTs, results.c:838-866)
+  bool top_class(int *ntop) const {
+    const int n = (int)by_score.size();
+    const bool single = n < 2 || score[by_score[1]] != score[by_score[0]];
+    int k = n;
+    if (n > 2) { k = 2; while (k < n && score[by_score[k]] == score[by_score[1]]) k++; }
+    if (ntop) *ntop = k;
+    return single;
+  }
+  // Output filter (resultSetFilterResults, results.c:2592-2626): absolute score, matched bases, distance from the best
+  void apply_output_filter(int min_score, int below_best, double min_identity, uint32_t read_len) {
+    if (by_score.empty()) return;
+    const double idt = min_identity <= 1.0 ? min_identity * read_len : min_identity;
+    const int need_matched = (int)(uint32_t)idt, best = score[by_score[0]];
+    const int floor_rel = (below_best >= 0 && min_score + below_best < best) ? best - below_best : 0;
+    for (int32_t r : by_score) {
+      if (score[r] < min_score || matched_bases(str((uint32_t)r)) < need_matched) bits[r] |= WITHHELD;
+      else if (score[r] < floor_rel) bits[r] |= BELOW_RELATIVE;
+    }
+  }
+  static int matched_bases(const uint8_t *s) {                    // diffStrCalcAliLen's match count (diffstr.c:932-952)
+    int m = 0;
+    for (; *s; ++s) m += (*s & 63) + ((*s >> 6) == OP_MATCH ? 1 : 0);
+    return m;
+  }
+
+  // One mapping call's alignments into the table (what resultSetAddFromAli, results.c:1852-1942, leaves when the set is
+  // not empty): the call's first alignment is compared with the set's last row -- same coordinates, score and sequence --
+  // and if it repeats it, it is dropped together with the rest of its candidate (`starts_candidate` marks where the next
+  // candidate's alignments begin).  The running maxima and the counters are the call's.
+  template <class Raw> void take_call(const Raw *res, uint32_t n, const uint8_t *pool, int32_t max_after, int32_t second_after) {
+    uint32_t from = 0;
+    if (n && rows()) {
+      const uint32_t last = rows() - 1;
+      if (res[0].s_start == r_lo[last] && res[0].s_end == r_hi[last] && res[0].q_start == q_lo[last] && res[0].q_end == q_hi[last] &&
+          res[0].swatscor == score[last] && (int64_t)res[0].sidx == seq[last])
+        for (from = 1; from < n && !(res[from].reverse & 2u); from++) {}
+    }
+    for (uint32_t i = from; i < n; i++)
+      add(res[i].swatscor, res[i].q_start, res[i].q_end, res[i].s_start, res[i].s_end, res[i].sidx, (res[i].reverse & 1u) != 0, pool + res[i].stroffs, res[i].strlen);
+    if (n) set_bits = 0;
+    score_max = max_after; score_2nd = second_after;
+  }
+
+  // A table between two passes, as one run of bytes (a block of pairs keeps two of these per pair, not two Tables)
+  void pack(std::vector<uint8_t> &o) const {
+    o.clear();
+    const uint32_t head[13] = {rows(), (uint32_t)by_score.size(), (uint32_t)segment_begin.size(), (uint32_t)strings.size(), set_bits, (uint32_t)nsegments,
+                               (uint32_t)n_ali_done, (uint32_t)n_ali_tot, (uint32_t)score_max, (uint32_t)score_2nd, n_hits_used, n_hits_tot, (uint32_t)by_segment.size()};
+    put(o, head, 13);
+    put(o, r_lo.data(), rows()); put(o, r_hi.data(), rows()); put(o, seq.data(), rows()); put(o, prob.data(), rows());
+    put(o, score.data(), rows()); put(o, quality.data(), rows()); put(o, q_lo.data(), rows()); put(o, q_hi.data(), rows()); put(o, bits.data(), rows());
+    put(o, str_at.data(), rows()); put(o, str_len.data(), rows()); put(o, by_score.data(), by_score.size()); put(o, by_segment.data(), by_segment.size());
+    put(o, segment_begin.data(), segment_begin.size());
+    put(o, primary.data(), rows()); put(o, segment.data(), rows()); put(o, rank.data(), rows());
+    put(o, strings.data(), strings.size());
+  }
+  void unpack(const uint8_t *p, size_t len) {
+    clear();
+    if (!len) return;
+    uint32_t head[13];
+    get(p, head, 13);
+    const size_t n = head[0], nl = head[1], nb = head[2], ns = head[3];
+    set_bits = head[4]; nsegments = (int)head[5]; n_ali_done = (int32_t)head[6]; n_ali_tot = (int32_t)head[7]; score_max = (int32_t)head[8]; score_2nd = (int32_t)head[9];
+    n_hits_used = head[10]; n_hits_tot = head[11];
+    r_lo.resize(n); get(p, r_lo.data(), n); r_hi.resize(n); get(p, r_hi.data(), n); seq.resize(n); get(p, seq.data(), n); prob.resize(n); get(p, prob.data(), n);
+    score.resize(n); get(p, score.data(), n); quality.resize(n); get(p, quality.data(), n); q_lo.resize(n); get(p, q_lo.data(), n); q_hi.resize(n); get(p, q_hi.data(), n);
+    bits.resize(n); get(p, bits.data(), n); str_at.resize(n); get(p, str_at.data(), n); str_len.resize(n); get(p, str_len.data(), n);
+    by_score.resize(nl); get(p, by_score.data(), nl); by_segment.resize(head[12]);
+    get(p, by_segment.data(), by_segment.size()); segment_begin.resize(nb); get(p, segment_begin.data(), nb);
+    primary.resize(n); get(p, primary.data(), n); segment.resize(n); get(p, segment.data(), n); rank.resize(n); get(p, rank.data(), n);
+    strings.resize(ns); get(p, strings.data(), ns);
+  }
+  template <class T> static void put(std::vector<uint8_t> &o, const T *v, size_t n) { if (n) { const uint8_t *b = (const uint8_t *)v; o.insert(o.end(), b, b + n * sizeof(T)); } }
+  template <class T> static void get(const uint8_t *&p, T *v, size_t n) { if (n) { memcpy(v, p, n * sizeof(T)); p += n * sizeof(T); } }
 
   struct Key { uint64_t hi, lo; uint32_t arrival, row; };
 

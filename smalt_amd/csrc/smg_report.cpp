@@ -286,7 +286,8 @@ extern "C" int smaltgpu_reads_parse(smaltgpu_reads *rs, const char *text, uint64
 namespace {
 
 enum : uint32_t { RF_SELECT = 0x01, RF_REVERSE = 0x04, RF_NOOUTPUT = 0x10, RF_BELOWRELSW = 0x20, RF_REPORTED = 0x200 };   // results.h:67-82
-enum : uint32_t { MF_MAPPED = 0x01, MF_REVERSE = 0x02, MF_2NDMATE = 0x08, MF_PRIMARY = 0x10, MF_PARTIAL = 0x20, MF_MULTI = 0x40 };   // report.h:66-74
+enum : uint32_t { MF_MAPPED = 0x01, MF_REVERSE = 0x02, MF_PAIRED = 0x04, MF_2NDMATE = 0x08, MF_PRIMARY = 0x10, MF_PARTIAL = 0x20, MF_MULTI = 0x40 };   // report.h:66-74
+enum : uint8_t { RP_MAPPED = 0x01, RP_CONTIG = 0x02, RP_PROPER = 0x04, RP_WITHIN = 0x08 };                                                        // report.h:76-81
 enum { MAPSCOR_MAX_RANDOM = 3, SAMPLESIZ_MAPQ_RANDOM = 9, QUALSCOR_SCAL = 10, CIGAR_MAXTAG = 99 };   // results.c:57,73,80; report.c:73
 
 struct Ali {                              // REPALI (report.c:130-145)
@@ -457,12 +458,20 @@ int draw_range(const ReadCtx &cx, uint32_t i) {
   return ns > 1 ? ns : 0;
 }
 
-bool print_cigar_line(std::string &o, const ReadCtx &cx, uint32_t i, const Ali &a) {      // fprintREPALIcigar (report.c:711-760)
+// the other mate's printed alignment, the template length and what is known about the pairing (REPPAIR_*) -- null for single reads
+struct PairSide { const Ali *mate; int isize; uint8_t pairflg; };
+
+bool print_cigar_line(std::string &o, const ReadCtx &cx, uint32_t i, const Ali &a, const PairSide *ps = nullptr) {      // fprintREPALIcigar (report.c:711-760)
   char buf[96];
   const bool mapped = (a.status & MF_MAPPED) != 0;
   char flagchr;
-  if (mapped) flagchr = (a.status & MF_PARTIAL) ? 'P' : 'S';              // getMapLabelFromFlag (report.c:217-246), no pair flags
-  else flagchr = (a.status & MF_MULTI) ? 'R' : 'N';
+  if (mapped) {                                                           // getMapLabelFromFlag (report.c:217-246)
+    uint8_t pf = ps ? ps->pairflg : 0;
+    if (ps && ps->mate && a.sidx == ps->mate->sidx) pf |= RP_CONTIG;       // report.c:1173-1176 (an unprinted mate carries sequence 0)
+    if (a.status & MF_PARTIAL) flagchr = 'P';
+    else if (pf & RP_MAPPED) flagchr = (pf & RP_CONTIG) ? ((pf & RP_PROPER) ? ((pf & RP_WITHIN) ? 'A' : 'B') : 'C') : 'D';
+    else flagchr = 'S';
+  } else flagchr = (a.status & MF_MULTI) ? 'R' : 'N';
   const int mq = mapped ? (a.mapscor > CIGAR_MAXTAG ? CIGAR_MAXTAG : a.mapscor) : 0;
   snprintf(buf, sizeof(buf), "cigar:%c:%2.2d ", flagchr, mq);
   o += buf;
@@ -481,7 +490,7 @@ bool print_cigar_line(std::string &o, const ReadCtx &cx, uint32_t i, const Ali &
   return true;
 }
 
-bool print_sam_line(std::string &o, const ReadCtx &cx, uint32_t i, const Ali &a) {        // fprintREPALIsam (report.c:762-906), single reads
+bool print_sam_line(std::string &o, const ReadCtx &cx, uint32_t i, const Ali &a, const PairSide *ps = nullptr) {        // fprintREPALIsam (report.c:762-906)
   char buf[96];
   const smaltgpu_report_opts &op = *cx.op;
   const bool mapped = (a.status & MF_MAPPED) != 0, soft = (op.modflags & SMALTGPU_REP_SOFTCLIP) != 0;
@@ -491,6 +500,20 @@ bool print_sam_line(std::string &o, const ReadCtx &cx, uint32_t i, const Ali &a)
   unsigned flag = 0;
   first_word(o, cx.rv->names + cx.rv->name_off[i], true);
   int clip_start = 0, clip_end = 0;
+  // mate fields (report.c:795-815)
+  int isize = ps ? ps->isize : 0;
+  uint32_t mpos = 0;
+  const char *mate_seq = nullptr;
+  if (a.status & MF_PAIRED) {
+    flag |= 0x1;
+    if (a.status & MF_2NDMATE) { flag |= 0x80; isize = -isize; } else flag |= 0x40;
+    if (ps && ps->mate && (ps->mate->status & MF_MAPPED)) {
+      mpos = (uint32_t)ps->mate->ss;
+      if (ps->mate->status & MF_REVERSE) flag |= 0x20;
+      if (ps->mate->sidx < 0 || ps->mate->sidx >= cx.nseq) return false;
+      mate_seq = cx.seqnames[ps->mate->sidx];
+    } else { flag |= 0x8; isize = 0; }
+  }
   uint32_t seg0 = 0, segn = 0;
   bool rev = false;
   if (mapped) {
@@ -500,8 +523,9 @@ bool print_sam_line(std::string &o, const ReadCtx &cx, uint32_t i, const Ali &a)
     if (!segn || seg0 + segn > qlen) segn = qlen - seg0;                 // appendSeqSegment (sequence.c:865-867)
     if (rev) { flag |= 0x10; clip_start = (int)(qlen - a.qe); clip_end = (int)a.qs - 1; }
     else { clip_start = (int)a.qs - 1; clip_end = (int)(qlen - a.qe); }
+    if (ps && (ps->pairflg & RP_PROPER) && (ps->pairflg & RP_WITHIN)) flag |= 0x2;
     if (a.status & MF_PARTIAL) flag |= 0x100;
-  } else flag |= 0x4;
+  } else { flag |= 0x4; isize = 0; }
   snprintf(buf, sizeof(buf), "\t%hu\t", (unsigned short)flag);
   o += buf;
   if (mapped) { if (a.sidx < 0 || a.sidx >= cx.nseq) return false; first_word(o, cx.seqnames[a.sidx], false); }
@@ -513,7 +537,10 @@ bool print_sam_line(std::string &o, const ReadCtx &cx, uint32_t i, const Ali &a)
     if (!put_cigar(o, a.dstr, true, !(op.modflags & SMALTGPU_REP_XMISMATCH), clip_start, clip_end, soft ? 'S' : 'H')) return false;
     nm = diff_edit_distance(a.dstr);
   } else o.push_back('*');
-  o += "\t*\t0\t0\t";
+  o.push_back('\t');
+  if (mate_seq) first_word(o, mate_seq, false); else o.push_back('*');
+  snprintf(buf, sizeof(buf), "\t%i\t%i\t", (int)mpos, isize);
+  o += buf;
   if (mapped || soft) {
     if (!mapped) { seg0 = 0; segn = qlen; }
     const size_t b = o.size();
@@ -609,6 +636,183 @@ extern "C" int smaltgpu_report_emit(smaltgpu_report *rp, const smaltgpu_post_out
   for (const std::string &s : rp->part) tot += s.size();
   rp->text.reserve(tot);
   for (const std::string &s : rp->part) rp->text += s;
+  *text = rp->text.data(); *len = rp->text.size();
+  return SMALTGPU_OK;
+}
+
+// =====================================================================================================================
+// report of read pairs: the tail of rmapPair (resultSetFindPairs, output filters: rmap.c:2099-2109),
+// resultSetAddPairToReport (resultpairs.c:1222) and reportWrite (report.c:1758) for every pair of a mapped block
+// =====================================================================================================================
+#include "smg_pairrun.hpp"
+
+namespace {
+
+using smgpairs::Entry;
+using smgpost::Table;
+
+// The printed alignments of one pair: the reference keeps a list per mate and a list of (read entry, mate entry) pairs; an
+// alignment that is reported twice (two pairings share it) takes one slot, the later report overwriting the earlier one
+// (reportAddMap / findREPALI, report.c:545-578, :1587-1720).
+struct PairSheet {
+  struct Link { int ia, ib, isize; uint8_t pairflg; };
+  std::vector<Ali> side[2];
+  std::vector<uint8_t> printed[2];
+  std::vector<Link> links;
+  void clear() { side[0].clear(); side[1].clear(); links.clear(); }
+  int put(int w, const Ali &a) {
+    std::vector<Ali> &v = side[w];
+    for (size_t k = v.size(); k-- > 0;) {
+      const Ali &b = v[k];
+      if (a.ss == b.ss && a.se == b.se && a.sidx == b.sidx && a.qs == b.qs && a.qe == b.qe && (a.status & (MF_REVERSE | MF_2NDMATE)) == (b.status & (MF_REVERSE | MF_2NDMATE))) { v[k] = a; return (int)k; }
+    }
+    v.push_back(a);
+    return (int)v.size() - 1;
+  }
+};
+
+Ali ali_of(const Table &t, int row, int quality, uint32_t mateflg) {            // resultSetAddResultToReport (results.c:2216-2250)
+  Ali a;
+  memset(&a, 0, sizeof(a));
+  if (row < 0 || (t.bits[(size_t)row] & smgpost::WITHHELD) || t.str_len[(size_t)row] < 1) { a.status = mateflg & ~(uint32_t)MF_MAPPED; return a; }
+  a.status = mateflg | MF_MAPPED | ((t.bits[(size_t)row] & smgpost::REVERSED) ? (uint32_t)MF_REVERSE : 0u);
+  a.swatscor = t.score[(size_t)row]; a.mapscor = quality;
+  a.qs = t.q_lo[(size_t)row]; a.qe = t.q_hi[(size_t)row]; a.ss = t.r_lo[(size_t)row]; a.se = t.r_hi[(size_t)row]; a.sidx = (int32_t)t.seq[(size_t)row];
+  a.dstr = t.str((uint32_t)row);
+  return a;
+}
+
+// one reported pairing onto the sheet (addPairResultsToReport, resultpairs.c:1024-1086)
+void sheet_add(PairSheet &sh, const Entry &e, const Table &A, const Table &B) {
+  using namespace smgpairs;
+  PairSheet::Link ln{-1, -1, 0, 0};
+  const bool a_out = e.a >= 0 && !(A.bits[(size_t)e.a] & smgpost::WITHHELD), b_out = e.b >= 0 && !(B.bits[(size_t)e.b] & smgpost::WITHHELD);
+  if ((e.know & PM_PAIRED) && a_out && b_out) {
+    ln.pairflg |= RP_MAPPED;
+    if (e.know & PM_SAME_SEQUENCE) {
+      ln.pairflg |= RP_CONTIG;
+      ln.isize = layout_of(A, (uint32_t)e.a, B, (uint32_t)e.b).tlen;
+      if (e.know & PM_IN_RANGE) ln.pairflg |= RP_WITHIN;
+      if (e.know & PM_ORIENTED) ln.pairflg |= RP_PROPER;
+    }
+  }
+  const uint32_t base = MF_PAIRED | MF_PRIMARY;
+  ln.ia = sh.put(0, ali_of(A, e.a, e.quality_a, base | ((e.know & PM_READ_AMBIGUOUS) ? (uint32_t)MF_MULTI : 0u)));
+  ln.ib = sh.put(1, ali_of(B, e.b, e.quality_b, base | MF_2NDMATE | ((e.know & PM_MATE_AMBIGUOUS) ? (uint32_t)MF_MULTI : 0u)));
+  sh.links.push_back(ln);
+}
+
+struct PairJob {
+  const smaltgpu_pairs *pairs;
+  ReadCtx cx[2];
+  const smaltgpu_report_opts *op;
+  const smaltgpu_pair_opts *po;
+};
+
+// everything for pair p up to the choice; -> number of random draws the choice needs (counting mode: dr.values == nullptr)
+bool pair_entries(const PairJob &jb, uint32_t p, Table &A, Table &B, smgpairs::Join &join, std::vector<Entry> &entries, smgpairs::Draws &dr) {
+  const smgpairs::PairBlock &blk = jb.pairs->blk;
+  const std::vector<uint8_t> &ra = blk.packed[2 * (size_t)p], &rb = blk.packed[2 * (size_t)p + 1];
+  A.unpack(ra.data(), ra.size());
+  B.unpack(rb.data(), rb.size());
+  const smgpairs::PairPlan &pl = blk.plan[p];
+  join.pairs.clear();
+  if (!pl.idle) {                         // a pair of two mates shorter than a word returns before the pairing (rmap.c:1833-1834)
+    if (!join.run(A, B, pl.state, jb.po->library, jb.po->insert_min, jb.po->insert_max)) return false;
+    A.apply_output_filter(jb.op->min_swscor, jb.op->min_swscor_below_max, jb.op->min_identity, (uint32_t)(jb.cx[0].rv->read_off[p + 1] - jb.cx[0].rv->read_off[p]));
+    B.apply_output_filter(jb.op->min_swscor, jb.op->min_swscor_below_max, jb.op->min_identity, (uint32_t)(jb.cx[1].rv->read_off[p + 1] - jb.cx[1].rv->read_off[p]));
+  }
+  smgpairs::choose(entries, join, A, B, pl.state, jb.op->outflags, dr);
+  return true;
+}
+
+bool pair_lines(std::string &o, const PairJob &jb, uint32_t p, const Table &A, const Table &B, const std::vector<Entry> &entries, PairSheet &sh) {
+  sh.clear();
+  for (const Entry &e : entries) sheet_add(sh, e, A, B);
+  const bool sam = jb.op->format == SMALTGPU_FMT_SAM;
+  auto line = [&](int w, const Ali &a, const PairSide *ps) { return sam ? print_sam_line(o, jb.cx[w], p, a, ps) : print_cigar_line(o, jb.cx[w], p, a, ps); };
+  for (int w = 0; w < 2; w++) sh.printed[w].assign(sh.side[w].size(), 0);
+  for (const PairSheet::Link &ln : sh.links) {                       // reportWrite (report.c:1758-1867): the pairs first ...
+    const Ali &a = sh.side[0][(size_t)ln.ia], &b = sh.side[1][(size_t)ln.ib];
+    sh.printed[0][(size_t)ln.ia] = sh.printed[1][(size_t)ln.ib] = 1;
+    const PairSide pa{&b, ln.isize, ln.pairflg}, pb{&a, ln.isize, ln.pairflg};
+    if (!line(0, a, &pa) || !line(1, b, &pb)) return false;
+  }
+  const PairSide rest{nullptr, 0, sh.links.empty() ? (uint8_t)0 : sh.links[0].pairflg};       // ... then what no pair printed
+  for (int w = 0; w < 2; w++)
+    for (size_t k = 0; k < sh.side[w].size(); k++) if (!sh.printed[w][k] && !line(w, sh.side[w][k], &rest)) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int smaltgpu_report_emit_pairs(smaltgpu_report *rp, const smaltgpu_pairs *pairs, const smaltgpu_reads_view *reads, const smaltgpu_reads_view *mates,
+                                          const char *const *seqnames, int64_t nseq, const smaltgpu_report_opts *op, const smaltgpu_pair_opts *po, int nthreads,
+                                          const char **text, uint64_t *len) {
+  if (!rp || !pairs || !reads || !mates || !seqnames || !op || !po || !text || !len) return smaltgpu_set_error(SMALTGPU_EARG, "smaltgpu_report_emit_pairs: null argument");
+  const uint32_t n = pairs->blk.npairs;
+  if (reads->nreads != n || mates->nreads != n) return smaltgpu_set_error(SMALTGPU_EARG, "smaltgpu_report_emit_pairs: reads, mates and mapped pairs differ in number");
+  if (op->format != SMALTGPU_FMT_CIGAR && op->format != SMALTGPU_FMT_SAM) return smaltgpu_set_error(SMALTGPU_EARG, "unknown output format");
+  PairJob jb{pairs, {ReadCtx{nullptr, reads, op, seqnames, nseq}, ReadCtx{nullptr, mates, op, seqnames, nseq}}, op, po};
+  if (nthreads < 1) nthreads = 1;
+  if ((uint32_t)nthreads > n / 256 + 1) nthreads = (int)(n / 256 + 1);
+  const bool drawing = (op->outflags & SMALTGPU_OUT_RANDSEL) != 0;
+  // pass 1: every pair that needs no random number is printed; the others say how many they need
+  struct Slice { uint32_t part; uint64_t at, len; };
+  std::vector<Slice> where(n ? n : 1);
+  std::vector<uint8_t> need(n ? n : 1, 0);
+  rp->part.assign((size_t)nthreads + 1, std::string());
+  std::vector<int64_t> bad((size_t)nthreads, -1);
+  auto pass = [&](int t, uint32_t lo, uint32_t hi, bool second, const std::vector<uint32_t> *todo, const std::vector<double> *values, const std::vector<uint64_t> *value_at) {
+    std::string &o = rp->part[(size_t)t];
+    Table A, B;
+    smgpairs::Join join;
+    std::vector<Entry> entries;
+    PairSheet sh;
+    for (uint32_t j = lo; j < hi; j++) {
+      const uint32_t p = second ? (*todo)[j] : j;
+      smgpairs::Draws dr;
+      if (second) { dr.values = values->data() + (*value_at)[j]; dr.have = need[p]; }
+      if (!pair_entries(jb, p, A, B, join, entries, dr)) { if (bad[(size_t)t] < 0) bad[(size_t)t] = p; continue; }
+      if (!second && drawing && dr.used > 0) { need[p] = (uint8_t)dr.used; continue; }
+      const uint64_t at = o.size();
+      if (!pair_lines(o, jb, p, A, B, entries, sh)) { if (bad[(size_t)t] < 0) bad[(size_t)t] = p; continue; }
+      where[p] = Slice{(uint32_t)t, at, o.size() - at};
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++) {
+      const uint32_t lo = (uint32_t)((uint64_t)n * t / nthreads), hi = (uint32_t)((uint64_t)n * (t + 1) / nthreads);
+      rp->part[(size_t)t].reserve((size_t)(hi - lo) * (op->format == SMALTGPU_FMT_SAM ? 840 : 192));
+      if (nthreads == 1) pass(0, lo, hi, false, nullptr, nullptr, nullptr); else th.emplace_back(pass, t, lo, hi, false, nullptr, nullptr, nullptr);
+    }
+    for (std::thread &x : th) x.join();
+  }
+  // pass 2: the random numbers in pair order, as one thread of the reference draws them; then the pairs that waited for them
+  if (drawing) {
+    std::vector<uint32_t> todo;
+    std::vector<uint64_t> value_at;
+    std::vector<double> values;
+    for (uint32_t p = 0; p < n; p++) if (need[p]) { todo.push_back(p); value_at.push_back(values.size()); for (int k = 0; k < need[p]; k++) values.push_back(drand48()); }
+    if (!todo.empty()) {
+      const int t = nthreads;                               // the extra part
+      const uint64_t before = rp->part[(size_t)t].size();
+      (void)before;
+      bad.push_back(-1);
+      // few pairs wait: one thread
+      std::string &o = rp->part[(size_t)t];
+      o.clear();
+      pass(t, 0, (uint32_t)todo.size(), true, &todo, &values, &value_at);
+    }
+  }
+  for (int64_t b : bad) if (b >= 0) { char m[128]; snprintf(m, sizeof(m), "smaltgpu_report_emit_pairs: pair %lld: inconsistent alignment sets or alignment strings", (long long)b); return smaltgpu_set_error(SMALTGPU_EINTERNAL, m); }
+  // stitch in pair order
+  size_t tot = 0;
+  for (const std::string &s_ : rp->part) tot += s_.size();
+  rp->text.clear();
+  rp->text.reserve(tot);
+  for (uint32_t p = 0; p < n; p++) rp->text.append(rp->part[where[p].part], where[p].at, where[p].len);
   *text = rp->text.data(); *len = rp->text.size();
   return SMALTGPU_OK;
 }

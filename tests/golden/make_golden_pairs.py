@@ -28,6 +28,9 @@ CONFIGS = [
     dict(tag="gp_k13s6_pe", nchr=3, chrlen=200000, k=13, s=6, npairs=140, rlen=100, rep=0.35, div=0.03, opts="-i 500"),
     dict(tag="gp_k11s3_mp", nchr=2, chrlen=150000, k=11, s=3, npairs=90, rlen=75, rep=0.3, div=0.02, opts="-i 450 -j 150 -l mp", ins=(300, 40)),
     dict(tag="gp_k13s6_150", nchr=4, chrlen=150000, k=13, s=6, npairs=100, rlen=150, rep=0.4, div=0.05, opts="-i 500 -q 5", qualmix=True),
+    # exact repeat copies longer than a fragment: pairs with several equally good pairings (the choice among pairings, pairs
+    # reported for multiple placements, every pairing printed under -d 0)
+    dict(tag="gp_k13s6_ties", nchr=2, chrlen=120000, k=13, s=6, npairs=120, rlen=80, rep=0.5, div=0.0, opts="-i 500", cons=700, sub=0.004, indel=0.05),
 ]
 
 
@@ -35,11 +38,11 @@ def make(cfg, tmp):
     tag = cfg["tag"]
     seed = int(hashlib.md5(tag.encode()).hexdigest()[:6], 16)
     rng = np.random.default_rng(seed + 77)
-    ch = synth.make_reference(cfg["nchr"], cfg["chrlen"], seed=seed, repeat_frac=cfg["rep"], n_fam=2, cons_len=400, divergence=cfg["div"])
+    ch = synth.make_reference(cfg["nchr"], cfg["chrlen"], seed=seed, repeat_frac=cfg["rep"], n_fam=2, cons_len=cfg.get("cons", 400), divergence=cfg["div"])
     fa = os.path.join(tmp, tag + ".fa")
     synth.write_fasta(fa, ch)
     ins = cfg.get("ins", (300, 30))
-    r1, r2, _ = synth.make_pairs(ch, cfg["npairs"], cfg["rlen"], seed=seed + 1, insert_mean=ins[0], insert_sd=ins[1], sub_rate=0.02, indel_read_frac=0.2)
+    r1, r2, _ = synth.make_pairs(ch, cfg["npairs"], cfg["rlen"], seed=seed + 1, insert_mean=ins[0], insert_sd=ins[1], sub_rate=cfg.get("sub", 0.02), indel_read_frac=cfg.get("indel", 0.2))
     fqs = []
     for which, reads in ((1, r1), (2, r2)):
         fq = os.path.join(tmp, "%s_%d.fq" % (tag, which))
