@@ -47,8 +47,8 @@ def parse_args():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--sub-batch", type=int, default=262144)
     ap.add_argument("--streams", type=int, default=1, help="mappers (HIP streams) that take the sub-batches in turn: kernels of consecutive sub-batches overlap")
-    ap.add_argument("--paired", action="store_true", help="BASELINE configs[2]: 1 M read PAIRS (2 x read-len, FR, fragments N(300,30), -i 500) through the reference "
-                    "program bound to the library (oracle/_ref/smalt_gpu): rmapPair's rounds run on the GPU, pairing and mapping qualities are the reference's host code; pairs/s")
+    ap.add_argument("--paired", action="store_true", help="BASELINE configs[2]: 1 M read PAIRS (2 x read-len, FR, fragments N(300,30), -i 500) through smaltgpu_map_pairs_resident: "
+                    "rmapPair's rounds on the GPU, the decisions between them in the library; pairs/s with kernel ms per round, roofline and cpu_baseline")
     ap.add_argument("--static-shards", action="store_true", help="N > 1: contiguous shard per rank instead of the shared sub-batch cursor")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-buffers", action="store_true", help="skip the extra PCIe-inclusive measurement of smaltgpu_map_batch on pageable host buffers")
@@ -82,6 +82,21 @@ def spawn_ranks(args):
                 for q in live:            # a rank died: the others would wait in a collective for ever
                     q.terminate()
     return rc
+
+
+def host_core_count():
+    """every core this process may run on: CPU affinity and the container's CPU quota (cgroup v2 cpu.max)"""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return cores
 
 
 def cpu_model():
@@ -172,35 +187,210 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
-def paired_line(args):
-    """configs[2].  rmapPair (rmap.c:1744) decides between its mapping rounds on mapping qualities and proper pairs, which are
-    the reference's results.c / resultpairs.c (host side): the measurable unit is therefore the reference
-    program with its worker bound to the library (tools/bench_tool.py --paired), index and reads on disk, start-up removed by
-    the difference of two runs.  Its output is compared with the unmodified program's on the CPU sample."""
-    n = args.reads or 1_000_000
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_tool.py"), "--paired", "--reads", str(n), "--cpu-reads", str(min(n, max(4000, args.cpu_sample // 6))),
-           "--read-len", str(args.read_len), "--nchr", str(args.nchr), "--chr-mbp", str(args.chr_mbp), "--threads", str(len(os.sched_getaffinity(0))),
-           "--gpu-threads", str(len(os.sched_getaffinity(0)))]
+def cpu_baseline_pairs(args, gix, reads, mates, rlen, cores_info):
+    """The UNMODIFIED reference (`oracle/_ref/smalt map -n T -i 500`) on a bounded sample of the same pairs and the same index
+    files; the index load cancels in the slope of two sample sizes."""
+    smalt = os.path.join(ROOT, "oracle", "_ref", "smalt")
+    if not os.path.exists(smalt):
+        return dict(value=None, unit="read pairs/s", cores=0, kind="reference", sample="oracle/_ref/smalt is not built")
+    cores, host_cores = cores_info
+    n2 = min(max(4000, args.cpu_sample // 3), reads.shape[0])
+    n1 = max(n2 // 10, 500)
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        prefix = os.path.join(tmp, "bench")
+        gix.save(prefix)
+
+        def write_fq(path, arr, n, which):
+            q = b"I" * rlen
+            with open(path, "wb") as f:
+                for i in range(n):
+                    f.write(b"@p%d/%d\n" % (i, which) + arr[i].tobytes() + b"\n+\n" + q + b"\n")
+
+        def run(n):
+            f1, f2 = os.path.join(tmp, "a_%d.fq" % n), os.path.join(tmp, "b_%d.fq" % n)
+            write_fq(f1, reads, n, 1)
+            write_fq(f2, mates, n, 2)
+            t = time.time()
+            subprocess.run([smalt, "map", "-n", str(cores), "-i", "500", "-f", "cigar", "-o", os.path.join(tmp, "o.cig"), prefix, f1, f2], check=True, capture_output=True)
+            return time.time() - t
+        t1, t2 = run(n1), run(n2)
+        both = 0                                          # pairs with both mates mapped, as `value` counts them
+        prev = None
+        for ln in open(os.path.join(tmp, "o.cig")):
+            f = ln.split()
+            mapped = f[0].split(":")[1] not in ("N", "R")
+            if prev is not None and prev[0] == f[1].rsplit("/", 1)[0]:
+                both += prev[1] and mapped
+                prev = None
+            else:
+                prev = (f[1].rsplit("/", 1)[0], mapped)
+        rate = (n2 - n1) / max(t2 - t1, 1e-6) * (both / n2)
+        return dict(value=rate, unit="read pairs/s", cores=cores, host_cores=host_cores, cpu_model=cpu_model(), kind="reference",
+                    sample="smalt map -n %d -i 500 on the first %d vs %d pairs of the bench batch (slope: index load cancels), same index files; %.1f s + %.1f s wall"
+                    % (cores, n1, n2, t1, t2))
+
+
+def paired_main(args):
+    """BASELINE configs[2]: read pairs through the library alone.  One step = smaltgpu_map_pairs_resident over every block of
+    the job: the rounds of rmapPair (rmap.c:1744) on the GPU, the decisions between the rounds (post-call passes, proper-pair
+    probe, search intervals) on host threads.  Reads and mates are resident in HBM when the timed region starts; the pairing
+    and the report lines (smaltgpu_report_emit_pairs) belong to the whole-program figure, not to this path figure."""
+    import ctypes as C
+
+    import torch
+    from smalt_amd import api, gpuindex
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    k, s, rlen = 13, 6, args.read_len
+    chrlen, nchr = int(args.chr_mbp * 1e6), args.nchr
+    sop = np.arange(nchr + 1, dtype=np.int64) * chrlen
+    names = ["chr%d" % (i + 1) for i in range(nchr)]
+    npairs = args.reads or 1_000_000
     t0 = time.time()
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode:
-        raise SystemExit("bench_tool failed: " + r.stderr[-1500:])
-    d = json.loads(r.stdout.strip().splitlines()[-1])
-    return {"metric": "mapped read pairs/sec (1M pairs 2x%dbp vs 3Gbp ref)" % args.read_len, "value": d["gpu_bound_reads_per_s"], "unit": "read pairs/s", "n_gpus": 1,
-            "steps": 1, "warmup": 0, "ms_per_step": (d["wall_s"]["gpu"] - d["wall_s"]["gpu_small"]) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "configs[2]: %d read pairs 2 x %d bp (FR, fragments N(300,30), -i 500) vs %d x %.0f Mbp synthetic reference, k=13 s=6; whole bound program "
-                                   "`smalt_gpu map -n %d` from FASTQ files to CIGAR output, index load removed" % (n, args.read_len, args.nchr, args.chr_mbp, d["threads_gpu_bound"]),
-                       "outputs_identical_on_common_pairs": d["outputs_identical_on_common_reads"], "lines_compared": d["lines_compared"], "wall_s": d["wall_s"], "bench_wall_s": time.time() - t0},
-            "roofline": None,
-            "cpu_baseline": {"value": d["cpu_reads_per_s"], "unit": "read pairs/s", "cores": d["threads_cpu"], "kind": "reference", "cpu_model": cpu_model(),
-                             "sample": "smalt map -n %d -i 500 on the first %d pairs, same index files (start-up removed by a second, small run)" % (d["threads_cpu"], d["reads"]["cpu"])}}
+    ref = gpuindex.make_reference_gpu(nchr, chrlen, 20261004, dev)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    ascii_ref = lut[ref.long()]
+    gix = api.Index.build_device(ascii_ref.data_ptr(), [int(x) for x in sop], names, k, s, 0)
+    del ascii_ref
+    reads, mates, _ = gpuindex.make_pairs_gpu(ref, sop, npairs, rlen, 777)
+    del ref
+    torch.cuda.synchronize()
+    setup_s = time.time() - t0
+    print("[bench] setup: reference, index (%.1f ms on the device) and %d pairs in %.1f s" % (gix.build_ms, npairs, setup_s), file=sys.stderr, flush=True)
+    host_cores = host_core_count()
+    cores = max(1, int(os.environ.get("SMALT_BENCH_CPU_THREADS", host_cores)))
+    par = gix.default_params()
+    sub = min(args.sub_batch, npairs)
+    os.environ.setdefault("SMALTGPU_CANDS_PER_READ", "768")
+    import threading
+    nstream = max(1, args.streams if args.streams > 1 else int(os.environ.get("SMALT_BENCH_PAIR_STREAMS", "2")))
+    mappers = [api.Mapper(gix, sub, rlen, slot_budget_gb=64 // nstream) for _ in range(nstream)]
+    offs = torch.arange(sub + 1, dtype=torch.int64, device=dev) * rlen
+    h_offs = np.arange(sub + 1, dtype=np.uint64) * np.uint64(rlen)
+    po = api.PairOpts(0, 500, api.LIB_PE, 0, max(1, cores // nstream))
+    L = api.lib()
+    handles = [C.c_void_p(L.smaltgpu_pairs_create()) for _ in range(nstream)]
+    nblk = (npairs + sub - 1) // sub
+    kms = np.zeros((5, 16))
+    work = np.zeros((5, 32), dtype=np.uint64)
+    calls = np.zeros(4, dtype=np.uint64)
+    round_ms = np.zeros(4)
+    lock = threading.Lock()
+
+    def one_step(collect):
+        """the blocks of the job, taken in turn by `nstream` host threads with a mapper (HIP stream) each: the host work between
+        the rounds of one block runs while the device works on the other block"""
+        tot = {"both": 0, "any": 0, "next": 0, "err": None}
+
+        def drive(si):
+            mp, handle = mappers[si], handles[si]
+            while True:
+                with lock:
+                    b = tot["next"]
+                    tot["next"] += 1
+                if b >= nblk or tot["err"]:
+                    return
+                b0 = b * sub
+                n = min(sub, npairs - b0)
+                src = api.ResidentReads()
+                for w, t in enumerate((reads, mates)):
+                    src.d_bases[w] = t.data_ptr() + b0 * rlen
+                    src.d_quals[w] = None
+                    src.d_read_off[w] = offs.data_ptr()
+                    src.read_off[w] = h_offs.ctypes.data
+                    src.nreads[w] = n
+                rv = L.smaltgpu_map_pairs_resident(mp.h, C.byref(src), None, None, None, None, n, C.byref(par), C.byref(po), handle)
+                if rv:
+                    tot["err"] = "smaltgpu_map_pairs_resident failed: %s" % L.smaltgpu_last_error().decode()
+                    return
+                npr = C.c_uint32()
+                info = C.POINTER(api.PairInfo)()
+                cl = (C.c_uint64 * 4)()
+                rm = (C.c_double * 4)()
+                L.smaltgpu_pairs_info(handle, C.byref(npr), C.byref(info), cl, rm)
+                a = np.ctypeslib.as_array(C.cast(info, C.POINTER(C.c_uint16)), shape=(n, 3))       # flags+rounds | nali[0] | nali[1]
+                km = (C.c_double * 80)()
+                wk = (C.c_uint64 * 160)()
+                L.smaltgpu_pairs_timers(handle, km, wk)
+                with lock:
+                    tot["both"] += int(((a[:, 1] > 0) & (a[:, 2] > 0)).sum())
+                    tot["any"] += int(((a[:, 1] > 0) | (a[:, 2] > 0)).sum())
+                    if collect:
+                        kms[:] += np.array(km).reshape(5, 16)
+                        work[:] += np.array(wk, dtype=np.uint64).reshape(5, 32)
+                        calls[:] += np.array(cl, dtype=np.uint64)
+                        round_ms[:] += np.array(rm)
+        th = [threading.Thread(target=drive, args=(i,)) for i in range(nstream)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if tot["err"]:
+            raise SystemExit(tot["err"])
+        return tot["both"], tot["any"]
+
+    for w in range(args.warmup):
+        tw = time.time()
+        one_step(False)
+        print("[bench] warmup step %.2f s" % (time.time() - tw), file=sys.stderr, flush=True)
+    torch.cuda.synchronize()
+    t1 = time.time()
+    both = any_ = 0
+    for _ in range(args.steps):
+        b_, a_ = one_step(True)
+        both += b_
+        any_ += a_
+    torch.cuda.synchronize()
+    dt = time.time() - t1
+    tn = [L.smaltgpu_timer_name(i).decode() for i in range(7)]
+    sw = tn.index("sw_full")
+    cells = float(work[:, 2].sum())
+    sw_ms = float(kms[:, sw].sum())
+    tcups = cells / (sw_ms * 1e-3) / 1e12 if sw_ms > 0 else 0.0
+    nlaunch = int((calls > 0).sum()) * nblk * args.steps or 1          # K2a launches: one per round and block
+    rname = ["A first mate", "B second mate restricted", "C second mate again", "D first mate over the on-the-fly index", "hit totals"]
+    per_round = {rname[r]: {tn[i]: float(kms[r, i]) / args.steps for i in range(7) if kms[r, i] > 0} for r in range(5)}
+    gpu_ms = float(kms.sum()) / args.steps
+    line = {
+        "metric": "mapped read pairs/sec (1M pairs 2x%dbp vs 3Gbp ref)" % rlen, "value": both / dt, "unit": "read pairs/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": "configs[2]: %d read pairs 2 x %d bp (FR, fragments N(300,30), -i 500) vs %d x %.0f Mbp synthetic reference (15%% repeats), k=%d s=%d; "
+                               "smaltgpu_map_pairs_resident: rmapPair's rounds on the GPU, the decisions between them on %d host threads" % (npairs, rlen, nchr, args.chr_mbp, k, s, cores),
+                   "pairs_per_step": npairs, "block_pairs": sub, "pairs_per_s_total": args.steps * npairs / dt,
+                   "both_mates_mapped_fraction": both / (args.steps * npairs), "a_mate_mapped_fraction": any_ / (args.steps * npairs),
+                   "mapping_calls_per_pair": {rname[r]: float(calls[r]) / (args.steps * npairs) for r in range(4)}, "setup_s": setup_s, "index_build_ms": gix.build_ms,
+                   "host_threads": cores, "streams": nstream},
+        "roofline": dict(kernel="k_sw_full16", bound="valu", achieved=tcups * OPS_PER_CELL, peak=VALU_PEAK_TOPS, unit="TOP/s", frac=tcups * OPS_PER_CELL / VALU_PEAK_TOPS,
+                         frac_issue=tcups * OPS_PER_CELL / VALU_PEAK_TOPS, ops_per_cell_issue=OPS_PER_CELL, frac_survey=tcups * OPS_PER_CELL_SURVEY / VALU_PEAK_TOPS,
+                         ops_per_cell_survey=OPS_PER_CELL_SURVEY, gcups=tcups * 1e3, traffic=None, avg_launch_ms=sw_ms / nlaunch, cells_per_launch=cells / nlaunch,
+                         peak_note="256 CU x 4 SIMD x 32 lane-ops/clk x 2.4 GHz; same units as the single-end line; all rounds' K2a launches together; with 2 streams the kernels of two blocks share the device, so the per-launch time includes that sharing"),
+        "kernel_ms_per_step_by_round": per_round,
+        "kernel_ms_per_step": {tn[i]: float(kms[:, i].sum()) / args.steps for i in range(7)},
+        "gpu_busy_fraction": gpu_ms / (dt * 1e3 / args.steps),
+        "round_wall_ms_per_step": {rname[r]: float(round_ms[r]) / args.steps for r in range(4)},
+    }
+    if not args.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = cpu_baseline_pairs(args, gix, reads.cpu().numpy().reshape(npairs, rlen), mates.cpu().numpy().reshape(npairs, rlen), rlen, (cores, host_cores))
+        except Exception as e:
+            line["cpu_baseline"] = dict(value=None, unit="read pairs/s", cores=0, kind="reference", sample="failed: %r" % (e,))
+    print(json.dumps(line), flush=True)
+    for h in handles:
+        L.smaltgpu_pairs_free(h)
+    for mp in mappers:
+        mp.close()
+    gix.close()
 
 
 def main():
     args = parse_args()
     if args.paired:
-        print(json.dumps(paired_line(args)), flush=True)
+        if args.gpus > 1:
+            raise SystemExit("--paired measures one GPU (configs[2]); the multi-GPU line is the single-end job (configs[3])")
+        paired_main(args)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))            # before torch / HIP are touched in this process

@@ -180,6 +180,20 @@ int smaltgpu_map_batch_ctx(smaltgpu_mapper *m, const uint8_t *bases, const uint8
 int smaltgpu_hit_totals(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
                         const smaltgpu_params *par, uint32_t *nhits);
 
+/* The same two calls for rounds whose reads come from two batches that are already resident in HBM (reads and mates of a block of
+ * pairs): read i of the round is read ids[i] >> 1 of batch ids[i] & 1; the mapper gathers the round on the device.  Only the
+ * offsets are needed on the host (read lengths). */
+typedef struct smaltgpu_resident_reads {
+  const uint8_t *d_bases[2], *d_quals[2];     /* device; d_quals: both or neither */
+  const uint64_t *d_read_off[2];              /* device: nreads[w] + 1 offsets */
+  const uint64_t *read_off[2];                /* the same offsets in host memory */
+  uint32_t nreads[2];
+} smaltgpu_resident_reads;
+int smaltgpu_map_batch_ctx_resident(smaltgpu_mapper *m, const smaltgpu_resident_reads *src, const uint32_t *ids, uint32_t nreads,
+                                    const smaltgpu_params *par, const smaltgpu_callctx *ctx, smaltgpu_batch_out *out);
+int smaltgpu_hit_totals_resident(smaltgpu_mapper *m, const smaltgpu_resident_reads *src, const uint32_t *ids, uint32_t nreads,
+                                 const smaltgpu_params *par, uint32_t *nhits);
+
 /* ---- paired reads, whole: rmapPair (rmap.h:175-194, rmap.c:1744-2112) for a BLOCK of pairs -------------------
  * smaltgpu_map_pairs runs the block through the rounds above -- hit totals, first mate, second mate restricted, second mate
  * again, first mate again over the on-the-fly index; each round one batch of smaltgpu_map_batch_ctx -- and takes the decisions
@@ -208,9 +222,18 @@ void smaltgpu_pairs_free(smaltgpu_pairs *p);
 int smaltgpu_map_pairs(smaltgpu_mapper *m, const uint8_t *bases1, const uint8_t *quals1, const uint64_t *read_off1, const uint8_t *bases2,
                        const uint8_t *quals2, const uint64_t *read_off2, uint32_t npairs, const smaltgpu_params *par, const smaltgpu_pair_opts *po,
                        smaltgpu_pairs *out);
+/* Same with the reads and mates of the block resident in HBM (bench.py: the timed region starts with the inputs on the device).
+ * `src` as above; host copies of the bases / qualities are optional: `bases1/2` are needed when alignments can cross reference
+ * sequences (concatenated mode: the pieces are scored again on the host), `quals1/2` for the base-quality rule among equally
+ * good alignments (results.c:1247-1285; without them reads count as FASTA input there). */
+int smaltgpu_map_pairs_resident(smaltgpu_mapper *m, const smaltgpu_resident_reads *src, const uint8_t *bases1, const uint8_t *quals1, const uint8_t *bases2,
+                                const uint8_t *quals2, uint32_t npairs, const smaltgpu_params *par, const smaltgpu_pair_opts *po, smaltgpu_pairs *out);
 /* what a block looked like: per pair the flags and counts above; calls[4] (may be NULL) = mapping calls per round; round_ms[4]
  * (may be NULL) = host wall time of each round's batch incl. its copies */
 int smaltgpu_pairs_info(const smaltgpu_pairs *p, uint32_t *npairs, const smaltgpu_pair_info **info, uint64_t *calls, double *round_ms);
+/* device time per kernel (ms[5][16]: rounds 0-3 and the hit totals, kernels in the order of smaltgpu_timer_name) and the mapper's
+ * work counters (work[5][32]) summed over the block's batches; either may be NULL.  For bench.py's roofline object. */
+int smaltgpu_pairs_timers(const smaltgpu_pairs *p, double *kernel_ms, uint64_t *work);
 /* the index a mapper was created on, and the batch it was sized for (smaltgpu_map_pairs takes blocks of up to max_batch_reads pairs) */
 const smaltgpu_index *smaltgpu_mapper_index(const smaltgpu_mapper *m);
 int smaltgpu_mapper_capacity(const smaltgpu_mapper *m, uint32_t *max_batch_reads, uint32_t *max_read_len, uint64_t *max_bases);

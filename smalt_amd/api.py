@@ -87,6 +87,21 @@ REP_SOFTCLIP, REP_HEADER, REP_XMISMATCH = 0x02, 0x04, 0x08
 OUT_BEST, OUT_SINGLE, OUT_RANDSEL = 0x01, 0x02, 0x08
 
 
+class PairOpts(C.Structure):           # smaltgpu_pair_opts
+    _fields_ = [("insert_min", C.c_int32), ("insert_max", C.c_int32), ("library", C.c_int32), ("every_pair", C.c_int32), ("nthreads", C.c_int32)]
+
+
+class PairInfo(C.Structure):           # smaltgpu_pair_info
+    _fields_ = [("pairflg", C.c_uint8), ("rounds", C.c_uint8), ("nali", C.c_uint16 * 2)]
+
+
+LIB_PE, LIB_MP, LIB_PP, LIB_ANY = 1, 2, 3, 4
+
+
+class ResidentReads(C.Structure):      # smaltgpu_resident_reads
+    _fields_ = [("d_bases", C.c_void_p * 2), ("d_quals", C.c_void_p * 2), ("d_read_off", C.c_void_p * 2), ("read_off", C.c_void_p * 2), ("nreads", C.c_uint32 * 2)]
+
+
 class MapperOpts(C.Structure):
     _fields_ = [("cands_per_read", C.c_uint32), ("slot_budget_gb", C.c_uint32)]
 
@@ -144,6 +159,16 @@ def lib():
                                              C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.smaltgpu_report_emit.argtypes = [C.c_void_p, C.POINTER(PostOut), C.POINTER(BatchOut), C.POINTER(ReadsView), C.POINTER(C.c_char_p), C.c_int64,
                                            C.POINTER(ReportOpts), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.smaltgpu_pairs_create.restype = C.c_void_p
+        L.smaltgpu_pairs_free.argtypes = [C.c_void_p]
+        L.smaltgpu_map_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Params),
+                                         C.POINTER(PairOpts), C.c_void_p]
+        L.smaltgpu_pairs_timers.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.smaltgpu_map_pairs_resident.argtypes = [C.c_void_p, C.POINTER(ResidentReads), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Params),
+                                                  C.POINTER(PairOpts), C.c_void_p]
+        L.smaltgpu_pairs_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.POINTER(PairInfo)), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+        L.smaltgpu_report_emit_pairs.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ReadsView), C.POINTER(ReadsView), C.POINTER(C.c_char_p), C.c_int64,
+                                                 C.POINTER(ReportOpts), C.POINTER(PairOpts), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.smaltgpu_index_seqnames.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_int64)]
         L.smaltgpu_map_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
                                                 C.POINTER(Params)]
@@ -326,6 +351,24 @@ class Mapper:
         out = (C.c_uint32 * max(1, len(reads)))()
         _check(lib().smaltgpu_hit_totals(self.h, bases, q, off, len(reads), C.byref(params), out))
         return list(out)[:len(reads)]
+
+    def map_pairs_raw(self, bases1, off1, quals1, bases2, off2, quals2, params: Params, popts: PairOpts, pairs_handle=None):
+        """smaltgpu_map_pairs on contiguous host arrays (numpy uint8 bases / uint64 offsets per mate file): rmapPair for a block.
+        -> (handle of the mapped block, numpy view of smaltgpu_pair_info, calls per round, host ms per round); the handle goes to
+        smaltgpu_report_emit_pairs and is freed with lib().smaltgpu_pairs_free (or handed back in as pairs_handle)."""
+        import numpy as np
+        L = lib()
+        h = pairs_handle or C.c_void_p(L.smaltgpu_pairs_create())
+        n = len(off1) - 1
+        ptr = lambda a: None if a is None else C.c_void_p(a.ctypes.data)
+        _check(L.smaltgpu_map_pairs(self.h, ptr(bases1), ptr(quals1), ptr(off1), ptr(bases2), ptr(quals2), ptr(off2), n, C.byref(params), C.byref(popts), h))
+        npairs = C.c_uint32()
+        info = C.POINTER(PairInfo)()
+        calls = (C.c_uint64 * 4)()
+        ms = (C.c_double * 4)()
+        _check(L.smaltgpu_pairs_info(h, C.byref(npairs), C.byref(info), calls, ms))
+        arr = np.ctypeslib.as_array(C.cast(info, C.POINTER(C.c_uint8)), shape=(max(1, npairs.value), 6))[:npairs.value]
+        return h, arr, list(calls), list(ms)
 
     def map_batch_raw(self, bases, off, quals, params: Params) -> BatchOut:
         """smaltgpu_map_batch on contiguous host arrays (numpy uint8 bases / uint64 offsets); the returned

@@ -305,6 +305,7 @@ struct smaltgpu_mapper {
   // device buffers
   uint8_t *d_bases = nullptr, *d_quals = nullptr, *d_codes = nullptr, *d_codes_rc = nullptr;
   uint64_t *d_off = nullptr;
+  uint32_t *d_ids = nullptr;                  // read ids of a round gathered from resident batches (smaltgpu_map_batch_ctx_resident)
   Batch b;
   uint8_t *d_counters = nullptr;            // rc_count | res_count | dstr_count | err_flag | work[8]
   uint8_t *seed_scr = nullptr; size_t seed_bytes = 0; uint32_t seed_slots = 0;
@@ -400,6 +401,7 @@ extern "C" int smaltgpu_mapper_create_ex(smaltgpu_mapper **out, const smaltgpu_i
 #define DA(ptr, n) if (!rv) rv = dalloc(&(ptr), (size_t)(n))
   DA(m->d_bases, m->max_bases + 16); DA(m->d_quals, m->max_bases + 16); DA(m->d_codes, m->max_bases + 16); DA(m->d_codes_rc, m->max_bases + 16);
   DA(m->d_off, (size_t)max_batch_reads + 1);
+  DA(m->d_ids, (size_t)max_batch_reads + 1);
   DA(b.hi, 2 * (size_t)max_batch_reads);
   DA(b.seeds, 2 * (size_t)max_batch_reads * m->qmax);
   DA(b.qmask, 2 * (size_t)max_batch_reads * m->qmax);
@@ -562,7 +564,7 @@ extern "C" int smaltgpu_mapper_create_ex(smaltgpu_mapper **out, const smaltgpu_i
 extern "C" void smaltgpu_mapper_free(smaltgpu_mapper *m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
-  void *ps[] = {m->d_bases, m->d_quals, m->d_codes, m->d_codes_rc, m->d_off, m->b.hi, m->b.seeds, m->b.qmask, m->b.ch, m->b.ctl,
+  void *ps[] = {m->d_bases, m->d_quals, m->d_codes, m->d_codes_rc, m->d_off, m->d_ids, m->b.hi, m->b.seeds, m->b.qmask, m->b.ch, m->b.ctl,
                 m->b.stat, m->b.align_retry, m->b.cands_retry, m->b.rcpool, m->b.long_list, m->b.strip_list, m->strip_bnd, m->strip_win, m->b.respool, m->b.dstrpool, m->d_counters, m->seed_scr, m->cand_scr, m->cand_scr2, m->cand_scr_dbg,
                 m->sw_rows, m->align_scr, m->align_scr2};
   for (void *p : ps) if (p) (void)hipFree(p);
@@ -956,6 +958,8 @@ extern "C" int smaltgpu_hit_totals(smaltgpu_mapper *m, const uint8_t *bases, con
   m->h_hi.resize(2 * (size_t)nreads + 1);
   if (nreads) HIPCHK(hipMemcpyAsync(m->h_hi.data(), m->b.hi, 2 * (size_t)nreads * sizeof(HitInfoHdr), hipMemcpyDeviceToHost, m->stream));
   HIPCHK(hipStreamSynchronize(m->stream));
+  for (int i = 0; i < T_NUM; i++) { float f = 0; (void)hipEventElapsedTime(&f, m->ev[i], m->ev[i + 1]); m->ms[i] = f; }      // seeding only: the later stages read 0
+  memset(m->work, 0, sizeof(m->work));
   for (uint32_t i = 0; i < nreads; i++) nhits[i] = m->h_hi[2 * (size_t)i].nhit_cut + m->h_hi[2 * (size_t)i + 1].nhit_cut;
   return SMALTGPU_OK;
 }
@@ -972,6 +976,76 @@ extern "C" int smaltgpu_map_batch_ctx(smaltgpu_mapper *m, const uint8_t *bases, 
   rv = map_range(m, bases, quals, read_off, nreads, par, out, ctx);
   if (rv == SMALTGPU_ECAP && out->nreads == nreads && nreads > 0 && !m->debug) return remap_overflowed(m, bases, quals, read_off, nreads, par, out, ctx);
   return rv;
+}
+
+// ---- rounds over batches that are resident in HBM (reads and mates of a block of pairs): the round's reads are gathered on the
+// device; only the offsets (lengths) are needed on the host ----
+static int gather_round(smaltgpu_mapper *m, const smaltgpu_resident_reads *src, const uint32_t *ids, uint32_t nreads, bool *with_quals) {
+  m->h_off.resize((size_t)nreads + 1);
+  uint64_t tot = 0;
+  for (uint32_t i = 0; i < nreads; i++) {
+    const uint32_t w = ids[i] & 1u, r = ids[i] >> 1;
+    if (r >= src->nreads[w]) return fail(SMALTGPU_EARG, "read id %u is outside its batch", ids[i]);
+    const uint64_t len = src->read_off[w][r + 1] - src->read_off[w][r];
+    if (len > m->max_len) return fail(SMALTGPU_EARG, "read %u is longer than the mapper's max_read_len", i);
+    m->h_off[i] = tot;
+    tot += len;
+  }
+  m->h_off[nreads] = tot;
+  if (tot > m->max_bases) return fail(SMALTGPU_EARG, "batch exceeds the mapper's base capacity");
+  *with_quals = src->d_quals[0] && src->d_quals[1];
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipMemcpyAsync(m->d_off, m->h_off.data(), ((size_t)nreads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
+  HIPCHK(hipMemcpyAsync(m->d_ids, ids, (size_t)nreads * sizeof(uint32_t), hipMemcpyHostToDevice, m->stream));
+  const int rv = launch_gather_reads(m->stream, m->d_bases, *with_quals ? m->d_quals : nullptr, m->d_off, nreads, m->d_ids, src->d_bases, src->d_quals, src->d_read_off);
+  if (rv) return fail(SMALTGPU_ENODEV, "kernel launch failed: %s", hipGetErrorString((hipError_t)rv));
+  return SMALTGPU_OK;
+}
+
+extern "C" int smaltgpu_map_batch_ctx_resident(smaltgpu_mapper *m, const smaltgpu_resident_reads *src, const uint32_t *ids, uint32_t nreads,
+                                                const smaltgpu_params *par, const smaltgpu_callctx *ctx, smaltgpu_batch_out *out) {
+  if (!m || !src || !ids || !par || !out || !src->d_bases[0] || !src->d_bases[1] || !src->d_read_off[0] || !src->d_read_off[1] || !src->read_off[0] || !src->read_off[1])
+    return fail(SMALTGPU_EARG, "null argument");
+  if (nreads > m->max_reads) return fail(SMALTGPU_EARG, "batch of %u reads exceeds the mapper's capacity %u", nreads, m->max_reads);
+  int rv = check_par(m, par);
+  if (rv) return rv;
+  out->nreads = 0;
+  bool wq = false;
+  if ((rv = gather_round(m, src, ids, nreads, &wq))) return rv;
+  CtxDev cd;
+  if (ctx) { const int cr = upload_ctx(m, ctx, nreads, &cd); if (cr) return cr; }
+  rv = run_pipeline(m, m->d_bases, wq ? m->d_quals : nullptr, m->d_off, nreads, par, ctx ? &cd : nullptr, false);
+  m->have_host_off = true;
+  if (!rv) rv = smaltgpu_fetch_results(m, out);
+  if (rv == SMALTGPU_ECAP && out->nreads == nreads && nreads > 0 && !m->debug) {
+    // a pool overflowed: the reads that did not fit are mapped again in smaller batches, from a host copy of the gathered round
+    const uint64_t tot = m->h_off[nreads];
+    std::vector<uint8_t> hb(tot + 1), hq(wq ? tot + 1 : 0);
+    std::vector<uint64_t> ho(m->h_off.begin(), m->h_off.begin() + nreads + 1);
+    HIPCHK(hipMemcpy(hb.data(), m->d_bases, tot, hipMemcpyDeviceToHost));
+    if (wq) HIPCHK(hipMemcpy(hq.data(), m->d_quals, tot, hipMemcpyDeviceToHost));
+    return remap_overflowed(m, hb.data(), wq ? hq.data() : nullptr, ho.data(), nreads, par, out, ctx);
+  }
+  return rv;
+}
+
+extern "C" int smaltgpu_hit_totals_resident(smaltgpu_mapper *m, const smaltgpu_resident_reads *src, const uint32_t *ids, uint32_t nreads,
+                                             const smaltgpu_params *par, uint32_t *nhits) {
+  if (!m || !src || !ids || !par || !nhits) return fail(SMALTGPU_EARG, "null argument");
+  if (nreads > m->max_reads) return fail(SMALTGPU_EARG, "batch of %u reads exceeds the mapper's capacity %u", nreads, m->max_reads);
+  int rv = check_par(m, par);
+  if (rv) return rv;
+  bool wq = false;
+  if ((rv = gather_round(m, src, ids, nreads, &wq))) return rv;
+  rv = run_pipeline(m, m->d_bases, wq ? m->d_quals : nullptr, m->d_off, nreads, par, nullptr, true);
+  if (rv) return rv;
+  m->h_hi.resize(2 * (size_t)nreads + 1);
+  if (nreads) HIPCHK(hipMemcpyAsync(m->h_hi.data(), m->b.hi, 2 * (size_t)nreads * sizeof(HitInfoHdr), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  for (int i = 0; i < T_NUM; i++) { float f = 0; (void)hipEventElapsedTime(&f, m->ev[i], m->ev[i + 1]); m->ms[i] = f; }      // seeding only: the later stages read 0
+  memset(m->work, 0, sizeof(m->work));
+  for (uint32_t i = 0; i < nreads; i++) nhits[i] = m->h_hi[2 * (size_t)i].nhit_cut + m->h_hi[2 * (size_t)i + 1].nhit_cut;
+  return SMALTGPU_OK;
 }
 
 extern "C" int smaltgpu_timers(const smaltgpu_mapper *m, double *ms, uint64_t *work, int n) {

@@ -1,6 +1,7 @@
-// smaltgpu-map -- `smalt map` for single reads on top of the C ABI of include/smaltgpu.h, file to file:
+// smaltgpu-map -- `smalt map` for single reads and read pairs on top of the C ABI of include/smaltgpu.h, file to file:
 //   FASTQ/FASTA text --smaltgpu_reads_parse--> batch --smaltgpu_map_batch (GPU)--> raw alignments
-//   --smaltgpu_postprocess--> mapping qualities, order --smaltgpu_report_emit--> CIGAR / SAM text.
+//   --smaltgpu_postprocess--> mapping qualities, order --smaltgpu_report_emit--> CIGAR / SAM text;
+//   two files of mates: --smaltgpu_map_pairs (the rounds of rmapPair on the GPU)--> --smaltgpu_report_emit_pairs--> text.
 // The option letters, defaults and derived flags follow the reference's `smalt map` (menu.c:1147-1160 defaults,
 // :1340-1345 -d, :1487-1497 -r; smalt.c:209-245 output formats, :490-503 result flags, :608-615 default -m) so that the
 // same command line prints the same lines (tests/test_gpu_report.py).  Host code only: it needs libsmaltgpu.so, not hipcc.
@@ -39,7 +40,7 @@ const char VERSION[] = "0.2";
 
 void usage() {
   fprintf(stderr,
-          "usage: smaltgpu-map [options] <index prefix> <reads.fq|reads.fa>[.gz]\n"
+          "usage: smaltgpu-map [options] <index prefix> <reads.fq|reads.fa>[.gz] [<mates.fq|mates.fa>[.gz]]\n"
           "  -f <fmt>   cigar (default) | sam | samsoft, SAM modifiers behind a colon: nohead, clip, x (e.g. sam:nohead,x)\n"
           "  -o <file>  output file (default: standard output)\n"
           "  -m <int>   minimum Smith-Waterman score (default: word length + step - 1)\n"
@@ -54,13 +55,17 @@ void usage() {
           "  -B <int>   reads per GPU batch (default 262144)\n"
           "  -g <list>  devices, e.g. 0 or 0,1,2,3 (default 0): the index is read once and copied device to device, every device gets\n"
           "             two mappers (SMALTGPU_MAP_WORKERS: 1-4), blocks go to whichever is free\n"
-          "single reads only; paired reads (-i -j -l -p), split reads (-p) and -w go through the bound reference program (INTEGRATION.md)\n");
+          "  -i <int>   maximum insert size of read pairs (default 500); -j <int> minimum insert size (default 0)\n"
+          "  -l <lib>   pair library: pe (default) | mp | pp\n"
+          "with two read files the reads are mapped as pairs (read i of the first with read i of the second file);\n"
+          "split reads (-p), -w and insert-size histograms (-g) go through the bound reference program (INTEGRATION.md)\n");
   exit(2);
 }
 
-struct Block {                                  // one block of reads on its way through the stages
-  smaltgpu_reads *rs = nullptr;
-  smaltgpu_reads_view v;
+struct Block {                                  // one block of reads (or pairs) on its way through the stages
+  smaltgpu_reads *rs = nullptr, *rs2 = nullptr;
+  smaltgpu_reads_view v, v2;                    // v2: the mates
+  smaltgpu_pairs *pairs = nullptr;
   uint32_t maxlen = 0;
   int state = 0;                                // 0 free, 1 parsed, 2 mapped + post-processed, 3 end of input
   int worker = -1;
@@ -126,7 +131,7 @@ struct Source {
 
 int main(int argc, char **argv) {
   const char *fmt = "cigar", *oufil = nullptr;
-  int m = -1, d = 0, seed = 0, q = 0, nthreads = 0;
+  int m = -1, d = 0, seed = 0, q = 0, nthreads = 0, ins_max = 500, ins_min = 0, lib = SMALTGPU_LIB_PE;
   std::vector<int> devices;
   bool d_given = false, randrepeat = true, exhaustive = false;
   double minid = 0.0, mincover = 0.0;
@@ -135,8 +140,8 @@ int main(int argc, char **argv) {
   for (; a < argc && argv[a][0] == '-' && argv[a][1]; a++) {
     const char o = argv[a][1];
     if (o == 'x' && !argv[a][2]) { exhaustive = true; continue; }
-    if (argv[a][2] || !strchr("fomdrycqnBg", o)) {
-      if (strchr("ijlpwSTFa", o) && !argv[a][2]) die("option not supported by this program (use the bound `smalt map`, INTEGRATION.md)", argv[a]);
+    if (argv[a][2] || !strchr("fomdrycqnBgijl", o)) {
+      if (strchr("pwSTFa", o) && !argv[a][2]) die("option not supported by this program (use the bound `smalt map`, INTEGRATION.md)", argv[a]);
       usage();
     }
     if (a + 1 >= argc) usage();
@@ -151,12 +156,17 @@ int main(int argc, char **argv) {
       case 'c': mincover = atof(val); if (mincover < 0) die("-c out of range"); break;
       case 'q': q = atoi(val); break;
       case 'n': nthreads = atoi(val); break;
+      case 'i': ins_max = atoi(val); break;
+      case 'j': ins_min = atoi(val); break;
+      case 'l': lib = !strcmp(val, "pe") ? SMALTGPU_LIB_PE : !strcmp(val, "mp") ? SMALTGPU_LIB_MP : !strcmp(val, "pp") ? SMALTGPU_LIB_PP : 0; if (!lib) die("-l: pe, mp or pp"); break;
       case 'B': batch = atol(val); if (batch < 1 || batch > (1L << 20)) die("-B out of range (1 .. 1048576)"); break;
       case 'g': for (const char *c = val; *c;) { devices.push_back(atoi(c)); while (*c && *c != ',') c++; if (*c) c++; } break;
     }
   }
-  if (argc - a != 2) usage();
-  const char *prefix = argv[a], *readfil = argv[a + 1];
+  if (argc - a != 2 && argc - a != 3) usage();
+  const char *prefix = argv[a], *readfil = argv[a + 1], *matefil = argc - a == 3 ? argv[a + 2] : nullptr;
+  const bool paired = matefil != nullptr;
+  if (paired && ins_min > ins_max) die("-j above -i");
   if (nthreads < 1) { nthreads = (int)std::thread::hardware_concurrency(); if (nthreads > 16) nthreads = 16; if (nthreads < 1) nthreads = 1; }
 
   smaltgpu_report_opts ro;
@@ -186,8 +196,9 @@ int main(int argc, char **argv) {
   }
   if (ro.outflags & SMALTGPU_OUT_RANDSEL) srand48(seed <= 0 ? (long)time(nullptr) : (long)seed);     // RANSEED (randef.h:19)
 
-  Source src;                                                                            // input: plain or gzip text
+  Source src, src2;                                                                      // input: plain or gzip text
   src.open(readfil);
+  if (paired) src2.open(matefil);
   FILE *ou = oufil ? fopen(oufil, "w") : stdout;
   if (!ou) die("cannot write", oufil);
   static char oubuf[1 << 22];
@@ -213,6 +224,9 @@ int main(int argc, char **argv) {
   if (exhaustive) par.rmapflg |= SMALTGPU_FLG_NOSHRTINFO | SMALTGPU_FLG_SENSITIVE;      // smalt.c:531-533
   par.min_basqval = (uint8_t)q;
   if (mincover < 1.01) { par.min_cover = 0; par.min_cover_frac = mincover; } else { par.min_cover = (uint32_t)mincover; par.min_cover_frac = 0.0; }   // smalt.c:1113-1126
+  smaltgpu_pair_opts po;
+  po.insert_min = ins_min; po.insert_max = ins_max; po.library = lib; po.every_pair = exhaustive ? 1 : 0;                              // smalt.c:533 (-x: RMAPFLG_ALLPAIR)
+  po.nthreads = nthreads > 2 ? nthreads / 2 : 1;
   const uint32_t *packed = (par.rmapflg & SMALTGPU_FLG_SEQBYSEQ) ? nullptr : smaltgpu_index_packed_host(ix);    // concatenated mode: alignments across junctions are cut
   if (!(par.rmapflg & SMALTGPU_FLG_SEQBYSEQ) && !packed) die("index", smaltgpu_last_error());
 
@@ -230,7 +244,9 @@ int main(int argc, char **argv) {
   if (per_dev * ndev > MAXWORK) per_dev = MAXWORK / ndev;
   const int NWORK = per_dev * ndev, NBLK = NWORK + 2;
   std::vector<Block> blk((size_t)NBLK);
-  for (Block &b : blk) b.rs = smaltgpu_reads_create();
+  for (Block &b : blk) { b.rs = smaltgpu_reads_create(); if (paired) { b.rs2 = smaltgpu_reads_create(); b.pairs = smaltgpu_pairs_create(); } }
+  // a failing call's text, never empty (the block must not pass for mapped when a call failed without a message)
+  auto why = [](const char *what) { const char *e = smaltgpu_last_error(); return std::string(e && *e ? e : what); };
   std::mutex mu;
   std::condition_variable cv;
   uint64_t n_parsed = 0, n_taken = 0, n_written = 0;      // block serial numbers: block k lives in blk[k % NBLK]
@@ -246,23 +262,38 @@ int main(int argc, char **argv) {
       { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return failed || k < n_written + NBLK; }); if (failed) return; }
       uint64_t win = bytes_per_read > 0 ? (uint64_t)(bytes_per_read * (double)batch * 1.05) + 65536 : (1u << 20);
       const double tp0 = now();
-      bool last = false;
-      for (;;) {
-        uint64_t got = 0;
-        const char *text = src.window(win, &got, &last);
-        if (!got) { b.v.nreads = 0; break; }
-        if (smaltgpu_reads_parse(b.rs, text, got, last ? 1 : 0, (uint32_t)batch, nthreads, &b.v)) {
-          std::lock_guard<std::mutex> lk(mu); b.err = smaltgpu_last_error(); failed = true; cv.notify_all(); return;
+      // up to `want` reads from a source; exact: the block must hold exactly that many unless the source ends (the mates of a block)
+      auto parse_from = [&](Source &sc, smaltgpu_reads *rs, smaltgpu_reads_view *v, uint32_t want, bool exact) -> bool {
+        bool last = false;
+        uint64_t w = win;
+        for (;;) {
+          uint64_t got = 0;
+          const char *text = sc.window(w, &got, &last);
+          if (!got) { v->nreads = 0; return true; }
+          if (smaltgpu_reads_parse(rs, text, got, last ? 1 : 0, want, nthreads, v)) {
+            std::lock_guard<std::mutex> lk(mu); b.err = why("cannot parse the reads"); failed = true; cv.notify_all(); return false;
+          }
+          if (last || (exact ? v->nreads == want : v->nreads > 0)) return true;
+          w *= 4;                                          // not enough complete records in the window
         }
-        if (b.v.nreads || last) break;
-        win *= 4;                                          // not one complete record in the window
+      };
+      if (!parse_from(src, b.rs, &b.v, (uint32_t)batch, false)) return;
+      if (paired && b.v.nreads) {
+        if (!parse_from(src2, b.rs2, &b.v2, b.v.nreads, true)) return;
+        if (b.v2.nreads != b.v.nreads) { std::lock_guard<std::mutex> lk(mu); b.err = "the two read files hold different numbers of reads"; failed = true; cv.notify_all(); return; }
+      } else if (paired) {
+        bool last2 = false; uint64_t got2 = 0;
+        (void)src2.window(1, &got2, &last2);
+        if (got2) { std::lock_guard<std::mutex> lk(mu); b.err = "the two read files hold different numbers of reads"; failed = true; cv.notify_all(); return; }
       }
       if (!b.v.nreads) { std::lock_guard<std::mutex> lk(mu); n_blocks_total = k; input_done = true; cv.notify_all(); return; }
       t_parse += now() - tp0;
       bytes_per_read = (double)b.v.consumed / (double)b.v.nreads;
       src.consume(b.v.consumed);
+      if (paired) src2.consume(b.v2.consumed);
       b.maxlen = 1;
       for (uint32_t i = 0; i < b.v.nreads; i++) { const uint32_t l = (uint32_t)(b.v.read_off[i + 1] - b.v.read_off[i]); if (l > b.maxlen) b.maxlen = l; }
+      if (paired) for (uint32_t i = 0; i < b.v2.nreads; i++) { const uint32_t l = (uint32_t)(b.v2.read_off[i + 1] - b.v2.read_off[i]); if (l > b.maxlen) b.maxlen = l; }
       { std::lock_guard<std::mutex> lk(mu); b.state = 1; n_parsed = k + 1; cv.notify_all(); }
     }
   });
@@ -289,19 +320,25 @@ int main(int argc, char **argv) {
         W.mp = nullptr;
         const uint32_t cr = b.v.nreads > (uint32_t)batch ? b.v.nreads : (uint32_t)batch, cl = (b.maxlen + 31u) & ~31u;
         smaltgpu_mapper_opts mo = {0, (uint32_t)(per_dev <= 2 ? 28 : 18)};      // the mappers of a device share its memory: candidate slots of 18-28 GB each
-        if (smaltgpu_mapper_create_ex(&W.mp, ixs[(size_t)(w % ndev)], cr, cl > W.cap_len ? cl : W.cap_len, &mo)) err = smaltgpu_last_error();
+        if (smaltgpu_mapper_create_ex(&W.mp, ixs[(size_t)(w % ndev)], cr, cl > W.cap_len ? cl : W.cap_len, &mo)) err = why("cannot create a mapper");
         else { W.cap_reads = cr; W.cap_len = cl > W.cap_len ? cl : W.cap_len; }
       }
       t1 = now(); t_create[w] += t1 - t0; t0 = t1;
-      if (err.empty()) {
+      if (err.empty() && paired) {
+        // the rounds of rmapPair for the block; the results rest in the block, the mapper is free for the next one
+        const bool q2 = b.v.has_qual && b.v2.has_qual;
+        if (smaltgpu_map_pairs(W.mp, b.v.bases, q2 ? b.v.quals : nullptr, b.v.read_off, b.v2.bases, q2 ? b.v2.quals : nullptr, b.v2.read_off, b.v.nreads, &par, &po, b.pairs))
+          err = why("mapping the pairs failed");
+        t1 = now(); t_map[w] += t1 - t0; t0 = t1;
+      } else if (err.empty()) {
         const int rv = smaltgpu_map_batch(W.mp, b.v.bases, b.v.has_qual ? b.v.quals : nullptr, b.v.read_off, b.v.nreads, &par, &b.raw);
-        if (rv && !((rv == SMALTGPU_ECAP || rv == SMALTGPU_EINTERNAL) && b.raw.nreads == b.v.nreads)) err = smaltgpu_last_error();
+        if (rv && !((rv == SMALTGPU_ECAP || rv == SMALTGPU_EINTERNAL) && b.raw.nreads == b.v.nreads)) err = why("mapping the reads failed");
+        t1 = now(); t_map[w] += t1 - t0; t0 = t1;
+        if (err.empty() && smaltgpu_postprocess(W.post, sop, nseq, &b.raw, b.v.bases, b.v.has_qual ? b.v.quals : nullptr, b.v.read_off, packed, &par,
+                                                nthreads > 2 ? nthreads / 2 : 1, &b.post)) err = why("post-processing failed");
+        t_post[w] += now() - t0;
       }
-      t1 = now(); t_map[w] += t1 - t0; t0 = t1;
-      if (err.empty() && smaltgpu_postprocess(W.post, sop, nseq, &b.raw, b.v.bases, b.v.has_qual ? b.v.quals : nullptr, b.v.read_off, packed, &par,
-                                              nthreads > 2 ? nthreads / 2 : 1, &b.post)) err = smaltgpu_last_error();
-      t_post[w] += now() - t0;
-      { std::lock_guard<std::mutex> lk(mu); b.worker = w; if (!err.empty()) { b.err = err; failed = true; } b.state = 2; cv.notify_all(); }
+      { std::lock_guard<std::mutex> lk(mu); b.worker = w; if (paired) W.busy = false; if (!err.empty()) { b.err = err; failed = true; } b.state = 2; cv.notify_all(); }
     }
   };
   std::vector<std::thread> workers;
@@ -321,12 +358,13 @@ int main(int argc, char **argv) {
     }
     const char *txt; uint64_t tl;
     t1 = now(); t_wait += t1 - t0; t0 = t1;
-    if (smaltgpu_report_emit(rep, &b.post, &b.raw, &b.v, seqnames, nseq, &ro, nthreads, &txt, &tl)) failure = smaltgpu_last_error();
+    if (paired ? smaltgpu_report_emit_pairs(rep, b.pairs, &b.v, &b.v2, seqnames, nseq, &ro, &po, nthreads, &txt, &tl)
+               : smaltgpu_report_emit(rep, &b.post, &b.raw, &b.v, seqnames, nseq, &ro, nthreads, &txt, &tl)) failure = why("formatting the report failed");
     t1 = now(); t_emit += t1 - t0; t0 = t1;
     if (failure.empty() && tl && fwrite(txt, 1, tl, ou) != tl) failure = "write error";
     t_write += now() - t0;
     nreads_total += b.v.nreads;
-    { std::lock_guard<std::mutex> lk(mu); b.state = 0; wk[b.worker].busy = false; n_written = k + 1; if (!failure.empty()) failed = true; cv.notify_all(); }
+    { std::lock_guard<std::mutex> lk(mu); b.state = 0; if (!paired) wk[b.worker].busy = false; n_written = k + 1; if (!failure.empty()) failed = true; cv.notify_all(); }
     if (!failure.empty()) break;
   }
   { std::lock_guard<std::mutex> lk(mu); if (!failure.empty()) failed = true; cv.notify_all(); }
@@ -334,14 +372,14 @@ int main(int argc, char **argv) {
   for (std::thread &t : workers) t.join();
   if (failed && failure.empty()) for (Block &x : blk) if (!x.err.empty()) failure = x.err;
   for (Worker &W : wk) { if (W.mp) smaltgpu_mapper_free(W.mp); if (W.post) smaltgpu_post_free(W.post); }
-  for (Block &b : blk) smaltgpu_reads_free(b.rs);
+  for (Block &b : blk) { smaltgpu_reads_free(b.rs); if (b.rs2) smaltgpu_reads_free(b.rs2); if (b.pairs) smaltgpu_pairs_free(b.pairs); }
   smaltgpu_report_free(rep);
   for (smaltgpu_index *x : ixs) smaltgpu_index_free(x);
   if (ou != stdout) { if (fclose(ou)) failure = "write error"; } else fflush(ou);
   if (failed || !failure.empty()) die("failed", failure.c_str());
   if (getenv("SMALTGPU_MAP_VERBOSE")) {
     const double ti = std::chrono::duration<double>(t_index - t_start).count(), tm = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_index).count();
-    fprintf(stderr, "smaltgpu-map: %llu reads, index load %.3f s, reads in to lines out %.3f s (%.0f reads/s)\n", (unsigned long long)nreads_total, ti, tm,
+    fprintf(stderr, "smaltgpu-map: %llu reads (or pairs), index load %.3f s, reads in to lines out %.3f s (%.0f reads/s)\n", (unsigned long long)nreads_total, ti, tm,
             tm > 0 ? (double)nreads_total / tm : 0.0);
     double tc = 0, tm_ = 0, tp = 0;
     for (int w = 0; w < NWORK; w++) { tc += t_create[w]; tm_ += t_map[w]; tp += t_post[w]; }

@@ -9,6 +9,8 @@ enum : int { SW_FULL_WMAX = 1016,   // longest reference window of the register-
              SW_SHORT_WMAX = 248 };  // windows up to here take the small-LDS instance of the packed kernel (more resident waves)
 
 int launch_encode(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint32_t n, uint8_t *codes, uint8_t *codes_rc);
+int launch_gather_reads(hipStream_t s, uint8_t *dst_bases, uint8_t *dst_quals, const uint64_t *dst_off, uint32_t n, const uint32_t *ids,
+                        const uint8_t *const src_bases[2], const uint8_t *const src_quals[2], const uint64_t *const src_off[2]);
 int launch_fine_index(hipStream_t s, const Batch &b, const DevIndex &ix);     // needs b.iv_off/iv, b.fine_idx/fine_pos/fine_off
 int launch_seed(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint8_t *scratch, size_t sbytes, uint32_t nslots);
 struct CandGeom {              // scratch geometry of the candidate stage (both code paths share one HBM slot)

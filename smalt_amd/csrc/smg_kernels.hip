@@ -28,6 +28,28 @@ __global__ void __launch_bounds__(64) k_encode(const uint8_t *bases, const uint6
   }
 }
 
+// The reads of one round of a block of pairs, taken from the two batches that are resident in HBM (reads and mates): read i of
+// the round is read ids[i] >> 1 of batch ids[i] & 1.  One workgroup per read, bytes copied 16 at a time where both sides
+// allow it (HBM to HBM, coalesced on both ends).
+__global__ void __launch_bounds__(64) k_gather_reads(uint8_t *dst_bases, uint8_t *dst_quals, const uint64_t *dst_off, uint32_t n, const uint32_t *ids,
+                                                     const uint8_t *b0, const uint8_t *b1, const uint8_t *q0, const uint8_t *q1, const uint64_t *o0, const uint64_t *o1) {
+  for (uint32_t r = blockIdx.x; r < n; r += gridDim.x) {
+    const uint32_t id = ids[r], w = id & 1u, i = id >> 1;
+    const uint64_t so = w ? o1[i] : o0[i], d = dst_off[r];
+    const uint32_t len = (uint32_t)(dst_off[r + 1] - d);
+    const uint8_t *sb = (w ? b1 : b0) + so, *sq = dst_quals ? (w ? q1 : q0) + so : nullptr;
+    if ((((uintptr_t)sb | (uintptr_t)(dst_bases + d)) & 15u) == 0 && (!sq || (((uintptr_t)sq | (uintptr_t)(dst_quals + d)) & 15u) == 0)) {
+      const uint32_t nv = len >> 4;
+      for (uint32_t v = threadIdx.x; v < nv; v += 64) {
+        ((uint4 *)(dst_bases + d))[v] = ((const uint4 *)sb)[v];
+        if (sq) ((uint4 *)(dst_quals + d))[v] = ((const uint4 *)sq)[v];
+      }
+      for (uint32_t t = (nv << 4) + threadIdx.x; t < len; t += 64) { dst_bases[d + t] = sb[t]; if (sq) dst_quals[d + t] = sq[t]; }
+    } else
+      for (uint32_t t = threadIdx.x; t < len; t += 64) { dst_bases[d + t] = sb[t]; if (sq) dst_quals[d + t] = sq[t]; }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // S1 + S2: one wave per (read, strand); scratch in LDS when it fits, else in HBM slots
 // ---------------------------------------------------------------------------------------
@@ -1227,6 +1249,16 @@ int launch_encode(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint
   if (!n) return 0;
   uint32_t grid = n < 16384u ? n : 16384u;
   hipLaunchKernelGGL(k_encode, dim3(grid), dim3(64), 0, s, bases, off, n, codes, codes_rc);
+  SMG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_gather_reads(hipStream_t s, uint8_t *dst_bases, uint8_t *dst_quals, const uint64_t *dst_off, uint32_t n, const uint32_t *ids,
+                        const uint8_t *const src_bases[2], const uint8_t *const src_quals[2], const uint64_t *const src_off[2]) {
+  if (!n) return 0;
+  const uint32_t grid = n < 32768u ? n : 32768u;
+  hipLaunchKernelGGL(k_gather_reads, dim3(grid), dim3(64), 0, s, dst_bases, dst_quals, dst_off, n, ids, src_bases[0], src_bases[1],
+                     dst_quals ? src_quals[0] : nullptr, dst_quals ? src_quals[1] : nullptr, src_off[0], src_off[1]);
   SMG_LAUNCH_CHECK();
   return 0;
 }

@@ -16,7 +16,7 @@
 namespace smgpairs {
 
 struct BlockInput {                         // two batches in the layout of smaltgpu_map_batch: [0] reads, [1] mates
-  const uint8_t *bases[2], *quals[2];       // quals[w] may be null
+  const uint8_t *bases[2], *quals[2];       // quals[w] may be null; bases[w] may be null when the reads are resident on the device
   const uint64_t *off[2];
   uint32_t npairs;
 };
@@ -75,9 +75,9 @@ struct PairBlock {
         if (st.max1scor >= 1) {                                        // a call without a score-pass hit returns before the pass (rmap.c:1376)
           smgpost::Read r;
           r.len = len_of(in, id);
-          r.bases = in.bases[w] + in.off[w][pr];
+          r.bases = in.bases[w] ? in.bases[w] + in.off[w][pr] : nullptr;
           r.quals = in.quals[w] ? in.quals[w] + in.off[w][pr] : nullptr;
-          const smgpost::Outcome oc = tb.settle(ref, r, bp.packed_host ? &pen : nullptr);
+          const smgpost::Outcome oc = tb.settle(ref, r, bp.packed_host && r.bases ? &pen : nullptr);
           if (oc != smgpost::DONE) {
             snprintf(msg, sizeof(msg), "pair %u, mate %u: %s", pr, w + 1, oc == smgpost::WANTS_REFERENCE ? "an alignment crosses reference sequences and no host copy of the reference was given" : tb.why);
             if (bad[(size_t)t].empty()) bad[(size_t)t] = msg;
@@ -242,5 +242,7 @@ struct smaltgpu_pairs {
   std::vector<smaltgpu_pair_info> info;
   uint64_t calls[4] = {0, 0, 0, 0};
   double round_ms[4] = {0, 0, 0, 0};
+  double kernel_ms[5][16];                    // per round (4 = hit totals) and kernel: device time of the block
+  uint64_t work[5][32];
 };
 #endif

@@ -17,10 +17,19 @@ struct DeviceExec {
   smaltgpu_params par;
   uint32_t cap_reads;
   uint64_t cap_bases;
+  const smaltgpu_resident_reads *resident = nullptr;      // the block's reads in HBM: rounds are gathered on the device
   std::vector<uint8_t> bases, quals;
   std::vector<uint64_t> off;
   double ms[4] = {0, 0, 0, 0};
+  double kernel_ms[5][16];                   // device time per kernel (smaltgpu_timer_name order), rounds 0-3 and [4] = the hit totals
+  uint64_t work[5][32];                      // the mapper's work counters likewise
   int rc = SMALTGPU_OK;
+  void tally(int slot) {
+    double t[16] = {0}; uint64_t w[32] = {0};
+    const int nt = smaltgpu_timers(m, t, w, 32);
+    for (int i = 0; i < nt && i < 16; i++) kernel_ms[slot][i] += t[i];
+    for (int i = 0; i < 32; i++) work[slot][i] += w[i];
+  }
   bool with_quals() const { return in.quals[0] && in.quals[1]; }
   void gather(const uint32_t *ids, uint32_t n) {
     off.resize((size_t)n + 1);
@@ -43,9 +52,14 @@ struct DeviceExec {
       uint64_t nb = 0;
       while (hi < n && hi - lo < cap_reads && nb + PairBlock::len_of(in, ids[hi]) <= cap_bases) nb += PairBlock::len_of(in, ids[hi++]);
       if (hi == lo) { rc = SMALTGPU_EARG; err = "a read is longer than the mapper was created for"; return false; }
-      gather(ids + lo, hi - lo);
-      const int rv = smaltgpu_hit_totals(m, bases.data(), with_quals() ? quals.data() : nullptr, off.data(), hi - lo, &par, hits + lo);
+      int rv;
+      if (resident) rv = smaltgpu_hit_totals_resident(m, resident, ids + lo, hi - lo, &par, hits + lo);
+      else {
+        gather(ids + lo, hi - lo);
+        rv = smaltgpu_hit_totals(m, bases.data(), with_quals() ? quals.data() : nullptr, off.data(), hi - lo, &par, hits + lo);
+      }
       if (rv) return fail_with(err, rv);
+      tally(4);
       lo = hi;
     }
     return true;
@@ -53,13 +67,18 @@ struct DeviceExec {
   bool map(const Round &rd, smaltgpu_batch_out *o, std::string &err) {
     const auto t0 = std::chrono::steady_clock::now();
     if (rd.n > cap_reads) { rc = SMALTGPU_EARG; err = "the block holds more pairs than the mapper's batch size"; return false; }
-    gather(rd.ids, rd.n);
     smaltgpu_callctx cx;
     memset(&cx, 0, sizeof(cx));
     cx.iv_off = rd.iv_off; cx.iv = rd.iv; cx.min_swatscor = rd.min_score; cx.prev_max = rd.prev_max; cx.fine_index = rd.kind == ROUND_FINE;
-    const int rv = smaltgpu_map_batch_ctx(m, bases.data(), with_quals() ? quals.data() : nullptr, off.data(), rd.n, &par, &cx, o);
+    int rv;
+    if (resident) rv = smaltgpu_map_batch_ctx_resident(m, resident, rd.ids, rd.n, &par, &cx, o);
+    else {
+      gather(rd.ids, rd.n);
+      rv = smaltgpu_map_batch_ctx(m, bases.data(), with_quals() ? quals.data() : nullptr, off.data(), rd.n, &par, &cx, o);
+    }
     // a read that failed on its own carries its code in stat[].errcode; the runner names it
     if (rv && !((rv == SMALTGPU_ECAP || rv == SMALTGPU_EINTERNAL) && o->nreads == rd.n)) return fail_with(err, rv);
+    tally(rd.kind);
     ms[rd.kind] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return true;
   }
@@ -70,10 +89,10 @@ struct DeviceExec {
 extern "C" smaltgpu_pairs *smaltgpu_pairs_create(void) { return new smaltgpu_pairs(); }
 extern "C" void smaltgpu_pairs_free(smaltgpu_pairs *p) { delete p; }
 
-extern "C" int smaltgpu_map_pairs(smaltgpu_mapper *m, const uint8_t *bases1, const uint8_t *quals1, const uint64_t *read_off1, const uint8_t *bases2,
-                                  const uint8_t *quals2, const uint64_t *read_off2, uint32_t npairs, const smaltgpu_params *par, const smaltgpu_pair_opts *po,
-                                  smaltgpu_pairs *out) {
-  if (!m || !bases1 || !bases2 || !read_off1 || !read_off2 || !par || !po || !out) return smaltgpu_set_error(SMALTGPU_EARG, "smaltgpu_map_pairs: null argument");
+static int map_pairs(smaltgpu_mapper *m, const smaltgpu_resident_reads *resident, const uint8_t *bases1, const uint8_t *quals1, const uint64_t *read_off1,
+                     const uint8_t *bases2, const uint8_t *quals2, const uint64_t *read_off2, uint32_t npairs, const smaltgpu_params *par,
+                     const smaltgpu_pair_opts *po, smaltgpu_pairs *out) {
+  if (!m || !read_off1 || !read_off2 || !par || !po || !out || (!resident && (!bases1 || !bases2))) return smaltgpu_set_error(SMALTGPU_EARG, "smaltgpu_map_pairs: null argument");
   if (po->insert_min > po->insert_max) return smaltgpu_set_error(SMALTGPU_EARG, "smaltgpu_map_pairs: insert_min above insert_max");
   if (po->library < SMALTGPU_LIB_PE || po->library > SMALTGPU_LIB_ANY) return smaltgpu_set_error(SMALTGPU_EARG, "smaltgpu_map_pairs: unknown library type");
   const smaltgpu_index *ix = smaltgpu_mapper_index(m);
@@ -89,12 +108,16 @@ extern "C" int smaltgpu_map_pairs(smaltgpu_mapper *m, const uint8_t *bases1, con
   // alignments can cross sequence junctions only in concatenated mode: the pieces are scored against a host copy of the reference
   bp.packed_host = (par->rmapflg & SMALTGPU_FLG_SEQBYSEQ) ? nullptr : smaltgpu_index_packed_host(ix);
   if (!(par->rmapflg & SMALTGPU_FLG_SEQBYSEQ) && !bp.packed_host) return SMALTGPU_ENODEV;
+  if (bp.packed_host && (!bases1 || !bases2)) return smaltgpu_set_error(SMALTGPU_EARG, "smaltgpu_map_pairs: concatenated mode needs the read bases in host memory too (pieces of alignments across sequences are scored on the host)");
   bp.nthreads = po->nthreads < 1 ? 1 : po->nthreads;
   DeviceExec ex{m, in, bp.map, 0, 0};
+  ex.resident = resident;
+  memset(ex.kernel_ms, 0, sizeof(ex.kernel_ms)); memset(ex.work, 0, sizeof(ex.work));
   uint32_t maxlen = 0;
   if (smaltgpu_mapper_capacity(m, &ex.cap_reads, &maxlen, &ex.cap_bases)) return SMALTGPU_EARG;
   const bool ok = out->blk.run(ex, in, bp);
   for (int r = 0; r < 4; r++) { out->round_ms[r] = ex.ms[r]; out->calls[r] = out->blk.nrounds.size() == 4 ? out->blk.nrounds[(size_t)r] : 0; }
+  memcpy(out->kernel_ms, ex.kernel_ms, sizeof(ex.kernel_ms)); memcpy(out->work, ex.work, sizeof(ex.work));
   if (!ok) return smaltgpu_set_error(ex.rc != SMALTGPU_OK ? ex.rc : SMALTGPU_EINTERNAL, ("smaltgpu_map_pairs: " + out->blk.error).c_str());
   // the summary: flags, rounds, surviving alignments
   out->info.assign(npairs ? npairs : 1, smaltgpu_pair_info());
@@ -112,6 +135,26 @@ extern "C" int smaltgpu_map_pairs(smaltgpu_mapper *m, const uint8_t *bases1, con
       }
     }
   });
+  return SMALTGPU_OK;
+}
+
+extern "C" int smaltgpu_map_pairs(smaltgpu_mapper *m, const uint8_t *bases1, const uint8_t *quals1, const uint64_t *read_off1, const uint8_t *bases2,
+                                  const uint8_t *quals2, const uint64_t *read_off2, uint32_t npairs, const smaltgpu_params *par, const smaltgpu_pair_opts *po,
+                                  smaltgpu_pairs *out) {
+  return map_pairs(m, nullptr, bases1, quals1, read_off1, bases2, quals2, read_off2, npairs, par, po, out);
+}
+
+extern "C" int smaltgpu_map_pairs_resident(smaltgpu_mapper *m, const smaltgpu_resident_reads *src, const uint8_t *bases1, const uint8_t *quals1, const uint8_t *bases2,
+                                           const uint8_t *quals2, uint32_t npairs, const smaltgpu_params *par, const smaltgpu_pair_opts *po, smaltgpu_pairs *out) {
+  if (!src || !src->read_off[0] || !src->read_off[1] || src->nreads[0] < npairs || src->nreads[1] < npairs)
+    return smaltgpu_set_error(SMALTGPU_EARG, "smaltgpu_map_pairs_resident: the resident batches do not hold the block");
+  return map_pairs(m, src, bases1, quals1, src->read_off[0], bases2, quals2, src->read_off[1], npairs, par, po, out);
+}
+
+extern "C" int smaltgpu_pairs_timers(const smaltgpu_pairs *p, double *kernel_ms, uint64_t *work) {
+  if (!p) return smaltgpu_set_error(SMALTGPU_EARG, "smaltgpu_pairs_timers: null argument");
+  if (kernel_ms) memcpy(kernel_ms, p->kernel_ms, sizeof(p->kernel_ms));
+  if (work) memcpy(work, p->work, sizeof(p->work));
   return SMALTGPU_OK;
 }
 

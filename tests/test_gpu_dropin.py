@@ -168,3 +168,21 @@ def test_smalt_map_pairs_prints_the_same(k, s, nchr, chrlen, rlen, ins, opts, tm
         assert len(a) == len(b)
         diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
         assert not diff, (extra, len(diff), diff[:3])
+    # the same command line through smaltgpu-map, the program made of the library alone: the rounds, the decisions between them,
+    # pairing and the paired report are the library's own; blocks of 250 pairs
+    prog = os.path.join(ROOT, "smalt_amd", "smaltgpu-map")
+    r = subprocess.run([prog] + [o for o in opts if o != "-O"] + ["-B", "250", "-o", out_gpu, pre] + fqs, capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    b = [ln for ln in open(out_gpu).read().split("\n") if not ln.startswith("@PG")]
+    assert len(a) == len(b)
+    diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
+    assert not diff, ("smaltgpu-map", len(diff), diff[:3])
+    # negative control: with the mates of another pair the output must differ (the comparison above is not vacuous)
+    rot = os.path.join(tmp, "rot_2.fq")
+    recs = open(fqs[1]).read().split("\n")
+    with open(rot, "w") as f:
+        f.write("\n".join(recs[4:4 * 700] + recs[:4]) + "\n")
+    r = subprocess.run([prog] + [o for o in opts if o != "-O"] + ["-o", out_gpu, pre, fqs[0], rot], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    b = [ln for ln in open(out_gpu).read().split("\n") if not ln.startswith("@PG")]
+    assert sum(1 for x, y in zip(a, b) if x != y) > 100
