@@ -265,13 +265,18 @@ def paired_main(args):
     sub = min(args.sub_batch, npairs)
     os.environ.setdefault("SMALTGPU_CANDS_PER_READ", "768")
     import threading
-    nstream = max(1, args.streams if args.streams > 1 else int(os.environ.get("SMALT_BENCH_PAIR_STREAMS", "2")))
-    mappers = [api.Mapper(gix, sub, rlen, slot_budget_gb=64 // nstream) for _ in range(nstream)]
+    # the timed region runs on ONE mapper (HIP stream) so that the event duration of a kernel is that of a kernel that has the
+    # device to itself (the roofline figure); a second mapper serves the extra two-stream measurement behind it
+    nstream = max(1, args.streams)
+    nmappers = max(nstream, 2)
+    mappers = [api.Mapper(gix, sub, rlen, slot_budget_gb=64 // nmappers) for _ in range(nmappers)]
     offs = torch.arange(sub + 1, dtype=torch.int64, device=dev) * rlen
     h_offs = np.arange(sub + 1, dtype=np.uint64) * np.uint64(rlen)
     po = api.PairOpts(0, 500, api.LIB_PE, 0, max(1, cores // nstream))
     L = api.lib()
-    handles = [C.c_void_p(L.smaltgpu_pairs_create()) for _ in range(nstream)]
+    handles = [C.c_void_p(L.smaltgpu_pairs_create()) for _ in range(nmappers)]
+    L.smaltgpu_pairs_host_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+    host_ms = np.zeros(7)
     nblk = (npairs + sub - 1) // sub
     kms = np.zeros((5, 16))
     work = np.zeros((5, 32), dtype=np.uint64)
@@ -279,7 +284,7 @@ def paired_main(args):
     round_ms = np.zeros(4)
     lock = threading.Lock()
 
-    def one_step(collect):
+    def one_step(collect, nstream=nstream):
         """the blocks of the job, taken in turn by `nstream` host threads with a mapper (HIP stream) each: the host work between
         the rounds of one block runs while the device works on the other block"""
         tot = {"both": 0, "any": 0, "next": 0, "err": None}
@@ -322,6 +327,9 @@ def paired_main(args):
                         work[:] += np.array(wk, dtype=np.uint64).reshape(5, 32)
                         calls[:] += np.array(cl, dtype=np.uint64)
                         round_ms[:] += np.array(rm)
+                        hm = (C.c_double * 7)()
+                        L.smaltgpu_pairs_host_times(handle, hm, 7)
+                        host_ms[:] += np.array(hm)
         th = [threading.Thread(target=drive, args=(i,)) for i in range(nstream)]
         for t in th:
             t.start()
@@ -371,7 +379,19 @@ def paired_main(args):
         "kernel_ms_per_step": {tn[i]: float(kms[:, i].sum()) / args.steps for i in range(7)},
         "gpu_busy_fraction": gpu_ms / (dt * 1e3 / args.steps),
         "round_wall_ms_per_step": {rname[r]: float(round_ms[r]) / args.steps for r in range(4)},
+        "host_ms_per_step": dict(zip(["behind A: post-call pass + search intervals", "behind B: post-call pass", "proper-pair probe", "behind C: post-call pass", "plan of D",
+                                      "behind D: post-call pass", "hit totals (wall, incl. the device)"], [float(x) / args.steps for x in host_ms])),
     }
+    # the same job on two mappers (HIP streams) taking the blocks in turn: the host work between the rounds of one block runs
+    # while the device works on the other block.  Not `value`: kernels of two blocks share the device, so their event durations
+    # are no longer those of a kernel on its own.
+    if nstream == 1:
+        one_step(False, 2)
+        torch.cuda.synchronize()
+        t2 = time.time()
+        b2, _ = one_step(False, 2)
+        torch.cuda.synchronize()
+        line["two_streams"] = {"pairs_per_s": b2 / (time.time() - t2), "note": "blocks dealt to two mappers; one extra step, not `value`"}
     if not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline_pairs(args, gix, reads.cpu().numpy().reshape(npairs, rlen), mates.cpu().numpy().reshape(npairs, rlen), rlen, (cores, host_cores))

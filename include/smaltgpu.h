@@ -234,6 +234,9 @@ int smaltgpu_pairs_info(const smaltgpu_pairs *p, uint32_t *npairs, const smaltgp
 /* device time per kernel (ms[5][16]: rounds 0-3 and the hit totals, kernels in the order of smaltgpu_timer_name) and the mapper's
  * work counters (work[5][32]) summed over the block's batches; either may be NULL.  For bench.py's roofline object. */
 int smaltgpu_pairs_timers(const smaltgpu_pairs *p, double *kernel_ms, uint64_t *work);
+/* host wall time [ms] of the work between the rounds of the block: passes behind round A (with the search intervals), behind B, the
+ * proper-pair probe, behind C, the plan of round D, behind D, and the hit-totals batches; returns the number of entries (7) */
+int smaltgpu_pairs_host_times(const smaltgpu_pairs *p, double *ms, int n);
 /* the index a mapper was created on, and the batch it was sized for (smaltgpu_map_pairs takes blocks of up to max_batch_reads pairs) */
 const smaltgpu_index *smaltgpu_mapper_index(const smaltgpu_mapper *m);
 int smaltgpu_mapper_capacity(const smaltgpu_mapper *m, uint32_t *max_batch_reads, uint32_t *max_read_len, uint64_t *max_bases);

@@ -60,6 +60,7 @@ static struct CombQueue {
   unsigned long batches[COMB_MAXDEV];                                /* combined batches run per device (diagnostic, SMALTGPU_COMBINE_STATS) */
 } g_q;
 static pthread_mutex_t g_init = PTHREAD_MUTEX_INITIALIZER;
+static int g_closing = 0;                                            /* a worker failed: no new batch is launched (gpuCombineClose) */
 
 static int grow(void **p, size_t *cap, size_t need, size_t elem)
 {
@@ -188,6 +189,27 @@ static void run_batch(struct CombSlot *d, const smaltgpu_index *ix, CombReq **re
   }
 }
 
+/* A worker hit an error it is going to end the program with (the reference's ERRMSGNO exits): stop launching, let the batches
+ * in flight finish, so that no kernel is running and no copy is under way when the process is torn down. */
+void gpuCombineClose(void)
+{
+  struct CombQueue *d = &g_q;
+  int busy;
+  pthread_mutex_lock(&g_init);
+  if (!d->init) { g_closing = 1; pthread_mutex_unlock(&g_init); return; }
+  pthread_mutex_unlock(&g_init);
+  pthread_mutex_lock(&d->mu);
+  g_closing = 1;
+  pthread_cond_broadcast(&d->cv);
+  do {
+    int u, v;
+    busy = d->assembling;
+    for (v = 0; v < d->ndev; v++) for (u = 0; u < COMB_NSLOT; u++) busy |= d->slot[v][u].busy;
+    if (busy) pthread_cond_wait(&d->cv, &d->mu);
+  } while (busy);
+  pthread_mutex_unlock(&d->mu);
+}
+
 int gpuCombineSubmit(int ndev, const smaltgpu_index *const *ixs, const char *bases, const char *quals, const uint64_t *off, uint32_t n,
                      const smaltgpu_params *par, GpuCombOut *out, char *errbuf, size_t errcap)
 {
@@ -212,13 +234,27 @@ int gpuCombineSubmitCtx(int ndev, const smaltgpu_index *const *ixs, const char *
   pthread_mutex_unlock(&g_init);
   req.bases = bases; req.quals = quals; req.off = off; req.n = n; req.par = par; req.out = out; req.ctx = ctx; req.done = 0; req.rv = 0; req.err[0] = 0;
   pthread_mutex_lock(&d->mu);
-  while (d->npending >= COMB_MAXREQ) pthread_cond_wait(&d->cv, &d->mu);
+  while (d->npending >= COMB_MAXREQ && !g_closing) pthread_cond_wait(&d->cv, &d->mu);
+  if (g_closing) { pthread_mutex_unlock(&d->mu); if (errbuf && errcap) snprintf(errbuf, errcap, "shutting down after an error in another worker"); return GPUCOMB_CLOSING; }
   d->pending[d->npending++] = &req;
   pthread_cond_broadcast(&d->cv);
   while (!req.done) {
     int sl = -1, dv = -1, u, v;
+    if (g_closing) {                                       /* not taken by a leader yet: withdraw */
+      int i, keep = 0, mine = 0;
+      for (i = 0; i < d->npending; i++) { if (d->pending[i] == &req) mine = 1; else d->pending[keep++] = d->pending[i]; }
+      if (mine) {
+        d->npending = keep;
+        pthread_cond_broadcast(&d->cv);
+        pthread_mutex_unlock(&d->mu);
+        if (errbuf && errcap) snprintf(errbuf, errcap, "shutting down after an error in another worker");
+        return GPUCOMB_CLOSING;
+      }
+      pthread_cond_wait(&d->cv, &d->mu);                   /* a leader holds the request: its batch is finishing */
+      continue;
+    }
     /* (a waiting thread may lead a batch of others)  first slot of every device before the second slot of any */
-    if (!d->assembling && d->npending > 0)
+    if (!d->assembling && d->npending > 0 && !g_closing)
       for (u = 0; u < g_nslot && sl < 0; u++) for (v = 0; v < d->ndev; v++) if (!d->slot[v][u].busy) { sl = u; dv = v; break; }
     if (sl >= 0) {
       CombReq *take[COMB_MAXREQ];
@@ -235,12 +271,17 @@ int gpuCombineSubmitCtx(int ndev, const smaltgpu_index *const *ixs, const char *
         if (d->npending == before) break;
       }
       const uint32_t maxreads = g_cfg.combine_reads;
-      {                                                    /* the oldest request decides the kind of batch; other kinds keep their place in the queue */
-        const int kind = d->pending[0]->ctx ? d->pending[0]->ctx->kind : GPUCOMB_PLAIN;
+      {                                                    /* the oldest request decides what the batch is made of: requests of its round kind, with the
+                                                            * same parameters and the same presence of base qualities (a batch has ONE parameter set, and
+                                                            * qualities for all reads or for none); the others keep their place in the queue */
+        const CombReq *first = d->pending[0];
+        const int kind = first->ctx ? first->ctx->kind : GPUCOMB_PLAIN;
         int keep = 0;
         for (i = 0; i < d->npending; i++) {
-          const int ki = d->pending[i]->ctx ? d->pending[i]->ctx->kind : GPUCOMB_PLAIN;
-          if (ki == kind && !(ntake && reads + d->pending[i]->n > maxreads) && ntake < COMB_MAXREQ) { reads += d->pending[i]->n; take[ntake++] = d->pending[i]; }
+          const CombReq *q = d->pending[i];
+          const int ki = q->ctx ? q->ctx->kind : GPUCOMB_PLAIN;
+          const int alike = ki == kind && (q->quals != NULL) == (first->quals != NULL) && !memcmp(q->par, first->par, sizeof(*q->par));
+          if (alike && !(ntake && reads + q->n > maxreads) && ntake < COMB_MAXREQ) { reads += q->n; take[ntake++] = d->pending[i]; }
           else d->pending[keep++] = d->pending[i];
         }
         d->npending = keep;

@@ -24,10 +24,15 @@ typedef struct {
 } GpuCombCtx;
 
 /* map the n reads of the caller (bases/quals concatenated, off[n+1]) as part of a combined batch on whichever of the ndev
- * devices (index images ixs[0..ndev)) has a free mapper; blocks until `out` holds the caller's slice.  All concurrent callers must pass the same parameters.  On failure errbuf (may be
+ * devices (index images ixs[0..ndev)) has a free mapper; blocks until `out` holds the caller's slice.  Requests that differ in their parameters or in
+ * whether they carry base qualities are never put into the same batch.  On failure errbuf (may be
  * NULL) receives the library's message (smaltgpu_last_error() is per thread and the batch may have run on another one). */
 int gpuCombineSubmit(int ndev, const smaltgpu_index *const *ixs, const char *bases, const char *quals, const uint64_t *off, uint32_t n,
                      const smaltgpu_params *par, GpuCombOut *out, char *errbuf, size_t errcap);
 int gpuCombineSubmitCtx(int ndev, const smaltgpu_index *const *ixs, const char *bases, const char *quals, const uint64_t *off, uint32_t n,
                         const smaltgpu_params *par, const GpuCombCtx *ctx, GpuCombOut *out, char *errbuf, size_t errcap);
+/* after an error a worker is going to end the program with: no further batch is launched, the call returns when the batches in
+ * flight are done.  Requests that arrive or still wait afterwards return GPUCOMB_CLOSING. */
+enum { GPUCOMB_CLOSING = -100 };
+void gpuCombineClose(void);
 #endif

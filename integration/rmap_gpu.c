@@ -82,6 +82,18 @@ static void gpuReadConfig(void)
   if (g_nphys < 1) g_ndev = 0;
 }
 
+/* A GPU-side failure ends the program the way the reference ends on any mapping error (ERRMSGNO -> exit, elib.c:335-353).
+ * Before that: no further batch is launched and the batches in flight finish (gpuCombineClose), so that the process is not
+ * torn down under running launches.  A worker that is turned away meanwhile (GPUCOMB_CLOSING) waits for the end instead of
+ * exiting a second time. */
+#include <unistd.h>
+static void gpuFailOrderly(const char *what)
+{
+  if (what && *what) fprintf(stderr, "smaltgpu: %s\n", what);
+  gpuCombineClose();
+}
+static void gpuParkIfClosing(int rv) { if (rv == GPUCOMB_CLOSING) for (;;) pause(); }
+
 static int gpuMapperFor(const RMap *rmp, uint32_t rlen);
 static int gpuMapperForBatch(const RMap *rmp, uint32_t rlen, uint32_t nreads, size_t nbases, int need_mapper);
 
@@ -234,9 +246,11 @@ int rmapGpuBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, int n, int 
   t1 = tmNow(); g_tm[slot][TM_STAGE] += t1 - t0; t0 = t1;
   if (combine) {
     char emsg[256] = "";
-    if (gpuCombineSubmit(g_ndev, (const smaltgpu_index *const *)g_ixdev, g_map[slot].bases, has_qual ? g_map[slot].quals : NULL, g_map[slot].off,
-                         (uint32_t)n, &par, &g_map[slot].comb, emsg, sizeof(emsg))) {
-      fprintf(stderr, "smaltgpu: %s\n", emsg);
+    const int crv = gpuCombineSubmit(g_ndev, (const smaltgpu_index *const *)g_ixdev, g_map[slot].bases, has_qual ? g_map[slot].quals : NULL, g_map[slot].off,
+                                     (uint32_t)n, &par, &g_map[slot].comb, emsg, sizeof(emsg));
+    if (crv) {
+      gpuParkIfClosing(crv);
+      gpuFailOrderly(emsg);
       ERRMSGNO(errmsgp, ERRCODE_FAILURE);
     }
     g_map[slot].out.nreads = (uint32_t)n; g_map[slot].out.res_off = g_map[slot].comb.res_off; g_map[slot].out.res = g_map[slot].comb.res;
@@ -288,7 +302,7 @@ int rmapGpuFinish(ErrMsg *errmsgp, RMap *rmp, int i, SeqFastq *readp, short max_
   if ((errcode = makeRMAPPROFfromRead(rmp->prp, readp, scormtxp, codecp))) ERRMSGNO(errmsgp, errcode);
   (void)seqFastqGetConstSequence(readp, &rlen, NULL);
   if (rlen < hashTableGetKtupLen(htp, NULL)) return ERRCODE_SUCCESS;                      /* ERRCODE_SHORTSEQ is swallowed (rmap.c:1736) */
-  if (o->stat[i].errcode) ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+  if (o->stat[i].errcode) { gpuFailOrderly("a read failed on the device"); ERRMSGNO(errmsgp, ERRCODE_FAILURE); }
   double t0 = tmNow(), t1;
   if ((errcode = resultSetInjectRaw(rmp->rsrp, (unsigned)(o->res_off[i + 1] - o->res_off[i]), o->res + o->res_off[i], o->diffstr,
                                     o->stat[i].swatscor_max, o->stat[i].swatscor_2ndmax)))
@@ -378,9 +392,11 @@ static int gpuPairRound(ErrMsg *errmsgp, int slot, SeqFastq *const *sq, int ns, 
     char emsg[256] = "";
     memset(&cc, 0, sizeof(cc));
     cc.kind = kind; cc.iv_off = iv_off; cc.iv = iv; cc.minsw = minsw; cc.prevmax = prevmax; cc.tot_out = tot_out;
-    if (gpuCombineSubmitCtx(g_ndev, (const smaltgpu_index *const *)g_ixdev, g_map[slot].bases, has_qual ? g_map[slot].quals : NULL, g_map[slot].off,
-                            (uint32_t)ns, par, kind == GPUCOMB_PLAIN ? NULL : &cc, &g_map[slot].comb, emsg, sizeof(emsg))) {
-      fprintf(stderr, "smaltgpu: %s\n", emsg);
+    const int crv = gpuCombineSubmitCtx(g_ndev, (const smaltgpu_index *const *)g_ixdev, g_map[slot].bases, has_qual ? g_map[slot].quals : NULL, g_map[slot].off,
+                                        (uint32_t)ns, par, kind == GPUCOMB_PLAIN ? NULL : &cc, &g_map[slot].comb, emsg, sizeof(emsg));
+    if (crv) {
+      gpuParkIfClosing(crv);
+      gpuFailOrderly(emsg);
       ERRMSGNO(errmsgp, ERRCODE_FAILURE);
     }
     if (out) { out->nreads = (uint32_t)ns; out->res_off = g_map[slot].comb.res_off; out->res = g_map[slot].comb.res; out->diffstr = g_map[slot].comb.dstr; out->stat = g_map[slot].comb.stat; }
@@ -407,7 +423,7 @@ static int gpuPairTake(ErrMsg *errmsgp, RMap *rmp, GpuPair *pp, int w, const sma
 {
   int errcode;
   ResultSet *rs = pp->rs[w];
-  if (o->stat[i].errcode) { fprintf(stderr, "smaltgpu: read failed on the device (code %d)\n", o->stat[i].errcode); ERRMSGNO(errmsgp, ERRCODE_FAILURE); }
+  if (o->stat[i].errcode) { char m[96]; snprintf(m, sizeof(m), "read failed on the device (code %d)", o->stat[i].errcode); gpuFailOrderly(m); ERRMSGNO(errmsgp, ERRCODE_FAILURE); }
   resultSetAlignmentStats(rs, o->stat[i].n_ali_done, o->stat[i].n_ali_tot, max_depth, o->stat[i].n_hits_used, o->stat[i].n_hits_tot);
   if ((errcode = resultSetAppendRaw(rs, (unsigned)(o->res_off[i + 1] - o->res_off[i]), o->res + o->res_off[i], o->diffstr,
                                     o->stat[i].swatscor_max, o->stat[i].swatscor_2ndmax)))

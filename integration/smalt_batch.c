@@ -57,9 +57,10 @@ static int processArgBlockGpu(ErrMsg *errmsgp,
       SmaltIOBuffArg *brgp = blockp->iobfp + i;
       ERRMSG_READNO(errmsgp, brgp->readno + 1);
       ERRMSG_READNAM(errmsgp, seqFastqGetSeqName(brgp->readp));
-      if (!brgp->isPaired) ERRMSGNO(errmsgp, ERRCODE_ASSERT);
-      if ((errcode = seqFastqEncode(brgp->readp, macop->codecp))) ERRMSGNO(errmsgp, errcode);
-      if ((errcode = seqFastqEncode(brgp->matep, macop->codecp))) ERRMSGNO(errmsgp, errcode);
+      if (!brgp->isPaired) errcode = ERRCODE_ASSERT;
+      if (!errcode) errcode = seqFastqEncode(brgp->readp, macop->codecp);
+      if (!errcode) errcode = seqFastqEncode(brgp->matep, macop->codecp);
+      if ((errcode)) { free(reads); ERRMSGNO(errmsgp, errcode); }
       reads[i] = brgp->readp; mates[i] = brgp->matep;
     }
     if (!errcode)
@@ -73,15 +74,17 @@ static int processArgBlockGpu(ErrMsg *errmsgp,
       const ResultPairs *pairp;
       ERRMSG_READNO(errmsgp, brgp->readno + 1);
       ERRMSG_READNAM(errmsgp, seqFastqGetSeqName(brgp->readp));
-      if ((errcode = rmapGpuPairFinish(errmsgp, map->rmp, i, &brgp->pairflg, macop->insert_min, macop->insert_max, macop->pairtyp, macop->rfp)))
-        break;
-      rmapGetData(&rsltp, &rslt_matep, &pairp, NULL, NULL, map->rmp);
-      errcode = resultSetAddPairToReport(brgp->rep, macop->ihp, pairp, brgp->pairflg, macop->rsltouflg, rsltp, rslt_matep);
-      if ((errcode)) ERRMSGNO(errmsgp, errcode);
-      if (MENU_SAMPLE == macop->subprogtyp &&
-          ERRCODE_SUCCESS == resultSetInferInsertSize(&brgp->isiz, RSLTSAMSPEC_V1P4, rsltp, rslt_matep))
-        brgp->pairflg |= RSLTPAIRFLG_INSERTSIZ;
+      /* the pair's sets are the RMap's from a Finish attempt until the Release, whatever happens in between */
+      errcode = rmapGpuPairFinish(errmsgp, map->rmp, i, &brgp->pairflg, macop->insert_min, macop->insert_max, macop->pairtyp, macop->rfp);
+      if (!errcode) {
+        rmapGetData(&rsltp, &rslt_matep, &pairp, NULL, NULL, map->rmp);
+        errcode = resultSetAddPairToReport(brgp->rep, macop->ihp, pairp, brgp->pairflg, macop->rsltouflg, rsltp, rslt_matep);
+        if (!errcode && MENU_SAMPLE == macop->subprogtyp &&
+            ERRCODE_SUCCESS == resultSetInferInsertSize(&brgp->isiz, RSLTSAMSPEC_V1P4, rsltp, rslt_matep))
+          brgp->pairflg |= RSLTPAIRFLG_INSERTSIZ;
+      }
       rmapGpuPairRelease(map->rmp);
+      if ((errcode)) { free(reads); ERRMSGNO(errmsgp, errcode); }
     }
     free(reads);
 #ifdef THREADS_DEBUG

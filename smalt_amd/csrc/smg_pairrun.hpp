@@ -8,6 +8,7 @@
 #ifndef SMG_PAIRRUN_HPP
 #define SMG_PAIRRUN_HPP
 #include <stdio.h>
+#include <chrono>
 #include <string>
 #include <thread>
 #include "../../include/smaltgpu.h"
@@ -44,6 +45,12 @@ struct PairBlock {
   std::vector<uint32_t> nrounds;              // mapping calls per round kind, for the caller's statistics
   std::string error;
   uint32_t npairs = 0;
+  // host wall time of the work between the rounds [ms]: passes after round A (with the intervals), B, C, D; the proper-pair
+  // probe; the decisions behind round C
+  enum { H_AFTER_A, H_AFTER_B, H_PROBE, H_AFTER_C, H_PLAN_D, H_AFTER_D, H_NUM };
+  double host_ms[H_NUM] = {0, 0, 0, 0, 0, 0};
+  struct Clock { std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+                 double lap() { const auto n = std::chrono::steady_clock::now(); const double d = std::chrono::duration<double, std::milli>(n - t).count(); t = n; return d; } };
 
   template <class Fn> static void spread(uint32_t n, int nthreads, Fn fn) {      // fn(lo, hi, thread)
     if (nthreads < 1) nthreads = 1;
@@ -99,6 +106,8 @@ struct PairBlock {
     packed.assign((size_t)2 * n, std::vector<uint8_t>());
     plan.assign(n, PairPlan());
     nrounds.assign(4, 0);
+    for (double &h : host_ms) h = 0;
+    Clock ck;
     if (!n) return true;
     const int nt = bp.nthreads < 1 ? 1 : bp.nthreads;
     std::vector<uint32_t> ids((size_t)2 * n), hits((size_t)2 * n, 0);
@@ -131,6 +140,7 @@ struct PairBlock {
     if (na) {
       Round rd{ROUND_PLAIN, ids.data(), na, nullptr, nullptr, nullptr, nullptr};
       if (!exec.map(rd, &o, error)) return false;
+      ck.lap();
       nrounds[ROUND_PLAIN] += na;
       iv_count.assign(na, 0);
       for (auto &part : iv_part) part.clear();
@@ -145,11 +155,14 @@ struct PairBlock {
           })) return false;
       // ---- round B: the second mate inside the intervals of the first ----
       stitch(na);
+      host_ms[H_AFTER_A] += ck.lap();
       for (uint32_t i = 0; i < na; i++) ids_b[i] = ids[i] ^ 1u;
       Round rb{ROUND_RESTRICTED, ids_b.data(), na, iv_off.data(), iv.data(), nullptr, nullptr};
       if (!exec.map(rb, &o, error)) return false;
+      ck.lap();
       nrounds[ROUND_RESTRICTED] += na;
       if (!take(rb, o, in, bp, [&](uint32_t, uint32_t, Table &, int) { return true; })) return false;
+      host_ms[H_AFTER_B] += ck.lap();
       // ---- proper pairs so far; who needs the unrestricted round ----
       std::vector<int> broken((size_t)nt, 0);
       spread(na, nt, [&](uint32_t lo, uint32_t hi, int t) {
@@ -164,6 +177,7 @@ struct PairBlock {
         }
       });
       for (int b : broken) if (b) { error = "a pair's alignment sets are not in order for pairing, or the insert range is empty"; return false; }
+      host_ms[H_PROBE] += ck.lap();
     }
 
     // ---- round C: the second mate without restriction; lone mates join here ----
@@ -181,8 +195,10 @@ struct PairBlock {
       });
       Round rc{ROUND_APPEND, ids.data(), nc, nullptr, nullptr, nullptr, prev_max.data()};
       if (!exec.map(rc, &o, error)) return false;
+      ck.lap();
       nrounds[ROUND_APPEND] += nc;
       if (!take(rc, o, in, bp, [&](uint32_t, uint32_t, Table &, int) { return true; })) return false;
+      host_ms[H_AFTER_C] += ck.lap();
       // ---- who maps the first mate again, inside the intervals of the second one's results ----
       iv_count.assign(nc, 0);
       for (auto &part : iv_part) part.clear();
@@ -224,10 +240,13 @@ struct PairBlock {
       if (nd) {
         iv_count = cnt_d;
         stitch(nd);
+        host_ms[H_PLAN_D] += ck.lap();
         Round rdd{ROUND_FINE, ids_d.data(), nd, iv_off.data(), iv.data(), ms_d.data(), pm_d.data()};
         if (!exec.map(rdd, &o, error)) return false;
+        ck.lap();
         nrounds[ROUND_FINE] += nd;
         if (!take(rdd, o, in, bp, [&](uint32_t, uint32_t, Table &, int) { return true; })) return false;
+        host_ms[H_AFTER_D] += ck.lap();
       }
     }
     return true;
@@ -242,6 +261,7 @@ struct smaltgpu_pairs {
   std::vector<smaltgpu_pair_info> info;
   uint64_t calls[4] = {0, 0, 0, 0};
   double round_ms[4] = {0, 0, 0, 0};
+  double totals_ms = 0;                       // host wall time of the hit-totals batches
   double kernel_ms[5][16];                    // per round (4 = hit totals) and kernel: device time of the block
   uint64_t work[5][32];
 };

@@ -46,7 +46,14 @@ struct DeviceExec {
     }
   }
   bool fail_with(std::string &err, int code) { rc = code; err = smaltgpu_last_error(); if (err.empty()) err = "the device call failed without a message"; return false; }
+  double totals_wall = 0;
   bool totals(const uint32_t *ids, uint32_t n, uint32_t *hits, std::string &err) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool ok = totals_inner(ids, n, hits, err);
+    totals_wall += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return ok;
+  }
+  bool totals_inner(const uint32_t *ids, uint32_t n, uint32_t *hits, std::string &err) {
     for (uint32_t lo = 0; lo < n;) {                   // in pieces the mapper can take
       uint32_t hi = lo;
       uint64_t nb = 0;
@@ -118,6 +125,7 @@ static int map_pairs(smaltgpu_mapper *m, const smaltgpu_resident_reads *resident
   const bool ok = out->blk.run(ex, in, bp);
   for (int r = 0; r < 4; r++) { out->round_ms[r] = ex.ms[r]; out->calls[r] = out->blk.nrounds.size() == 4 ? out->blk.nrounds[(size_t)r] : 0; }
   memcpy(out->kernel_ms, ex.kernel_ms, sizeof(ex.kernel_ms)); memcpy(out->work, ex.work, sizeof(ex.work));
+  out->totals_ms = ex.totals_wall;
   if (!ok) return smaltgpu_set_error(ex.rc != SMALTGPU_OK ? ex.rc : SMALTGPU_EINTERNAL, ("smaltgpu_map_pairs: " + out->blk.error).c_str());
   // the summary: flags, rounds, surviving alignments
   out->info.assign(npairs ? npairs : 1, smaltgpu_pair_info());
@@ -149,6 +157,13 @@ extern "C" int smaltgpu_map_pairs_resident(smaltgpu_mapper *m, const smaltgpu_re
   if (!src || !src->read_off[0] || !src->read_off[1] || src->nreads[0] < npairs || src->nreads[1] < npairs)
     return smaltgpu_set_error(SMALTGPU_EARG, "smaltgpu_map_pairs_resident: the resident batches do not hold the block");
   return map_pairs(m, src, bases1, quals1, src->read_off[0], bases2, quals2, src->read_off[1], npairs, par, po, out);
+}
+
+extern "C" int smaltgpu_pairs_host_times(const smaltgpu_pairs *p, double *ms, int n) {
+  if (!p || !ms) return smaltgpu_set_error(SMALTGPU_EARG, "smaltgpu_pairs_host_times: null argument");
+  for (int i = 0; i < n && i < smgpairs::PairBlock::H_NUM; i++) ms[i] = p->blk.host_ms[i];
+  if (n > smgpairs::PairBlock::H_NUM) ms[smgpairs::PairBlock::H_NUM] = p->totals_ms;
+  return smgpairs::PairBlock::H_NUM + 1;
 }
 
 extern "C" int smaltgpu_pairs_timers(const smaltgpu_pairs *p, double *kernel_ms, uint64_t *work) {

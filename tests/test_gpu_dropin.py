@@ -186,3 +186,24 @@ def test_smalt_map_pairs_prints_the_same(k, s, nchr, chrlen, rlen, ins, opts, tm
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     b = [ln for ln in open(out_gpu).read().split("\n") if not ln.startswith("@PG")]
     assert sum(1 for x, y in zip(a, b) if x != y) > 100
+
+
+@pytest.mark.skipif(not (os.path.exists(SMALT) and os.path.exists(SMALT_GPU)), reason="reference binaries not built (make -C oracle ref ref_gpu)")
+def test_pairs_with_32_workers_and_blocks_of_4096(tmp_path):
+    """More waiting worker threads than mapper slots x cohort size: `smalt_gpu map -n 32` with blocks of 4096 pairs
+    (SMALTGPU_BLOCK_READS) over 140 000 pairs -- 32 workers queue their rounds (hit totals, A, B, C, D) in the shared batch
+    queue (integration/gpu_combine.c) at once.  The output must be the unmodified program's, line for line."""
+    tmp = str(tmp_path)
+    fa, fqs = _pair_data(tmp, 3, 300_000, 140_000, 100, seed=4321, rep=0.3)
+    pre = os.path.join(tmp, "idx")
+    subprocess.run([SMALT, "index", "-k", "13", "-s", "6", pre, fa], check=True, capture_output=True)
+    out_ref, out_gpu = os.path.join(tmp, "ref.out"), os.path.join(tmp, "gpu.out")
+    opts = ["-f", "cigar", "-i", "500", "-O", "-r", "-1"]
+    subprocess.run([SMALT, "map", "-n", "16"] + opts + ["-o", out_ref, pre] + fqs, check=True, capture_output=True)
+    env = dict(os.environ, SMALTGPU_INDEX_PREFIX=pre, SMALTGPU_BLOCK_READS="4096")
+    r = subprocess.run([SMALT_GPU, "map", "-n", "32"] + opts + ["-o", out_gpu, pre] + fqs, capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    a, b = open(out_ref).read().split("\n"), open(out_gpu).read().split("\n")
+    assert len(a) == len(b) and len(a) > 250_000
+    diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
+    assert not diff, (len(diff), diff[:3])

@@ -68,12 +68,24 @@ def main():
 
         windows = {}
 
+        def keep_failure(binary, nthr, r):
+            """the whole stderr of a failing program goes to a file that travels back (a sweep that only reads our stdout
+            must not lose the reason)"""
+            d = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, "bench_tool_failure_%s_n%d_%d.err" % (os.path.basename(binary), nthr, int(time.time())))
+            with open(path, "wb") as f:
+                f.write(("exit status %d; environment: %s\n" % (r.returncode, {k: v for k, v in os.environ.items() if k.startswith("SMALTGPU")})).encode())
+                f.write(r.stderr)
+            sys.stderr.write("[bench_tool] stderr of the failing run kept in %s\n" % path)
+
         def run(binary, nthr, fq, out, env=None):
             t = time.time()
             inputs = [fq, fq + ".mates"] if a.paired else [fq]
             r = subprocess.run([binary, "map", "-n", str(nthr), "-O", "-r", "-1", "-f", "cigar"] + (["-i", "500"] if a.paired else []) + ["-o", out, prefix] + inputs,
                                capture_output=True, env=env)
             if r.returncode:
+                keep_failure(binary, nthr, r)
                 raise SystemExit("%s failed: %s" % (binary, r.stderr.decode()[-1500:]))
             tm = [ln for ln in r.stderr.decode().split("\n") if "smaltgpu timing" in ln]      # the binding's per-phase seconds (integration/rmap_gpu.c)
             for ln in tm:
@@ -93,6 +105,21 @@ def main():
         t_g0 = min(run(smalt_gpu, gthreads, small, os.path.join(tmp, "g0.cig"), env) for _ in range(3))     # start-up (index load, device init) varies: best of three
         t_g1 = run(smalt_gpu, gthreads, gpu_fq, os.path.join(tmp, "g1.cig"), env)
         native = None
+        if a.paired:
+            # the same job by smaltgpu-map on the two files: libsmaltgpu only (ingest, rmapPair's rounds, pairing, report)
+            prog = os.path.join(ROOT, "smalt_amd", "smaltgpu-map")
+            subprocess.run([prog, "-r", "-1", "-i", "500", "-f", "cigar", "-n", str(a.threads), "-o", os.path.join(tmp, "n0.cig"), prefix, small, small + ".mates"], capture_output=True)
+            r = subprocess.run([prog, "-r", "-1", "-i", "500", "-f", "cigar", "-n", str(a.threads), "-o", os.path.join(tmp, "n1.cig"), prefix, gpu_fq, gpu_fq + ".mates"],
+                               capture_output=True, env=dict(os.environ, SMALTGPU_MAP_VERBOSE="1"))
+            if r.returncode:
+                keep_failure(prog, a.threads, r)
+                raise SystemExit("smaltgpu-map failed: %s" % r.stderr.decode()[-1500:])
+            ln = [x for x in r.stderr.decode().split("\n") if "lines out" in x][-1]
+            sys.stderr.write("".join(x + "\n" for x in r.stderr.decode().split("\n") if x.startswith("smaltgpu-map:")))
+            secs = float(ln.split("lines out")[1].split()[0])
+            nat = open(os.path.join(tmp, "n1.cig")).read().split("\n")
+            native = {"pairs_per_s": a.reads / secs, "window_s": secs, "index_load_s": float(ln.split("index load")[1].split()[0]), "host_threads": a.threads,
+                      "identical_to_bound_program": nat == open(os.path.join(tmp, "g1.cig")).read().split("\n")}
         if not a.paired:
             # the same job by smaltgpu-map: libsmaltgpu only (read ingest, GPU path, post-processing, report) -- no reference code
             prog = os.path.join(ROOT, "smalt_amd", "smaltgpu-map")
