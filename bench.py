@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=1, help="mappers (HIP streams) that take the sub-batches in turn: kernels of consecutive sub-batches overlap")
     ap.add_argument("--paired", action="store_true", help="BASELINE configs[2]: 1 M read PAIRS (2 x read-len, FR, fragments N(300,30), -i 500) through smaltgpu_map_pairs_resident: "
                     "rmapPair's rounds on the GPU, the decisions between them in the library; pairs/s with kernel ms per round, roofline and cpu_baseline")
+    ap.add_argument("--long", action="store_true", help="BASELINE configs[4] shape: PacBio-shape reads of 8 kbp (3 %% substitutions, 5 %% insertions, 4 %% deletions) vs the 3 Gbp "
+                    "reference, k=20 s=13; --reads of them (default 3000 of the config's 100 k: a step must finish within minutes)")
     ap.add_argument("--static-shards", action="store_true", help="N > 1: contiguous shard per rank instead of the shared sub-batch cursor")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-buffers", action="store_true", help="skip the extra PCIe-inclusive measurement of smaltgpu_map_batch on pageable host buffers")
@@ -352,14 +354,15 @@ def paired_main(args):
         any_ += a_
     torch.cuda.synchronize()
     dt = time.time() - t1
-    tn = [L.smaltgpu_timer_name(i).decode() for i in range(7)]
+    ntim = L.smaltgpu_timers(mappers[0].h, None, None, 0)
+    tn = [L.smaltgpu_timer_name(i).decode() for i in range(ntim)]
     sw = tn.index("sw_full")
     cells = float(work[:, 2].sum())
     sw_ms = float(kms[:, sw].sum())
     tcups = cells / (sw_ms * 1e-3) / 1e12 if sw_ms > 0 else 0.0
     nlaunch = int((calls > 0).sum()) * nblk * args.steps or 1          # K2a launches: one per round and block
     rname = ["A first mate", "B second mate restricted", "C second mate again", "D first mate over the on-the-fly index", "hit totals"]
-    per_round = {rname[r]: {tn[i]: float(kms[r, i]) / args.steps for i in range(7) if kms[r, i] > 0} for r in range(5)}
+    per_round = {rname[r]: {tn[i]: float(kms[r, i]) / args.steps for i in range(ntim) if kms[r, i] > 0} for r in range(5)}
     gpu_ms = float(kms.sum()) / args.steps
     line = {
         "metric": "mapped read pairs/sec (1M pairs 2x%dbp vs 3Gbp ref)" % rlen, "value": both / dt, "unit": "read pairs/s", "n_gpus": 1,
@@ -376,7 +379,7 @@ def paired_main(args):
                          ops_per_cell_survey=OPS_PER_CELL_SURVEY, gcups=tcups * 1e3, traffic=None, avg_launch_ms=sw_ms / nlaunch, cells_per_launch=cells / nlaunch,
                          peak_note="256 CU x 4 SIMD x 32 lane-ops/clk x 2.4 GHz; same units as the single-end line; all rounds' K2a launches together; with 2 streams the kernels of two blocks share the device, so the per-launch time includes that sharing"),
         "kernel_ms_per_step_by_round": per_round,
-        "kernel_ms_per_step": {tn[i]: float(kms[:, i].sum()) / args.steps for i in range(7)},
+        "kernel_ms_per_step": {tn[i]: float(kms[:, i].sum()) / args.steps for i in range(ntim)},
         "gpu_busy_fraction": gpu_ms / (dt * 1e3 / args.steps),
         "round_wall_ms_per_step": {rname[r]: float(round_ms[r]) / args.steps for r in range(4)},
         "host_ms_per_step": dict(zip(["behind A: post-call pass + search intervals", "behind B: post-call pass", "proper-pair probe", "behind C: post-call pass", "plan of D",
@@ -405,8 +408,137 @@ def paired_main(args):
     gix.close()
 
 
+def long_main(args):
+    """BASELINE configs[4] shape.  One step = the whole path over `--reads` long reads resident in HBM, in batches of 1000 reads
+    (the scratch of a long read is large: direction matrices, hit slots).  The dominant kernel is the un-banded score pass in its
+    strip form (k_sw_strip16: reads and windows beyond the register tiling); its roofline is the same VALU issue peak as the
+    headline kernel's, cells = read length x window length per ranked candidate."""
+    import ctypes as C
+
+    import torch
+    from smalt_amd import api, gpuindex, synth
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    k, s, rlen = 20, 13, 8000
+    chrlen, nchr = int(args.chr_mbp * 1e6), args.nchr
+    sop = [i * chrlen for i in range(nchr + 1)]
+    names = ["chr%d" % (i + 1) for i in range(nchr)]
+    nreads = args.reads or 3000
+    t0 = time.time()
+    ref = gpuindex.make_reference_gpu(nchr, chrlen, 20261004, dev)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    ascii_ref = torch.cat([lut[c.long()] for c in ref.split(1 << 28)])
+    gix = api.Index.build_device(ascii_ref.data_ptr(), sop, names, k, s, 0)
+    del ascii_ref
+    rng = np.random.default_rng(4242)
+    reads = []
+    for i in range(nreads):               # sources fetched from HBM, sequencing errors applied on the host (smalt_amd/synth.py)
+        c = int(rng.integers(0, nchr))
+        p = int(rng.integers(0, chrlen - rlen - 8))
+        src = ref[c * chrlen + p: c * chrlen + p + rlen + 4].cpu().numpy()
+        r, _ = synth.make_long_reads([src], 1, rlen, seed=1000 + i, sub=0.03, ins=0.05, dele=0.04)
+        reads.append(synth.codes_to_ascii(r[0]))
+    del ref
+    torch.cuda.empty_cache()
+    maxlen = max(len(r) for r in reads)
+    batch = min(1000, nreads)
+    lens = np.array([len(r) for r in reads], dtype=np.int64)
+    off = np.zeros(nreads + 1, dtype=np.int64)
+    off[1:] = np.cumsum(lens)
+    d_bases = torch.from_numpy(np.frombuffer(b"".join(reads), dtype=np.uint8).copy()).to(dev)
+    par = gix.default_params()
+    mapper = api.Mapper(gix, batch, maxlen)
+    torch.cuda.synchronize()
+    setup_s = time.time() - t0
+    print("[bench] setup: reference, index (%.1f ms on the device) and %d reads of ~%d bases in %.1f s" % (gix.build_ms, nreads, rlen, setup_s), file=sys.stderr, flush=True)
+    ms_acc, work_acc = {}, [0] * 32
+
+    def one_step(collect):
+        mapped = 0
+        for b0 in range(0, nreads, batch):
+            n = min(batch, nreads - b0)
+            d_off = torch.from_numpy(off[b0:b0 + n + 1] - off[b0]).to(dev)
+            mapper.map_batch_device(d_bases.data_ptr() + int(off[b0]), 0, d_off.data_ptr(), n, int(off[b0 + n] - off[b0]), par)
+            try:
+                out = mapper.fetch_results()
+            except api.SmaltGpuError as e:
+                if e.code not in (-5, -6):
+                    raise
+                out = None                 # single reads over a device-side limit keep their error code; the others are complete
+            if out is not None:
+                st = np.ctypeslib.as_array(C.cast(out.stat, C.POINTER(C.c_uint32)), shape=(n, 10))
+                mapped += int((st[:, 7] > 0).sum())
+            if collect:
+                ms, wk = mapper.timers()
+                for kk, v in ms.items():
+                    ms_acc[kk] = ms_acc.get(kk, 0.0) + v
+                for i in range(32):
+                    work_acc[i] += wk[i]
+        return mapped
+    for w in range(args.warmup):
+        tw = time.time()
+        one_step(False)
+        print("[bench] warmup step %.2f s" % (time.time() - tw), file=sys.stderr, flush=True)
+    torch.cuda.synchronize()
+    t1 = time.time()
+    mapped = 0
+    for _ in range(args.steps):
+        mapped += one_step(True)
+    torch.cuda.synchronize()
+    dt = time.time() - t1
+    nlaunch = args.steps * ((nreads + batch - 1) // batch)
+    cells = float(work_acc[2])
+    sw_ms = ms_acc.get("sw_scalar", 0.0) + ms_acc.get("sw_full", 0.0)       # strips and bands run in the sw_scalar bracket
+    tcups = cells / (sw_ms * 1e-3) / 1e12 if sw_ms > 0 else 0.0
+    line = {
+        "metric": "mapped reads/sec (8 kbp PacBio-shape reads vs 3Gbp ref, k=20)", "value": mapped / dt, "unit": "mapped reads/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": "configs[4] shape: %d of the config's 100 k reads, %d-base sources with 3 %% substitutions, 5 %% insertions, 4 %% deletions vs %d x %.0f Mbp "
+                               "synthetic reference (15 %% repeats), k=%d s=%d (collision-type index built by the library), batches of %d reads" % (nreads, rlen, nchr, args.chr_mbp, k, s, batch),
+                   "reads_per_step": nreads, "mean_read_len": float(lens.mean()), "mapped_fraction": mapped / (args.steps * nreads), "bases_per_s": float(lens.sum()) * args.steps / dt,
+                   "setup_s": setup_s, "index_build_ms": gix.build_ms, "ranked_per_read": work_acc[3] / (args.steps * nreads)},
+        "roofline": dict(kernel="k_sw_strip16", bound="valu", achieved=tcups * OPS_PER_CELL, peak=VALU_PEAK_TOPS, unit="TOP/s", frac=tcups * OPS_PER_CELL / VALU_PEAK_TOPS,
+                         ops_per_cell_issue=OPS_PER_CELL, frac_survey=tcups * OPS_PER_CELL_SURVEY / VALU_PEAK_TOPS, gcups=tcups * 1e3, traffic=None, avg_launch_ms=sw_ms / nlaunch,
+                         cells_per_launch=cells / nlaunch, peak_note="same VALU issue peak and ops per cell as the headline kernel; the strip form carries H/F between strips through LDS and HBM"),
+        "kernel_ms_per_step": {kk: v / args.steps for kk, v in ms_acc.items()},
+        "align_phase": {"ticks_window_band_trace": work_acc[24:27], "band_passes": work_acc[27], "aligned_candidates": work_acc[28], "band_width_sum": work_acc[31]},
+    }
+    if not args.no_cpu_baseline:
+        smalt = os.path.join(ROOT, "oracle", "_ref", "smalt")
+        cores = max(1, int(os.environ.get("SMALT_BENCH_CPU_THREADS", host_core_count())))
+        try:
+            with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+                prefix = os.path.join(tmp, "ix")
+                gix.save(prefix)
+
+                def run(n):
+                    pth = os.path.join(tmp, "r%d.fq" % n)
+                    with open(pth, "wb") as f:
+                        for i in range(n):
+                            f.write(b"@r%d\n" % i + reads[i] + b"\n+\n" + b"5" * len(reads[i]) + b"\n")
+                    tt = time.time()
+                    subprocess.run([smalt, "map", "-n", str(cores), "-f", "cigar", "-o", os.path.join(tmp, "o.cig"), prefix, pth], check=True, capture_output=True)
+                    return time.time() - tt
+                n1, n2 = 4, min(nreads, max(20, cores + 8))
+                ta, tb = run(n1), run(n2)
+                line["cpu_baseline"] = dict(value=(n2 - n1) / max(tb - ta, 1e-6), unit="mapped reads/s", cores=cores, host_cores=host_core_count(), cpu_model=cpu_model(), kind="reference",
+                                            sample="smalt map -n %d on the first %d vs %d reads (slope: index load cancels), same index files; %.1f s + %.1f s wall" % (cores, n1, n2, ta, tb))
+        except Exception as e:
+            line["cpu_baseline"] = dict(value=None, unit="mapped reads/s", cores=0, kind="reference", sample="failed: %r" % (e,))
+    print(json.dumps(line), flush=True)
+    mapper.close()
+    gix.close()
+
+
 def main():
     args = parse_args()
+    if args.long:
+        if args.gpus > 1:
+            raise SystemExit("--long measures one GPU (configs[4])")
+        long_main(args)
+        return
     if args.paired:
         if args.gpus > 1:
             raise SystemExit("--paired measures one GPU (configs[2]); the multi-GPU line is the single-end job (configs[3])")
@@ -441,8 +573,19 @@ def main():
                 break
             got.append(j)
         parts = shard.gather_in_rank_order(got)
+        # ... and the guided dealing of the N > 1 job: every read of a 1 000 003-read job exactly once, pieces of 4096 .. 65536
+        dealer2 = shard.BatchDealer(1, static=args.static_shards)
+        dealer2.start("dry-guided")
+        pieces = []
+        while True:
+            pc = dealer2.next_range(1000003, 65536, 4096)
+            if pc is None:
+                break
+            pieces.append(pc)
+            time.sleep(0.0005 * (1 + rank))            # ranks of different speed
+        guided = shard.gather_in_rank_order(pieces)
         if rank == 0:
-            print(json.dumps({"n_gpus": world, "dry_run": True, "backend": backend, "dealt": parts}), flush=True)
+            print(json.dumps({"n_gpus": world, "dry_run": True, "backend": backend, "dealt": parts, "guided": guided}), flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -482,6 +625,7 @@ def main():
                 image["posidx"] = torch.as_tensor(_DevArray(d0.posidx, d0.nwords + 1), device=dev)
             meta = [d0.typ, d0.nbits_key, d0.nbits_lo, d0.npos, d0.nwords]
     bcast_ms = 0.0
+    bcast_by_array = {}
     if world > 1:
         ml = [meta]
         dist.broadcast_object_list(ml, 0)
@@ -489,6 +633,7 @@ def main():
         order = ("idx", "pos", "packed", "ref") + (("wordidx", "posidx") if meta[0] != 0 else ())
         image, bcast_s = shard.broadcast_image(image, dev, 0, order=order)
         bcast_ms = bcast_s * 1e3
+        bcast_by_array = {kk: {"ms": v["seconds"] * 1e3, "GB_per_s": v["bytes"] / max(v["seconds"], 1e-9) / 1e9} for kk, v in shard.broadcast_image.last_by_array.items()}
         ref = image["ref"]
     if rank == 0:
         gix = gix0
@@ -552,20 +697,33 @@ def main():
         dealer.start(tag)
         bi = 0
         while True:
-            j = dealer.next()
-            if j is None:
-                break
-            c, b0 = j // nsub_chunk, (j % nsub_chunk) * sub
-            n = min(sub, per_gpu - b0)
-            mp = mappers[bi % len(mappers)]
-            bi += 1
-            prev = state.pop(mp, None)
-            if prev is not None:
-                mp.fetch_begin()                      # waits for the mapper's previous sub-batch, enqueues the copies of its results
-            mp.map_batch_device(chunks[c].data_ptr() + b0 * args.read_len, 0, offs.data_ptr(), n, n * args.read_len, par)
-            state[mp] = n
-            if prev is not None:
-                fetch(mp, prev)                       # results put in read order on the host while the device runs the new sub-batch
+            if world > 1:                 # guided dealing over the job's reads: pieces shrink towards the end (shard.BatchDealer.next_range)
+                piece = dealer.next_range(job_reads, sub, 32768)
+                if piece is None:
+                    break
+                segs, at, left = [], piece[0], piece[1]
+                while left > 0:           # a piece that runs across two chunks of generated reads is mapped as two sub-batches
+                    c, b0 = at // per_gpu, at % per_gpu
+                    n = min(left, per_gpu - b0)
+                    segs.append((c, b0, n))
+                    at += n
+                    left -= n
+            else:
+                j = dealer.next()
+                if j is None:
+                    break
+                b0 = (j % nsub_chunk) * sub
+                segs = [(j // nsub_chunk, b0, min(sub, per_gpu - b0))]
+            for c, b0, n in segs:
+                mp = mappers[bi % len(mappers)]
+                bi += 1
+                prev = state.pop(mp, None)
+                if prev is not None:
+                    mp.fetch_begin()                      # waits for the mapper's previous sub-batch, enqueues the copies of its results
+                mp.map_batch_device(chunks[c].data_ptr() + b0 * args.read_len, 0, offs.data_ptr(), n, n * args.read_len, par)
+                state[mp] = n
+                if prev is not None:
+                    fetch(mp, prev)                       # results put in read order on the host while the device runs the new sub-batch
         for mp, n in list(state.items()):
             mp.fetch_begin()
             fetch(mp, n)
@@ -604,12 +762,12 @@ def main():
         tcups = cells / (sw_ms * 1e-3) / 1e12 if sw_ms > 0 else 0.0
         sw_tops = tcups * OPS_PER_CELL
         seed_bytes = work_acc[0] * 8 + work_acc[1] * 12
-        seed_ms = ms_acc.get("seed", 0.0) + ms_acc.get("cands", 0.0)
+        seed_ms = ms_acc.get("seed", 0.0) + ms_acc.get("hits", 0.0) + ms_acc.get("cands", 0.0)
         seed_gbs = seed_bytes / (seed_ms * 1e-3) / 1e9 if seed_ms > 0 else 0.0
         traffic_sw = traffic_seed = None          # HBM bytes per launch from the committed PMC passes (profiles/), scaled to this sub-batch
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            sc = sub / float(pt["reads_per_launch"])
+            sc = (my_reads / nlaunch) / float(pt["reads_per_launch"])      # mean reads per launch of this run
             traffic_sw = (pt["kernels"]["sw_full"]["fetch"] + pt["kernels"]["sw_full"]["write"]) * sc
             traffic_seed = sum(pt["kernels"][kk]["fetch"] + pt["kernels"][kk]["write"] for kk in ("seed", "cands")) * sc
         except Exception:
@@ -623,7 +781,7 @@ def main():
                        frac_survey=tcups * OPS_PER_CELL_SURVEY / VALU_PEAK_TOPS, ops_per_cell_survey=OPS_PER_CELL_SURVEY,
                        peak_note="256 CU x 4 SIMD x 32 lane-ops/clk x 2.4 GHz; packed 16-bit, max3 and perm issue at half rate with two halves each (profiles/r02_valu_rate.txt)",
                        traffic=traffic_sw, gcups=tcups * 1e3, avg_launch_ms=sw_ms / nlaunch, cells_per_launch=cells / nlaunch)
-        roof_seed = dict(kernel="k_seed+k_cands", bound="hbm", achieved=seed_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+        roof_seed = dict(kernel="k_seed+k_hits+k_cands", bound="hbm", achieved=seed_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
                          frac=seed_gbs / HBM_PEAK_GBS, traffic=traffic_seed, avg_launch_ms=seed_ms / nlaunch,
                          bytes_per_launch=seed_bytes / nlaunch)
         wl = ("configs[1]: %d x %d bp single-end reads" % (per_gpu, args.read_len)) if world == 1 else \
@@ -636,8 +794,8 @@ def main():
                        "reads_per_gpu_per_step": per_gpu, "job_reads_per_step": job_reads, "sub_batch": sub,
                        "mapped_fraction": mapped_all / (args.steps * job_reads),
                        "reads_per_s_total": args.steps * job_reads / dt, "setup_s": setup_s, "index_build_ms": build_ms,
-                       "index_broadcast_ms": bcast_ms, "backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
-                       "dealing": "static shards" if args.static_shards or world == 1 else "shared sub-batch cursor (c10d store)",
+                       "index_broadcast_ms": bcast_ms, "index_broadcast_by_array": bcast_by_array, "backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
+                       "dealing": "static shards" if args.static_shards or world == 1 else "shared read cursor (c10d store), guided piece sizes 32768..%d" % sub,
                        "reads_taken_min_max_per_rank": [reads_min / args.steps, reads_max / args.steps],
                        "parallelism": "read-shard x%d" % world, "streams": len(mappers)},
             "roofline": roof_sw if dom in ("sw_full",) else roof_seed,

@@ -92,7 +92,7 @@ typedef struct smaltgpu_readstat {
   uint32_t nres;
   int32_t max1scor;                   /* best score of the score pass (rmap.c:1355); < 1: mapSingleRead returned before the
                                        * traceback pass and did NOT re-sort the ResultSet (rmap.c:1376) */
-  int32_t reserved;
+  int32_t errsite;                    /* diagnostic: source line (library build) of the device-side limit or assertion behind errcode; 0 if none */
 } smaltgpu_readstat;
 
 typedef struct smaltgpu_batch_out {

@@ -47,7 +47,7 @@ class Result(C.Structure):
 class ReadStat(C.Structure):
     _fields_ = [("swatscor_max", C.c_int32), ("swatscor_2ndmax", C.c_int32), ("n_ali_done", C.c_int32),
                 ("n_ali_tot", C.c_int32), ("n_hits_used", C.c_uint32), ("n_hits_tot", C.c_uint32),
-                ("errcode", C.c_int32), ("nres", C.c_uint32), ("max1scor", C.c_int32), ("reserved", C.c_int32)]
+                ("errcode", C.c_int32), ("nres", C.c_uint32), ("max1scor", C.c_int32), ("errsite", C.c_int32)]
 
 
 class Interval(C.Structure):
@@ -390,7 +390,7 @@ class Mapper:
             res.append(rr)
             s = out.stat[i]
             stats.append(dict(swmax=s.swatscor_max, sw2nd=s.swatscor_2ndmax, nseg=s.n_ali_done, nseg_tot=s.n_ali_tot,
-                              nhit=s.n_hits_used, nhit_tot=s.n_hits_tot, err=s.errcode, max1=s.max1scor))
+                              nhit=s.n_hits_used, nhit_tot=s.n_hits_tot, err=s.errcode, max1=s.max1scor, errsite=s.errsite))
         return res, stats
 
     def map_batch_device(self, d_bases: int, d_quals: int, d_off: int, nreads: int, total_bases: int, params: Params):

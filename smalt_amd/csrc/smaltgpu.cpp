@@ -292,8 +292,8 @@ extern "C" void smaltgpu_params_default(smaltgpu_params *p, const smaltgpu_index
 }
 
 // ------------------------------------------------------------------------------------------
-enum { T_ENCODE = 0, T_SEED, T_CANDS, T_SW_FULL, T_SW_SCALAR, T_REPLAY, T_ALIGN, T_NUM };
-static const char *const kTimerNames[T_NUM] = {"encode", "seed", "cands", "sw_full", "sw_scalar", "replay", "align"};
+enum { T_ENCODE = 0, T_SEED, T_HITS, T_CANDS, T_SW_FULL, T_SW_SCALAR, T_REPLAY, T_ALIGN, T_NUM };
+static const char *const kTimerNames[T_NUM] = {"encode", "seed", "hits", "cands", "sw_full", "sw_scalar", "replay", "align"};
 extern "C" const char *smaltgpu_timer_name(int i) { return (i >= 0 && i < T_NUM) ? kTimerNames[i] : nullptr; }
 
 struct smaltgpu_mapper {
@@ -305,7 +305,9 @@ struct smaltgpu_mapper {
   // device buffers
   uint8_t *d_bases = nullptr, *d_quals = nullptr, *d_codes = nullptr, *d_codes_rc = nullptr;
   uint64_t *d_off = nullptr;
-  uint32_t *d_ids = nullptr;                  // read ids of a round gathered from resident batches (smaltgpu_map_batch_ctx_resident)
+  uint32_t *d_ids = nullptr;
+  uint32_t hits_W = 0, hits_wg = 0;          // k_hits: keys per window, workgroups (0: S3 stays inside k_cands)
+  HitRun *b_hitrun = nullptr;                 // the run table (Batch::hitrun is set per call: restricted calls do not use it)                  // read ids of a round gathered from resident batches (smaltgpu_map_batch_ctx_resident)
   Batch b;
   uint8_t *d_counters = nullptr;            // rc_count | res_count | dstr_count | err_flag | work[8]
   uint8_t *seed_scr = nullptr; size_t seed_bytes = 0; uint32_t seed_slots = 0;
@@ -432,6 +434,29 @@ extern "C" int smaltgpu_mapper_create_ex(smaltgpu_mapper **out, const smaltgpu_i
   DA(b.align_retry, max_batch_reads);
   DA(b.cands_retry, max_batch_reads);
   DA(m->d_counters, 512);
+  // S3 as a kernel of its own (k_hits) for mappers of short reads: sorted hit keys of every strand in one pool, 8 bytes per hit.
+  // SMALTGPU_HITS_SPLIT=0 keeps S3 inside k_cands; SMALTGPU_HITS_PER_READ sizes the pool (a batch that overflows it is re-mapped in
+  // smaller batches like any other pool overflow); SMALTGPU_HITS_WINDOW the keys per window of the kernel.
+  {
+    const char *e = getenv("SMALTGPU_HITS_SPLIT");
+    const bool split = (!e || atoi(e) != 0) && m->qmax <= 256;
+    if (split && !rv) {
+      const char *hp = getenv("SMALTGPU_HITS_PER_READ");
+      uint64_t per = hp ? strtoull(hp, nullptr, 10) : 6144;
+      if (per < 64) per = 64;
+      uint64_t cap = (uint64_t)max_batch_reads * per;
+      if (cap < (1ull << 20)) cap = 1ull << 20;                 // one read alone always fits (<= 2 x 4 x its hit-list allocation)
+      b.hitpool_cap = cap;
+      DA(b.hitpool, cap);
+      DA(b.hitrun, 2 * (size_t)max_batch_reads);
+      m->b_hitrun = b.hitrun;
+      const char *hw = getenv("SMALTGPU_HITS_WINDOW");
+      m->hits_W = hw ? (uint32_t)atoi(hw) : 1024u;       // measured (1 M reads of the bench): 512: 195 ms, 768: 124 ms, 1024: 112 ms
+      if (m->hits_W < 256) m->hits_W = 256;
+      if (m->hits_W > 1024) m->hits_W = 1024;
+      m->hits_wg = 256 * 24;                                     // persistent workgroups: more than can be resident at the smallest LDS block
+    }
+  }
   if (!rv) {
     b.rc_count = (uint32_t *)(m->d_counters + 0);
     b.res_count = (unsigned long long *)(m->d_counters + 8);
@@ -441,6 +466,8 @@ extern "C" int smaltgpu_mapper_create_ex(smaltgpu_mapper **out, const smaltgpu_i
     b.align_retry_n = (uint32_t *)(m->d_counters + 56);
     b.cands_retry_n = (uint32_t *)(m->d_counters + 60);
     b.work = (unsigned long long *)(m->d_counters + 64);
+    b.hit_count = (unsigned long long *)(m->d_counters + 328);
+    b.hits_cursor = (uint32_t *)(m->d_counters + 336);
   }
   // scratch geometry -------------------------------------------------------------------
   m->seed_bytes = (seed_scratch_bytes(m->qmax, d.s) + 255) & ~(size_t)255;
@@ -496,6 +523,9 @@ extern "C" int smaltgpu_mapper_create_ex(smaltgpu_mapper **out, const smaltgpu_i
     {
       uint64_t hw = next_pow2((uint64_t)m->cg.ngrp * alloc);
       if (hw < full.hcap_strand) hw = full.hcap_strand;
+      // rmapPair's restricted rounds keep one hit list per search interval, not per sequence (up to IV_MAX lists of up to `alloc`
+      // hits; the k = 5 index of the last round finds a hit per read base in every interval of a repeat): room for 2 M hits
+      if (hw < (2ull << 20)) hw = 2ull << 20;
       while (hw > full.hcap_strand && (hw > (1ull << 30) || geom_for(hw).slot_bytes > (4ull << 30))) hw >>= 1;      // at most 4 GB per slot
       if (hw > m->cg.hcap_strand) {
         m->cg2 = geom_for(hw); m->cg2.pass = 2; m->cand_bytes2 = m->cg2.slot_bytes;
@@ -565,7 +595,7 @@ extern "C" void smaltgpu_mapper_free(smaltgpu_mapper *m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   void *ps[] = {m->d_bases, m->d_quals, m->d_codes, m->d_codes_rc, m->d_off, m->d_ids, m->b.hi, m->b.seeds, m->b.qmask, m->b.ch, m->b.ctl,
-                m->b.stat, m->b.align_retry, m->b.cands_retry, m->b.rcpool, m->b.long_list, m->b.strip_list, m->strip_bnd, m->strip_win, m->b.respool, m->b.dstrpool, m->d_counters, m->seed_scr, m->cand_scr, m->cand_scr2, m->cand_scr_dbg,
+                m->b.stat, m->b.align_retry, m->b.cands_retry, m->b.hitpool, m->b_hitrun, m->b.rcpool, m->b.long_list, m->b.strip_list, m->strip_bnd, m->strip_win, m->b.respool, m->b.dstrpool, m->d_counters, m->seed_scr, m->cand_scr, m->cand_scr2, m->cand_scr_dbg,
                 m->sw_rows, m->align_scr, m->align_scr2};
   for (void *p : ps) if (p) (void)hipFree(p);
   m->h_stat.release(); m->h_res.release(); m->h_dstr.release();
@@ -641,6 +671,11 @@ static int run_pipeline(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_
   if (!rv && b.fine_idx) rv = launch_fine_index(s, b, d);
   HIPCHK(hipEventRecord(m->ev[T_SEED], s));
   if (!rv) rv = launch_seed(s, b, d, p, m->seed_scr, m->seed_bytes, m->seed_slots);
+  HIPCHK(hipEventRecord(m->ev[T_HITS], s));
+  // S3 ahead of the candidate stage (plain calls of short-read mappers; restricted calls keep it inside k_cands)
+  const bool split_hits = m->hits_W && m->b_hitrun && !b.iv_off && !seed_only;
+  b.hitrun = split_hits ? m->b_hitrun : nullptr;
+  if (!rv && split_hits) rv = launch_hits(s, b, d, p, m->hits_W, m->cg.tab, m->hits_wg);
   HIPCHK(hipEventRecord(m->ev[T_CANDS], s));
   if (seed_only) {
     for (int i = T_CANDS + 1; i <= T_NUM; i++) HIPCHK(hipEventRecord(m->ev[i], s));
@@ -732,7 +767,7 @@ extern "C" int smaltgpu_fetch_end(smaltgpu_mapper *m, smaltgpu_batch_out *out) {
     m->h_res_off[i] = w;
     smaltgpu_readstat &os = m->o_stat[i];
     os.swatscor_max = st.swmax; os.swatscor_2ndmax = st.sw2nd; os.n_ali_done = st.nseg; os.n_ali_tot = st.nseg_tot;
-    os.n_hits_used = st.nhit; os.n_hits_tot = st.nhit_tot; os.errcode = st.err; os.nres = st.nres; os.max1scor = st.max1; os.reserved = 0;
+    os.n_hits_used = st.nhit; os.n_hits_tot = st.nhit_tot; os.errcode = st.err; os.nres = st.nres; os.max1scor = st.max1; os.errsite = st.err_site;
     if (st.err) { if (!first_err) { first_err = st.err; first_err_read = i; } nerr++; }
     for (uint32_t j = 0; j < st.nres; j++) {
       const Result &r = m->h_res[st.res_off + j];
@@ -771,7 +806,8 @@ static int upload_ctx(smaltgpu_mapper *m, const smaltgpu_callctx *ctx, uint32_t 
     for (uint32_t i = 0; i <= n; i++) m->h_ivoff[i] = (uint32_t)(ctx->iv_off[i] - i0);
     for (uint32_t i = 0; i < n; i++) {
       uint64_t npos = 0;
-      if (m->h_ivoff[i + 1] - m->h_ivoff[i] > (uint32_t)IV_MAX) return fail(SMALTGPU_EARG, "read %u has more than %d search intervals", i, (int)IV_MAX);
+      // (a read with more than IV_MAX = 2047 intervals is not an error of the batch: the candidate stage gives that read
+      //  SMALTGPU_ECAP in its stat and every other read is mapped)
       for (uint64_t v = ctx->iv_off[i]; v < ctx->iv_off[i + 1]; v++) {
         const smaltgpu_interval &iv = ctx->iv[v];
         if (iv.sidx < 0 || iv.sidx >= d.nseq || iv.hi < iv.lo || m->ix->sop[(size_t)iv.sidx] + iv.hi >= m->ix->sop[(size_t)iv.sidx + 1])

@@ -166,11 +166,13 @@ template <bool LONG, class IT>
 SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, bool seqbyseq, uint32_t qlen, int k, int s,
                                uint32_t mincover, uint8_t *cover8, SegCand *cand, uint32_t candcap, uint32_t *ncand_io,
                                uint32_t *max_cover_io, uint32_t *max2nd_io, unsigned long long *ph,
-                               bool hold_tail, uint32_t *nproc_out, uint32_t *reg_base_io, const LongWork &lw, const IvRec *ivmap = nullptr) {
+                               bool hold_tail, uint32_t *nproc_out, uint32_t *reg_base_io, const LongWork &lw, const IvRec *ivmap = nullptr,
+                               bool presorted = false) {
   *nproc_out = n;
   if (!n) return 0;
   unsigned long long t0 = phase_clock(), t1;
 #define SMG_PH(i) { t1 = phase_clock(); ph[i] += t1 - t0; t0 = t1; }
+  if (!presorted) {                              // (k_hits delivers the keys of a strand in order)
 #if defined(__HIP_DEVICE_COMPILE__)
   if (StrandWork<IT>::L && n <= 1024) {          // LDS working set: keys sorted in registers
     if (n <= 256) wave_sort_u64_reg<4>(w.dat, n);
@@ -180,6 +182,7 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
 #else
   wave_sort_u64(w.dat, n);
 #endif
+  }
   SMG_SYNC();
   SMG_PH(2)
   uint32_t max_dshift = (uint32_t)(k * SEGMENTING_DIFFSHIFT / s) & 0xffffu;     // segment.c:426-429
@@ -345,7 +348,7 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
     if (f) {
       uint32_t lo = 0, hi = nreg;                // hit region of segment m (kept in the 40-byte record only: short reads skip the search)
       if (LONG) while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)w.reg_first[mid] <= m) lo = mid; else hi = mid; }
-      const uint32_t grp = seqbyseq ? (key_grp(w.dat[w.seed_first[w.segm_first[m]]]) & ((1u << KEY_SEQBITS) - 1)) : 0u;
+      const uint32_t grp = seqbyseq ? (key_grp(w.dat[w.seed_first[w.segm_first[m]]]) & ((2u << KEY_SEQBITS) - 1)) : 0u;     // (11 bits: interval numbers of restricted calls)
       int32_t seqidx = seqbyseq ? (int32_t)grp : -1;
       if (ivmap) seqidx = ivmap[seqidx].sx;       // interval-restricted call: the key's group is the interval number (rmap.c:486-490)
       SegCand c;
@@ -504,7 +507,7 @@ SMG_HD inline void dbg_hits(const CandsV2Scratch &x, const uint64_t *dat, uint32
     if (i < n) {
       const uint64_t key = dat[i];
       const uint32_t grp = key_grp(key), prev = i ? key_grp(dat[i - 1]) : last_grp;
-      const uint32_t gi = st * ngrp + (seqbyseq ? (grp & ((1u << KEY_SEQBITS) - 1)) : 0u);
+      const uint32_t gi = st * ngrp + (seqbyseq ? (grp & ((2u << KEY_SEQBITS) - 1)) : 0u);
       if (prev != grp) x.dbg_first[gi] = gbase + i + st * x.hcap_strand;
       (void)atomic_add_u32(&x.dbg_cnt[gi], 1u);
       dw[gbase + i] = key_packed(key);
@@ -565,8 +568,296 @@ SMG_HD inline bool cands_v2_applicable(const MapPar &p, int k, int s, uint32_t q
   return qlen < (1u << KEY_QBITS) && read_min_cover(p, qlen) < (uint32_t)(k + s);     // calcMinKtup (rmap.c:240-247) gives min_ktup == 1
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// S3 on its own (kernel k_hits): the hits of one read strand are gathered from the position lists of its seeds, packed,
+// put in order and written ONCE to the batch-wide pool; the candidate stage then streams them (stage_cands_v2, HITRUN_SORTED).
+// Same lists and the same windows of ascending diagonal as the fused form further down -- but nothing of S4-S7 lives in this
+// kernel, so it takes a third of the registers and half the LDS, and two to three times as many waves stay resident to hide
+// the dependent index reads and LDS round trips the stage waits for.  What the fused form does not treat as a plain strand
+// (allocation-boundary protocol, hashhit.c:1497), restricted calls (rmapPair) and reads of 256 bases and more keep S3 inside
+// the candidate stage (HITRUN_NONE); so does any strand on which this function meets something it does not expect.
+struct HitsScratch {
+  uint8_t *lds; size_t lds_bytes;
+  uint32_t W, tab;            // keys per window; entries of the per-list tables
+};
+SMG_HD inline size_t hits_lds_bytes(uint32_t W, uint32_t tab) { return (size_t)W * 8 + (((size_t)W + 64) * 2 + 15 & ~(size_t)15) + (size_t)5 * tab * 4 + 64; }
+
+SMG_HD inline void stage_hits(const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t r, uint32_t st, const HitsScratch &x, unsigned long long *ph) {
+  unsigned long long t0 = phase_clock(), t1;
+#define SMG_PH(i) { t1 = phase_clock(); ph[i] += t1 - t0; t0 = t1; }
+  const uint32_t rs = 2 * r + st;
+  const uint32_t qlen = read_len(b, r);
+  const int k = ix.k, s = ix.s;
+  const bool seqbyseq = (p.flags & FLG_SEQBYSEQ) != 0;
+  HitRun run;
+  run.off = 0; run.n = 0; run.mode = HITRUN_NONE;
+  typedef typename ptr_of<uint64_t, true>::type P64;
+  typedef typename ptr_of<uint16_t, true>::type P16;
+  typedef typename ptr_of<uint32_t, true>::type P32;
+  const uint32_t W = x.W;
+  P64 dat = (P64)x.lds;
+  P16 marks = (P16)(x.lds + (size_t)W * 8);
+  P32 gt = (P32)(x.lds + (size_t)W * 8 + ((((size_t)W + 64) * 2 + 15) & ~(size_t)15));
+  const uint32_t tabn = x.tab;
+  P32 g_pfx = gt, g_poff = gt + tabn, g_qo = gt + 2 * tabn, g_len = gt + 3 * tabn, g_cur = gt + 4 * tabn;
+  const HitInfoHdr hdr = b.hi[rs];
+  const uint32_t n_use = hdr.seed_rank > 0 ? hdr.seed_rank : hdr.n_seeds;
+  bool mine = qlen >= (uint32_t)k && qlen < 256u && !b.iv_off && cands_v2_applicable(p, k, s, qlen) && n_use < tabn && W > tabn + 128u &&
+              hits_lds_bytes(W, tabn) <= x.lds_bytes;
+  if (!mine) { SMG_LANE0 { b.hitrun[rs] = run; } return; }
+  int nhits_alloc, nhits_max;
+  {
+    double t = (double)qlen * log((double)qlen) * HITLST_LOGQLEN_FACT;   // hashhit.c:1266
+    long long target = (long long)t;
+    if (target > 0x7fffffffLL) target = 0x7fffffffLL; else if (target < HITLST_MINSIZ) target = HITLST_MINSIZ;
+    long long alloc = HITLST_BLKSZ;
+    if (target > alloc) alloc = ((target + HITLST_BLKSZ - 1) / HITLST_BLKSZ) * HITLST_BLKSZ;
+    nhits_alloc = (int)alloc; nhits_max = (int)target;
+  }
+  const uint32_t ncut = (uint32_t)(p.ncut > 0 ? p.ncut : 0);
+  const uint32_t smagic = div_magic(s);
+  const SeedRec *seeds = b.seeds + (size_t)rs * b.qmax;
+  uint8_t *qmask = b.qmask + (size_t)rs * b.qmax;
+  uint32_t tot = 0;
+  SMG_PAR_CHUNKS(base, n_use) { const uint32_t n = base + SMG_LANE; if (n < n_use && !(ncut > 0 && seeds[n].nhits > ncut)) tot += seeds[n].nhits; }
+  tot = wave_sum_u32(tot);
+  uint32_t d_used = n_use, d_mfinal = 0;                      // concatenated mode: hashCollectHitsUsingCutoff's outcome (hashhit.c:1593-1689)
+  if (seqbyseq) {
+    if (tot > (uint32_t)nhits_alloc) { SMG_LANE0 { b.hitrun[rs] = run; } return; }       // allocation-boundary protocol: the candidate stage's business
+    SMG_PAR_CHUNKS(base, n_use) { const uint32_t n = base + SMG_LANE; if (n < n_use && ncut > 0 && seeds[n].nhits > ncut) qmask[seeds[n].qoffs] = HQ_MULTIHIT; }
+  } else {
+    SMG_LANE0 {
+      uint32_t m = ncut;
+      for (;;) {
+        uint32_t total = 0, i;
+        bool ceiling = false;
+        for (i = 0; i < n_use; i++) {
+          const uint32_t nh = seeds[i].nhits;
+          if (nh < 1) continue;
+          if (m > 0 && nh > m) continue;
+          if ((int)(total + nh) > nhits_max) { ceiling = true; break; }
+          total += nh;
+        }
+        const uint32_t mf = m;
+        m /= 2;
+        if (!(ceiling && m > (uint32_t)MINHIT_PER_TUPLE)) { d_used = i; d_mfinal = mf; break; }
+      }
+    }
+    d_used = bcast_lane0(d_used); d_mfinal = bcast_lane0(d_mfinal);
+  }
+  // position lists that contribute, with the exclusive prefix of their lengths
+  uint32_t nlist = 0, total = 0;
+  SMG_PAR_CHUNKS(base, n_use) {
+    const uint32_t n = base + SMG_LANE;
+    bool take = false;
+    uint32_t nh = 0, poff = 0, qo = 0;
+    if (n < n_use) {
+      const SeedRec sd = seeds[n];
+      if (seqbyseq) take = !(ncut > 0 && sd.nhits > ncut);
+      else take = !(n >= d_used || (d_mfinal > 0 && sd.nhits > d_mfinal) || sd.nhits < 1);
+      if (take) {
+        const uint32_t *posp;
+        nh = index_positions(ix, sd.posidx, &posp);
+        poff = (uint32_t)(posp - ix.pos); qo = sd.qoffs;
+        take = nh > 0;
+      }
+    }
+    uint32_t incl = nh;
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if ((int)SMG_LANE >= o) incl += v; }
+#endif
+    const uint32_t slot = compact_slot(take, nlist);
+    if (take) { g_pfx[slot] = total + incl - nh; g_poff[slot] = poff; g_qo[slot] = qo; g_len[slot] = nh; g_cur[slot] = 0; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    total += (uint32_t)__shfl((int)incl, 63);
+#else
+    total += incl;
+#endif
+  }
+  SMG_SYNC();
+  if (!total) { run.mode = HITRUN_SORTED; SMG_LANE0 { b.hitrun[rs] = run; } return; }
+  // a place in the pool
+  {
+    unsigned long long at = 0;
+    SMG_LANE0 { at = atomic_add_u64(b.hit_count, (unsigned long long)total); }
+    run.off = (unsigned long long)bcast_lane0((uint32_t)at) | (unsigned long long)bcast_lane0((uint32_t)(at >> 32)) << 32;
+  }
+  run.n = total;
+  if (run.off + total > b.hitpool_cap) { run.mode = HITRUN_OVERFLOW; SMG_LANE0 { b.hitrun[rs] = run; } return; }
+  uint64_t *out = b.hitpool + run.off;
+  SMG_PH(0)
+  auto sort_and_write = [&](uint32_t n, uint32_t at) {
+    const unsigned long long ts0 = phase_clock();
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (n <= 256) wave_sort_u64_reg<4>(dat, n);
+    else if (n <= 512) wave_sort_u64_reg<8>(dat, n);
+    else if (n <= 1024) wave_sort_u64_reg<16>(dat, n);
+    else wave_sort_u64(dat, n);
+#else
+    wave_sort_u64(dat, n);
+#endif
+    SMG_SYNC();
+    SMG_PAR_CHUNKS(base, n) { const uint32_t i = base + SMG_LANE; if (i < n) out[at + i] = dat[i]; }
+    SMG_SYNC();
+    ph[2] += phase_clock() - ts0;
+  };
+  bool bad = false;
+  if (total <= W) {
+    for (uint32_t base = 0; base < total; base += 4 * SMG_NLANES) {        // four independent index reads in flight per lane
+      uint32_t pos[4], qo[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t h = base + (uint32_t)u * SMG_NLANES + SMG_LANE;
+        if (h < total) {
+          uint32_t lo = 0, hi = nlist;                     // last list with prefix <= h
+          while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g_pfx[mid] <= h) lo = mid; else hi = mid; }
+          pos[u] = ix.pos[g_poff[lo] + (h - g_pfx[lo])]; qo[u] = g_qo[lo];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t h = base + (uint32_t)u * SMG_NLANES + SMG_LANE;
+        if (h < total) {
+          uint64_t key = (hit_diag_m(st != 0, pos[u], qo[u], smagic) << KEY_QBITS) | qo[u];
+          if (seqbyseq) key |= (uint64_t)seq_of_pos(ix.seqlo, ix.nseq, pos[u]) << (KEY_DIAGBITS + KEY_QBITS);
+          dat[h] = key;
+        }
+      }
+    }
+    SMG_SYNC();
+    SMG_PH(1)
+    sort_and_write(total, 0);
+    t0 = phase_clock();
+  } else {
+    // windows of ascending diagonal: every list contributes what lies below the window's bound (stage_cands_v2, mode 1)
+    uint32_t remaining = total, written = 0;
+    uint64_t prev_bound = 0;
+    const uint32_t room = W - nlist;
+    while (remaining > 0) {
+      uint64_t bound = ~0ull;
+      SMG_PAR_CHUNKS(base, nlist) {
+        const uint32_t l = base + SMG_LANE;
+        if (l < nlist) {
+          const uint32_t cur = g_cur[l], rem = g_len[l] - cur;
+          if (rem) {
+            const uint32_t t = (uint32_t)(((uint64_t)room * rem) / remaining) + 1;
+            if (t < rem) {
+              const uint32_t pos = ix.pos[g_poff[l] + cur + t];
+              uint64_t kh = hit_diag_m(st != 0, pos, g_qo[l], smagic);
+              if (seqbyseq) kh |= (uint64_t)seq_of_pos(ix.seqlo, ix.nseq, pos) << KEY_DIAGBITS;
+              if (kh < bound) bound = kh;
+            }
+          }
+        }
+      }
+      bound = wave_min_u64(bound);
+      SMG_PAR_CHUNKS(base, room + nlist) { const uint32_t i = base + SMG_LANE; if (i < room + nlist) marks[i] = 0; }
+      SMG_SYNC();
+      uint32_t cnt_tot = 0;
+      SMG_PAR_CHUNKS(base, nlist) {
+        const uint32_t l = base + SMG_LANE;
+        uint32_t cnt = 0;
+        if (l < nlist) {
+          const uint32_t cur = g_cur[l], rem = g_len[l] - cur;
+          if (rem) {
+            const uint32_t t = (uint32_t)(((uint64_t)room * rem) / remaining) + 1;
+            uint32_t lo = 0, hi = t < rem ? t : rem;
+            const uint32_t *pp = ix.pos + g_poff[l] + cur;
+            const int64_t qs = (int64_t)(g_qo[l] / (uint32_t)s);
+            const uint64_t db = bound & ((1ull << KEY_DIAGBITS) - 1ull);
+            int64_t plim = st != 0 ? (int64_t)db - qs : (int64_t)db - (int64_t)(1ull << 32) + qs;
+            if (seqbyseq) {
+              const uint32_t sb = (uint32_t)(bound >> KEY_DIAGBITS);
+              if (sb >= (uint32_t)ix.nseq) plim = (int64_t)1 << 33;
+              else {
+                const int64_t slo = (int64_t)ix.seqlo[sb], shi = sb + 1 < (uint32_t)ix.nseq ? (int64_t)ix.seqlo[sb + 1] : ((int64_t)1 << 33);
+                plim = plim < slo ? slo : (plim > shi ? shi : plim);
+              }
+            } else if (bound == ~0ull) plim = (int64_t)1 << 33;
+            while (lo < hi) {                                  // eight-way search: seven independent index reads per round
+              const uint32_t n = hi - lo, step = (n + 7) >> 3;
+              uint32_t pv[7];
+#pragma unroll
+              for (int u = 0; u < 7; u++) { const uint32_t ip_ = lo + (uint32_t)(u + 1) * step - 1; pv[u] = ip_ < hi ? pp[ip_] : 0xffffffffu; }
+              uint32_t c = 0;
+#pragma unroll
+              for (int u = 0; u < 7; u++) c += ((lo + (uint32_t)(u + 1) * step - 1 < hi) && (int64_t)pv[u] < plim) ? 1u : 0u;
+              const uint32_t nlo = lo + c * step, piv = nlo + step - 1;
+              if (c < 7 && piv < hi) hi = piv;
+              lo = nlo;
+              if (step == 1 && c < 7) break;
+            }
+            cnt = lo < hi ? lo : hi;
+          }
+        }
+        uint32_t incl = cnt;
+#if defined(__HIP_DEVICE_COMPILE__)
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if ((int)SMG_LANE >= o) incl += v; }
+#endif
+        if (l < nlist) { g_pfx[l] = cnt_tot + incl - cnt; if (cnt && cnt_tot + incl - cnt < room + nlist) marks[cnt_tot + incl - cnt] = (uint16_t)(l + 1); }
+#if defined(__HIP_DEVICE_COMPILE__)
+        cnt_tot += (uint32_t)__shfl((int)incl, 63);
+#else
+        cnt_tot += incl;
+#endif
+      }
+      SMG_SYNC();
+      if (cnt_tot > W || cnt_tot == 0) { bad = true; break; }
+      const uint32_t sq_lo = seqbyseq ? (uint32_t)(prev_bound >> KEY_DIAGBITS) : 0u;
+      uint32_t sq_hi = seqbyseq ? (uint32_t)(bound >> KEY_DIAGBITS) : 0u;
+      if (sq_hi >= (uint32_t)ix.nseq) sq_hi = (uint32_t)ix.nseq - 1;
+      prev_bound = bound;
+      uint32_t id_carry = 0;
+      for (uint32_t base = 0; base < cnt_tot; base += 4 * SMG_NLANES) {
+        uint32_t pos[4], qo[4], mk[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t h = base + (uint32_t)u * SMG_NLANES + SMG_LANE; mk[u] = h < cnt_tot ? (uint32_t)marks[h] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t h = base + (uint32_t)u * SMG_NLANES + SMG_LANE;
+          const uint32_t id = wave_scan_max_u32(mk[u], id_carry, &id_carry);
+          if (h < cnt_tot) {
+            const uint32_t lo = id - 1;
+            pos[u] = ix.pos[g_poff[lo] + g_cur[lo] + (h - g_pfx[lo])]; qo[u] = g_qo[lo];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t h = base + (uint32_t)u * SMG_NLANES + SMG_LANE;
+          if (h < cnt_tot) {
+            uint64_t key = (hit_diag_m(st != 0, pos[u], qo[u], smagic) << KEY_QBITS) | qo[u];
+            if (seqbyseq) {
+              uint32_t lo = sq_lo, hi = sq_hi + 1;
+              while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (ix.seqlo[m] <= pos[u]) lo = m; else hi = m; }
+              key |= (uint64_t)lo << (KEY_DIAGBITS + KEY_QBITS);
+            }
+            dat[h] = key;
+          }
+        }
+      }
+      SMG_SYNC();
+      SMG_PAR_CHUNKS(base, nlist) {
+        const uint32_t l = base + SMG_LANE;
+        if (l < nlist) g_cur[l] += (l + 1 < nlist ? g_pfx[l + 1] : cnt_tot) - g_pfx[l];
+      }
+      remaining -= cnt_tot;
+      SMG_SYNC();
+      SMG_PH(1)
+      sort_and_write(cnt_tot, written);
+      t0 = phase_clock();
+      written += cnt_tot;
+    }
+    if (!bad && written != total) bad = true;
+  }
+  if (!bad) run.mode = HITRUN_SORTED;          // (else the candidate stage does this strand itself; the pool space stays unused)
+  SMG_LANE0 { b.hitrun[rs] = run; }
+#undef SMG_PH
+}
+
 // LONG: reads of 256 bases and more (wide covers, coverage masks in memory, 64-bit ranking words)
-template <bool LONG>
+// SPLIT: S3 runs ahead in k_hits; a strand it left alone (HITRUN_NONE) takes the HBM working set here, so the windowed gather is
+// not part of this instance (fewer live registers in the kernel)
+template <bool LONG, bool SPLIT = false>
 SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t r, CandsV2Scratch &x, unsigned long long *ph) {
   unsigned long long t0 = phase_clock(), t1;
 #define SMG_PH(i) { t1 = phase_clock(); ph[i] += t1 - t0; t0 = t1; }
@@ -576,7 +867,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   const bool seqbyseq = (p.flags & FLG_SEQBYSEQ) != 0;
   const uint32_t ngrp = x.ngrp;
   if (qlen < (uint32_t)k) {
-    SMG_LANE0 { ch.ncand = ch.n_sort = ch.n_mincover = ch.max_cover = ch.max2nd_cover = 0; ch.cover_deficit[0] = ch.cover_deficit[1] = 0; ch.rc_off = 0; ch.err = 0; ch.nhits[0] = ch.nhits[1] = 0; ch.n_reserved = 0; }
+    SMG_LANE0 { ch.ncand = ch.n_sort = ch.n_mincover = ch.max_cover = ch.max2nd_cover = 0; ch.cover_deficit[0] = ch.cover_deficit[1] = 0; ch.rc_off = 0; ch.err = 0; ch.err_site = 0; ch.nhits[0] = ch.nhits[1] = 0; ch.n_reserved = 0; }
     return 0;
   }
   const uint32_t min_cover = (uint32_t)k;                         // (min_ktup - 1) * s + k with min_ktup == 1
@@ -598,15 +889,15 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   }
   const uint32_t ncut = (uint32_t)(p.ncut > 0 ? p.ncut : 0);
   const uint32_t smagic = div_magic(s);
-  int err = 0;
+  int err = 0, site = 0;
   uint32_t ncand = 0, max_cover = 0, max2nd = 0, nhits_total = 0;
   if (x.dbg_first) { SMG_PAR_CHUNKS(base, 2 * ngrp) { uint32_t g = base + SMG_LANE; if (g < 2 * ngrp) { x.dbg_first[g] = 0; x.dbg_cnt[g] = 0; } } }
 
   // rmapPair's restricted calls (rmap.c:1940-1954, :2010-2039): one hit list per interval instead of per sequence
-  const bool ivmode = b.iv_off != nullptr;
+  const bool ivmode = !SPLIT && b.iv_off != nullptr;          // (restricted calls never run with S3 split off: the launcher sees to that)
   const uint32_t niv = ivmode ? b.iv_off[r + 1] - b.iv_off[r] : 0u;
   const IvRec *ivr = ivmode ? b.iv + b.iv_off[r] : nullptr;
-  if (ivmode && (niv > (uint32_t)IV_MAX || (uint64_t)2 * niv > x.candcap)) err = SMG_ERR_CAP;
+  if (ivmode && (niv > (uint32_t)IV_MAX || (uint64_t)2 * niv > x.candcap)) { err = SMG_ERR_CAP; site = __LINE__; }
 
   for (uint32_t st = 0; st < 2 && !err; st++) {
     const uint32_t rs = 2 * r + st;
@@ -678,13 +969,13 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
         nkeys += incl;
 #endif
       }
-      if (wave_any(ovf)) { err = SMG_ERR_CAP; break; }
+      if (wave_any(ovf)) { err = SMG_ERR_CAP; site = __LINE__; break; }
       SMG_SYNC();
       uint32_t nproc = nkeys, reg_base = 0;
       const int rv = strand_cands<LONG>(wg, nkeys, st != 0, true, qlen, k, s, min_cover, x.cover8, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph,
                                         false, &nproc, &reg_base, x.lw, ivr);
       t0 = phase_clock();
-      if (rv) { err = rv; break; }
+      if (rv) { err = rv; site = __LINE__; break; }
       SMG_LANE0 { ch.nhits[st] = nkeys; }
       nhits_total += nkeys;
       SMG_SYNC();
@@ -744,6 +1035,69 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
       x.lw.prune_on = 1;
     }
     SMG_PH(0)
+    // ---- the strand's keys already lie sorted in the batch-wide pool (k_hits): stream them through the LDS working set in
+    //      chunks that end at a hit-region boundary, the unfinished region carried into the next chunk ----
+    if (SPLIT && b.hitrun && !ivmode && b.hitrun[rs].mode != HITRUN_NONE) {
+      const HitRun run = b.hitrun[rs];
+      if (run.mode != HITRUN_SORTED) { err = SMG_ERR_CAP; site = __LINE__; break; }
+      const uint64_t *src = b.hitpool + run.off;
+      uint64_t *dbg_w = x.dbg_words ? x.dbg_words + (size_t)st * x.hcap_strand : nullptr;
+      const size_t wl_bytes = (strand_work_bytes<uint16_t>(x.lds_hits) + 15) & ~(size_t)15;
+      uint32_t W = x.lds_hits;
+      if (x.window && x.window < W) W = x.window;
+      const uint32_t ncand0 = ncand, mx0 = max_cover, mx20 = max2nd;
+      int rv = SMG_WINDOW_FALLBACK;
+      if (x.lds && wl_bytes <= x.lds_bytes && W >= 128) {
+        StrandWork<uint16_t> wl = strand_work_carve<uint16_t>(x.lds, x.lds_hits);
+        uint32_t carry = 0, done = 0, reg_base = 0, gproc = 0, last_grp = ~0u;
+        rv = 0;
+        while (done < run.n) {
+          if (carry + 64 > W) { rv = SMG_WINDOW_FALLBACK; break; }
+          const uint32_t take = (run.n - done) < (W - carry) ? (run.n - done) : (W - carry);
+          SMG_PAR_CHUNKS(base, take) { const uint32_t i = base + SMG_LANE; if (i < take) wl.dat[carry + i] = src[done + i]; }
+          done += take;
+          const uint32_t n = carry + take;
+          SMG_SYNC();
+          SMG_PH(1)
+          uint32_t nproc = n;
+          rv = strand_cands<LONG>(wl, n, st != 0, seqbyseq, qlen, k, s, min_cover, x.cover8, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph,
+                                  done < run.n, &nproc, &reg_base, x.lw, nullptr, true);
+          t0 = phase_clock();
+          if (rv) break;
+          if (dbg_w) dbg_hits(x, (const uint64_t *)wl.dat, nproc, gproc, st, ngrp, seqbyseq, dbg_w, last_grp);
+          gproc += nproc;
+          carry = n - nproc;
+          for (uint32_t base = 0; base < carry; base += SMG_NLANES) {
+            const uint32_t i = base + SMG_LANE;
+            uint64_t v = 0;
+            if (i < carry) v = wl.dat[nproc + i];
+            SMG_SYNC();
+            if (i < carry) wl.dat[i] = v;
+            SMG_SYNC();
+          }
+        }
+        ph[12] += run.n;
+      }
+      if (rv == SMG_WINDOW_FALLBACK) {                // a hit region larger than a chunk (or no LDS block): the whole strand on the HBM working set
+        ncand = ncand0; max_cover = mx0; max2nd = mx20;
+        SMG_SYNC();
+        if (x.dbg_first) { SMG_PAR_CHUNKS(base, ngrp) { uint32_t g = base + SMG_LANE; if (g < ngrp) { x.dbg_first[st * ngrp + g] = 0; x.dbg_cnt[st * ngrp + g] = 0; } } SMG_SYNC(); }
+        if (run.n > x.hcap_strand) { err = SMG_ERR_CAP; site = __LINE__; break; }
+        StrandWork<uint32_t> wg = strand_work_carve<uint32_t>(x.hbm, x.hcap_strand);
+        wg.dat = const_cast<uint64_t *>(src);         // in order already; the index arrays of S4 live in the slot
+        uint32_t nproc = run.n, reg_base = 0, last_grp = ~0u;
+        rv = strand_cands<LONG>(wg, run.n, st != 0, seqbyseq, qlen, k, s, min_cover, x.cover8, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph,
+                                false, &nproc, &reg_base, x.lw, nullptr, true);
+        t0 = phase_clock();
+        ph[14]++; ph[15] += t0 - ts;
+        if (!rv && dbg_w) dbg_hits(x, src, run.n, 0, st, ngrp, seqbyseq, dbg_w, last_grp);
+      }
+      if (rv) { err = rv; site = __LINE__; break; }
+      SMG_LANE0 { ch.nhits[st] = run.n; }
+      nhits_total += run.n;
+      SMG_SYNC();
+      continue;
+    }
     // ---- working set --------------------------------------------------------------------------
     //  mode 0: the whole strand fits the LDS working set
     //  mode 1: larger strands are streamed through the LDS working set in windows of ascending diagonal;
@@ -753,7 +1107,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     const size_t wl_bytes = (strand_work_bytes<uint16_t>(x.lds_hits) + 15) & ~(size_t)15;
     const bool lds_ok = x.lds && wl_bytes + (size_t)5 * x.tab * 4 <= x.lds_bytes && n_use < x.tab;
     const uint32_t tabn = lds_ok ? x.tab : ((n_use + 8) & ~3u);      // tables in the sort arrays (2 * candcap words) otherwise
-    if (!lds_ok && (uint64_t)5 * tabn > (uint64_t)2 * x.candcap) { err = SMG_ERR_CAP; break; }
+    if (!lds_ok && (uint64_t)5 * tabn > (uint64_t)2 * x.candcap) { err = SMG_ERR_CAP; site = __LINE__; break; }
     uint32_t W = x.lds_hits;
     if (x.window && x.window < W) W = x.window;
     StrandWork<uint16_t> wl = strand_work_carve<uint16_t>(x.lds, x.lds_hits);
@@ -794,12 +1148,12 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
       SMG_SYNC();
     }
     { const unsigned long long tq = phase_clock(); ph[11] += tq - t0; }
-    int mode = !simple ? 2 : ((lds_ok && total <= W) ? 0 : (lds_ok ? 1 : 2));
+    int mode = (!simple || SPLIT) ? 2 : ((lds_ok && total <= W) ? 0 : (lds_ok ? 1 : 2));
     const uint32_t ncand0 = ncand, mx0 = max_cover, mx20 = max2nd;
     uint32_t nkeys = 0;
     uint64_t *dbg_w = x.dbg_words ? x.dbg_words + (size_t)st * x.hcap_strand : nullptr;
 
-    if (mode == 1) {
+    if (!SPLIT && mode == 1) {
       uint32_t *g_cur = gt + 4 * tabn;                 // per-list cursor
       auto marks = wl.reg_num;                          // [W] list starts among the hits of the window under construction
       SMG_PAR_CHUNKS(base, nlist) { const uint32_t l = base + SMG_LANE; if (l < nlist) g_cur[l] = 0; }
@@ -957,7 +1311,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
         SMG_LANE0 { uint32_t c = 0; for (uint32_t l = 0; l < nlist; l++) { g_pfx[l] = c; c += g_len[l]; } }   // the windows reused the prefix table
         SMG_SYNC();
         if (x.dbg_first) { SMG_SYNC(); SMG_PAR_CHUNKS(base, ngrp) { uint32_t g = base + SMG_LANE; if (g < ngrp) { x.dbg_first[st * ngrp + g] = 0; x.dbg_cnt[st * ngrp + g] = 0; } } SMG_SYNC(); }
-      } else if (rv) { err = rv; break; }
+      } else if (rv) { err = rv; site = __LINE__; break; }
       else nkeys = total;
       ph[12] += total;
     }
@@ -967,7 +1321,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
       const uint32_t gcap = in_lds ? x.lds_hits : x.hcap_strand;
       uint64_t *dat = in_lds ? (uint64_t *)wl.dat : wg.dat;
       if (simple) {
-        if (total > gcap) { err = SMG_ERR_CAP; break; }
+        if (total > gcap) { err = SMG_ERR_CAP; site = __LINE__; break; }
         nkeys = total;
         for (uint32_t base = 0; base < nkeys; base += 4 * SMG_NLANES) {        // four independent index reads in flight per lane
           uint32_t pos[4], qo[4];
@@ -1013,7 +1367,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
             if (take && nkeys + slot < gcap) dat[nkeys + slot] = key;
           }
           nkeys += cnt;
-          if (nkeys > gcap) { err = SMG_ERR_CAP; break; }
+          if (nkeys > gcap) { err = SMG_ERR_CAP; site = __LINE__; break; }
         }
         if (err) break;
       }
@@ -1025,7 +1379,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
       else rv = strand_cands<LONG>(wg, nkeys, st != 0, seqbyseq, qlen, k, s, min_cover, x.cover8, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph, false, &nproc, &reg_base, x.lw);
       t0 = phase_clock();
       if (!in_lds) { ph[14]++; ph[15] += t0 - ts; }
-      if (rv) { err = rv; break; }
+      if (rv) { err = rv; site = __LINE__; break; }
       if (dbg_w) dbg_hits(x, dat, nkeys, 0, st, ngrp, seqbyseq, dbg_w, last_grp);
     }
     SMG_LANE0 { ch.nhits[st] = nkeys; }
@@ -1057,7 +1411,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     size_t hb = (size_t)(nwq + 1) * (uint32_t)s;
     if (hb < nbins) hb = nbins;
     kv64 = (uint64_t *)(x.hbm + ((hb * 4 + 15) & ~(size_t)15));
-    if ((size_t)((uint8_t *)kv64 - x.hbm) + (size_t)ncand * 8 > strand_work_bytes<uint32_t>(x.hcap_strand)) err = err ? err : SMG_ERR_CAP;
+    if ((size_t)((uint8_t *)kv64 - x.hbm) + (size_t)ncand * 8 > strand_work_bytes<uint32_t>(x.hcap_strand)) { if (!err) site = __LINE__; err = err ? err : SMG_ERR_CAP; }
   }
   SMG_SYNC();
   uint32_t cdf[2] = {0, 0};
@@ -1075,7 +1429,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   if (min_cov_thr > max2nd) { cdfx = min_cov_thr - max2nd; min_cov_thr = max2nd; }
   const uint32_t adj = (cdf[0] > cdfx) ? cdf[0] - cdfx : 0;       // deficit of strand [0] for both strands (:1676)
   uint32_t nmin = 0;
-  if (!LONG && !err && (ncand > (1u << WSORT_IDXBITS) || max_cover >= (uint32_t)WSORT_NBINS)) err = SMG_ERR_CAP;
+  if (!LONG && !err && (ncand > (1u << WSORT_IDXBITS) || max_cover >= (uint32_t)WSORT_NBINS)) { err = SMG_ERR_CAP; site = __LINE__; }
   if (!err) {
     if (ncand > lds_sort_cap) kv = x.sort_keys;
     SMG_PAR_CHUNKS(base, nbins) { const uint32_t i = base + SMG_LANE; if (i < nbins) hist[i] = 0; }
@@ -1149,10 +1503,10 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
   if (x.pass == 1 && err == SMG_ERR_CAP) err = SMG_ERR_RETRY;      // slot capacity: the second pass has full-size slots
   SMG_LANE0 {
     ch.ncand = ncand; ch.n_sort = nrank; ch.n_mincover = nmin; ch.max_cover = max_cover; ch.max2nd_cover = max2nd;
-    ch.err = err;
+    ch.err = err; ch.err_site = site;
     ch.n_reserved = ch.n_sort;
     ch.rc_off = atomic_add_u32(b.rc_count, ch.n_sort);
-    if ((uint64_t)ch.rc_off + ch.n_sort > b.rccap) { ch.err = SMG_ERR_CAP; ch.n_sort = 0; }
+    if ((uint64_t)ch.rc_off + ch.n_sort > b.rccap) { ch.err = SMG_ERR_CAP; ch.err_site = __LINE__; ch.n_sort = 0; }
   }
   SMG_SYNC();
   {                                         // ranked part to the slot (S7 below, diagnostics)

@@ -98,7 +98,7 @@ SMG_HD inline bool segcand_pack(SegCandP &p, const SegCand &c, uint32_t grp, boo
   p.rs = c.rs;
   p.w1 = (span << 16) | ((c.qs & 0xffu) << 8) | (c.qe & 0xffu);
   p.w2 = (uint32_t)(uint16_t)c.shiftoffs | ((uint32_t)(uint16_t)c.shift2mm << 16);
-  p.w3 = ((uint32_t)c.srange & 0x7fffu) | ((uint32_t)((c.flag & CANDFLG_REVERSE) ? 1u : 0u) << 15) | ((uint32_t)((c.flag & CANDFLG_MMALI) ? 1u : 0u) << 16) | (hasgrp ? (1u << 17) : 0u) | ((grp & 0x3ffu) << 18);
+  p.w3 = ((uint32_t)c.srange & 0x7fffu) | ((uint32_t)((c.flag & CANDFLG_REVERSE) ? 1u : 0u) << 15) | ((uint32_t)((c.flag & CANDFLG_MMALI) ? 1u : 0u) << 16) | (hasgrp ? (1u << 17) : 0u) | ((grp & 0x3fffu) << 18);
   return span <= 0xffffu && c.qs <= 0xffu && c.qe <= 0xffu && c.srange >= 0 && !(c.flag & ~(uint8_t)(CANDFLG_REVERSE | CANDFLG_MMALI));
 }
 SMG_HD inline void segcand_unpack(SegCand &c, const SegCandP &p, uint32_t cover) {
@@ -106,7 +106,7 @@ SMG_HD inline void segcand_unpack(SegCand &c, const SegCandP &p, uint32_t cover)
   c.shiftoffs = (int16_t)(uint16_t)(p.w2 & 0xffffu); c.shift2mm = (int16_t)(uint16_t)(p.w2 >> 16);
   c.srange = (int16_t)(p.w3 & 0x7fffu); c.flag = (uint8_t)(((p.w3 >> 15) & 1u ? CANDFLG_REVERSE : 0) | ((p.w3 >> 16) & 1u ? CANDFLG_MMALI : 0)); c.pad = 0;
   c.cover = cover; c.nseg = 0; c.hregix = 0;
-  c.seqidx = (p.w3 & (1u << 17)) ? (int32_t)((p.w3 >> 18) & 0x3ffu) : -1;
+  c.seqidx = (p.w3 & (1u << 17)) ? (int32_t)((p.w3 >> 18) & 0x3fffu) : -1;
 }
 
 struct RCand {                                                      // rmap.c:111-126
@@ -128,6 +128,7 @@ struct CandHdr {                                                    // segment.c
   int32_t err;
   uint32_t nhits[2];        // collected hits per strand (diagnostic)
   uint32_t n_reserved;      // pool entries reserved for this read (= n_sort unless the pool overflowed)
+  int32_t err_site;         // source line of the limit or assertion behind `err` (diagnostic; 0: none recorded)
 };
 
 struct ReadCtl {                                                    // scalars of mapSingleRead (rmap.c:1373-1400)
@@ -155,13 +156,14 @@ struct ReadStat {
   uint64_t res_off;         // first Result of this read in the pool
   uint64_t dstr_off;
   int32_t max1;             // best first-pass score (max1scor, rmap.c:1355): < 1 means mapSingleRead returned before the traceback pass
-  int32_t pad;
+  int32_t err_site;         // source line of the limit or assertion behind `err` (diagnostic; 0: none recorded)
 };
 
 // rmapPair (rmap.c:1744-2112): one search interval of a read, [lo, hi] 0-based inclusive in sequence sx (interval.c:44-49)
 struct IvRec { int32_t sx; uint32_t lo, hi; };
 enum : int { FINE_K = 5, FINE_S = 1,              // the on-the-fly index of the rescue round (rmap.c:91-92)
              FINE_NKEYS = 1 << (2 * FINE_K), FINE_IDX_STRIDE = FINE_NKEYS + 8,
-             IV_MAX = (1 << 10) - 1 };            // intervals per read: the interval number takes the sequence field of the hit sort key (KEY_SEQBITS)
+             IV_MAX = (1 << 11) - 1 };            // intervals per read: the interval number takes the sequence field of the hit sort key and the bit above it
+                                                  // (KEY_SEQBITS + 1 = 11 bits: the wave-parallel candidate stage keeps the strands apart, so bit 63 is free there)
 
 }  // namespace smg

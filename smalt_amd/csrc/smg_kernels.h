@@ -28,6 +28,7 @@ inline size_t cand_slot_bytes(const CandGeom &g, uint32_t qmax, int s) {
   size_t b = cands_v2_hbm_bytes(qmax, s, g.hcap_strand, g.ngrp, g.candcap, true);
   return a > b ? a : b;
 }
+int launch_hits(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t W, uint32_t tab, uint32_t nwg);
 int launch_cands(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint8_t *scratch, uint32_t nslots, const CandGeom &g);
 int launch_replay(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p);
 int launch_align(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint8_t *scratch, size_t sbytes, uint32_t nslots,

@@ -132,12 +132,35 @@ int launch_fine_index(hipStream_t s, const Batch &b, const DevIndex &ix) {
   return (int)hipGetLastError();
 }
 
+// S3 ahead of the candidate stage: one wave per read strand (stage_hits, smg_cands.hpp); 4 waves per SIMD by registers,
+// the LDS block (window keys + list tables) sized by the launcher for as many
+template <int WAVES>
+__global__ void __launch_bounds__(64, WAVES) k_hits(Batch b, DevIndex ix, MapPar p, uint32_t W, uint32_t tab, uint32_t lds_bytes) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  unsigned long long ph[4] = {0, 0, 0, 0};
+  __shared__ uint32_t qslot;
+  if (ix.nseq > 0 && ix.nseq < 512) {               // first k-mer serial of every sequence: looked up per hit
+    uint32_t *sl = (uint32_t *)(lds + LDS_GUARD + lds_bytes);
+    for (int i = (int)threadIdx.x; i <= ix.nseq; i += 64) sl[i] = ix.seqlo[i];
+    ix.seqlo = sl;
+    __syncthreads();
+  }
+  HitsScratch x;
+  x.lds = lds + LDS_GUARD; x.lds_bytes = lds_bytes; x.W = W; x.tab = tab;
+  const uint32_t nitem = 2 * b.nreads;
+  for (uint32_t it = next_item(b.hits_cursor, &qslot); it < nitem; it = next_item(b.hits_cursor, &qslot)) {
+    stage_hits(b, ix, p, it >> 1, it & 1u, x, ph);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) for (int i = 0; i < 3; i++) if (ph[i]) atomicAdd(b.work + WK_PHASE0 + i, ph[i]);
+}
+
 // S3 - S7: one wave per read.  Reads the wave-parallel form covers (smg_cands.hpp) keep their
 // per-strand working set in LDS; everything else takes the sequential restatement on the HBM slot.
 // LONGK: the mapper takes reads of 256 bases and more; every read then goes through the general instance of the
 // wave-parallel form (mappers for short reads keep the lean one: fewer registers, more resident waves).
-template <bool LONGK>
-__global__ void __launch_bounds__(64, 2) k_cands(Batch b, DevIndex ix, MapPar p, uint8_t *gscratch, CandGeom g, uint32_t lds_bytes) {
+template <bool LONGK, bool SPLIT = false, int WAVES = 2>
+__global__ void __launch_bounds__(64, WAVES) k_cands(Batch b, DevIndex ix, MapPar p, uint8_t *gscratch, CandGeom g, uint32_t lds_bytes) {
   extern __shared__ __align__(16) uint8_t lds[];
   unsigned long long nhit = 0;
   unsigned long long ph[16] = {0};
@@ -160,11 +183,11 @@ __global__ void __launch_bounds__(64, 2) k_cands(Batch b, DevIndex ix, MapPar p,
     if (cands_v2_applicable(p, rix.k, rix.s, read_len(b, r))) {
       CandsV2Scratch x = cands_v2_carve(lds + LDS_GUARD, lds_bytes, base, b.qmax, rix.s, g.hcap_strand, g.ngrp, g.candcap, g.debug != 0);
       x.window = g.window; x.lds_hits = g.lds_hits; x.tab = g.tab; x.pass = g.pass;
-      nhit += stage_cands_v2<LONGK>(b, rix, p, r, x, ph);
+      nhit += stage_cands_v2<LONGK, SPLIT>(b, rix, p, r, x, ph);
     } else if (b.iv_off) {                                           // interval-restricted calls exist in the wave-parallel form only
-      if (threadIdx.x == 0) { CandHdr &ch = b.ch[r]; ch.ncand = ch.n_sort = ch.n_mincover = ch.n_reserved = 0; ch.rc_off = 0; ch.err = SMG_ERR_ASSERT; ch.max_cover = ch.max2nd_cover = 0; }
+      if (threadIdx.x == 0) { CandHdr &ch = b.ch[r]; ch.ncand = ch.n_sort = ch.n_mincover = ch.n_reserved = 0; ch.rc_off = 0; ch.err = SMG_ERR_ASSERT; ch.err_site = __LINE__; ch.max_cover = ch.max2nd_cover = 0; }
     } else if (g.pass == 1) {                                        // the sequential form waits for the full-size slots
-      if (threadIdx.x == 0) { CandHdr &ch = b.ch[r]; ch.ncand = ch.n_sort = ch.n_mincover = ch.n_reserved = 0; ch.rc_off = 0; ch.err = SMG_ERR_RETRY; }
+      if (threadIdx.x == 0) { CandHdr &ch = b.ch[r]; ch.ncand = ch.n_sort = ch.n_mincover = ch.n_reserved = 0; ch.rc_off = 0; ch.err = SMG_ERR_RETRY; ch.err_site = __LINE__; }
     } else {
       CandScratch x = cand_scratch_carve(base, b.qmax, ix.s, g.hcap, g.ngrp, g.segcap, g.candcap);
       nhit += stage_cands(b, ix, p, r, x);
@@ -1273,12 +1296,32 @@ int launch_seed(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar 
   return 0;
 }
 
+int launch_hits(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint32_t W, uint32_t tab, uint32_t nwg) {
+  if (!b.nreads || !b.hitrun) return 0;
+  const uint32_t lds_bytes = (uint32_t)((hits_lds_bytes(W, tab) + 15) & ~(size_t)15);
+  const size_t seq_bytes = (ix.nseq > 0 && ix.nseq < 512) ? (((size_t)ix.nseq + 1) * 4 + 15) & ~(size_t)15 : 0;
+  uint32_t grid = 2 * b.nreads < nwg ? 2 * b.nreads : nwg;
+  static const int waves = getenv("SMALTGPU_HITS_WAVES") ? atoi(getenv("SMALTGPU_HITS_WAVES")) : 3;      // tuning hook (3 waves per SIMD: 148 registers, no spills; 2 and 4 measured the same)
+  if (waves == 3) hipLaunchKernelGGL(k_hits<3>, dim3(grid), dim3(64), lds_bytes + LDS_GUARD + seq_bytes, s, b, ix, p, W, tab, lds_bytes);
+  else if (waves == 2) hipLaunchKernelGGL(k_hits<2>, dim3(grid), dim3(64), lds_bytes + LDS_GUARD + seq_bytes, s, b, ix, p, W, tab, lds_bytes);
+  else hipLaunchKernelGGL(k_hits<4>, dim3(grid), dim3(64), lds_bytes + LDS_GUARD + seq_bytes, s, b, ix, p, W, tab, lds_bytes);
+  SMG_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_cands(hipStream_t s, const Batch &b, const DevIndex &ix, const MapPar &p, uint8_t *scratch, uint32_t nslots, const CandGeom &g) {
   if (!b.nreads) return 0;
   uint32_t grid = b.nreads < nslots ? b.nreads : nslots;
   const uint32_t lds_bytes = (uint32_t)(((strand_work_bytes<uint16_t>(g.lds_hits) + 15) & ~(size_t)15) + (size_t)5 * g.tab * 4);
   const size_t seq_bytes = (ix.nseq > 0 && ix.nseq < 512) ? (((size_t)ix.nseq + 1) * 4 + 15) & ~(size_t)15 : 0;     // LDS copy of seqlo
   if (b.qmax > 255) hipLaunchKernelGGL(k_cands<true>, dim3(grid), dim3(64), lds_bytes + LDS_GUARD + seq_bytes, s, b, ix, p, scratch, g, lds_bytes);
+  else if (b.hitrun) {
+    // S3 ran ahead (k_hits): no per-list tables in this kernel's LDS block, and (tuning hook) three waves per SIMD
+    static const int waves3 = getenv("SMALTGPU_CANDS_WAVES") && atoi(getenv("SMALTGPU_CANDS_WAVES")) == 3;
+    const uint32_t lb = (uint32_t)((strand_work_bytes<uint16_t>(g.lds_hits) + 15) & ~(size_t)15);
+    if (waves3) hipLaunchKernelGGL((k_cands<false, true, 3>), dim3(grid), dim3(64), lb + LDS_GUARD + seq_bytes, s, b, ix, p, scratch, g, lb);
+    else hipLaunchKernelGGL((k_cands<false, true, 2>), dim3(grid), dim3(64), lb + LDS_GUARD + seq_bytes, s, b, ix, p, scratch, g, lb);
+  }
   else hipLaunchKernelGGL(k_cands<false>, dim3(grid), dim3(64), lds_bytes + LDS_GUARD + seq_bytes, s, b, ix, p, scratch, g, lds_bytes);
   SMG_LAUNCH_CHECK();
   return 0;

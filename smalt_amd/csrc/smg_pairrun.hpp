@@ -74,7 +74,7 @@ struct PairBlock {
       for (uint32_t i = lo; i < hi; i++) {
         const uint32_t id = rd.ids[i], w = id & 1, pr = id >> 1;
         const smaltgpu_readstat &st = o.stat[i];
-        if (st.errcode) { snprintf(msg, sizeof(msg), "pair %u, mate %u: the mapping call failed on the device (code %d)", pr, w + 1, st.errcode); if (bad[(size_t)t].empty()) bad[(size_t)t] = msg; continue; }
+        if (st.errcode) { snprintf(msg, sizeof(msg), "pair %u, mate %u, round %d: the mapping call failed on the device (code %d, site %d)", pr, w + 1, (int)rd.kind, st.errcode, st.errsite); if (bad[(size_t)t].empty()) bad[(size_t)t] = msg; continue; }
         std::vector<uint8_t> &rest = packed[id];
         tb.unpack(rest.data(), rest.size());
         tb.n_ali_done = st.n_ali_done; tb.n_ali_tot = st.n_ali_tot; tb.n_hits_used = st.n_hits_used; tb.n_hits_tot = st.n_hits_tot;     // rmap.c:1337

@@ -15,6 +15,12 @@
 
 namespace smg {
 
+// S3 ahead of the candidate stage (k_hits): the sorted hit keys of one read strand in the batch-wide pool
+struct HitRun { unsigned long long off; uint32_t n; uint32_t mode; };
+enum : uint32_t { HITRUN_NONE = 0,      // the candidate stage gathers and sorts this strand itself
+                  HITRUN_SORTED = 1,    // hitpool[off .. off + n) holds the strand's keys in ascending order
+                  HITRUN_OVERFLOW = 2 };// the pool was full: the read takes SMG_ERR_CAP (re-mapped in a smaller batch)
+
 struct Batch {                          // one block of reads resident in HBM
   uint32_t nreads, qmax;                // qmax: stride of the per-read-strand arrays (>= longest read + 1)
   const uint8_t *codes;                 // 3-bit codes of all reads, forward orientation, concatenated
@@ -48,6 +54,10 @@ struct Batch {                          // one block of reads resident in HBM
   const int32_t *prevmax;               // [2 * nreads] running score maxima of the ResultSet the call appends to (rmap.c:881-885)
   uint32_t *fine_idx, *fine_pos;        // on-the-fly k=5 s=1 index of each read over its intervals (rmap.c:495-517): idx[r][FINE_IDX_STRIDE], pos
   const uint32_t *fine_off;             // [nreads + 1] first position of read r in fine_pos
+  // ---- S3 split off the candidate stage (k_hits): null when the mapper keeps S3 inside k_cands ----
+  HitRun *hitrun;                       // [2 * nreads]
+  uint64_t *hitpool; uint64_t hitpool_cap; unsigned long long *hit_count;    // bump-allocated sorted keys
+  uint32_t *hits_cursor;                // work-queue cursor of k_hits
 };
 
 // the index a read is seeded against: the mapper's, or the read's own on-the-fly index
@@ -403,7 +413,7 @@ SMG_HD inline uint32_t stage_cands(const Batch &b, const DevIndex &ix, const Map
   const uint32_t ngrp = x.ngrp;
 
   if (qlen < (uint32_t)k) {
-    SMG_LANE0 { ch.ncand = ch.n_sort = ch.n_mincover = ch.max_cover = ch.max2nd_cover = 0; ch.cover_deficit[0] = ch.cover_deficit[1] = 0; ch.rc_off = 0; ch.err = 0; ch.nhits[0] = ch.nhits[1] = 0; ch.n_reserved = 0; }
+    SMG_LANE0 { ch.ncand = ch.n_sort = ch.n_mincover = ch.max_cover = ch.max2nd_cover = 0; ch.cover_deficit[0] = ch.cover_deficit[1] = 0; ch.rc_off = 0; ch.err = 0; ch.err_site = 0; ch.nhits[0] = ch.nhits[1] = 0; ch.n_reserved = 0; }
     return 0;
   }
   // calcMinKtup (rmap.c:240-247) and the coverage threshold of mapSingleRead (:1283-1289)
@@ -594,10 +604,10 @@ SMG_HD inline uint32_t stage_cands(const Batch &b, const DevIndex &ix, const Map
     ch.ncand = cs.ncand; ch.n_sort = err ? 0 : n_sort; ch.n_mincover = n_mincover;
     ch.max_cover = cs.max_cover; ch.max2nd_cover = cs.max2nd_cover;
     ch.cover_deficit[0] = cdf[0]; ch.cover_deficit[1] = cdf[1];
-    ch.err = err;
+    ch.err = err; ch.err_site = err ? __LINE__ : 0;
     ch.n_reserved = ch.n_sort;
     ch.rc_off = atomic_add_u32(b.rc_count, ch.n_sort);
-    if ((uint64_t)ch.rc_off + ch.n_sort > b.rccap) { ch.err = SMG_ERR_CAP; ch.n_sort = 0; }
+    if ((uint64_t)ch.rc_off + ch.n_sort > b.rccap) { ch.err = SMG_ERR_CAP; ch.err_site = __LINE__; ch.n_sort = 0; }
   }
   SMG_SYNC();
   // ---- S7: windows and bands of the ranked candidates ----
@@ -1283,7 +1293,7 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
   const ReadCtl ctl = b.ctl[r];
   ReadStat &st = b.stat[r];
   const RCand *rc = b.rcpool + ch.rc_off;
-  enum { S_MINSW = 0, S_SWMAX = 1, S_SW2ND = 2, S_NRES = 3, S_NDSTR = 4, S_ERR = 5, S_SP = 6, S_NALI = 7 };
+  enum { S_MINSW = 0, S_SWMAX = 1, S_SW2ND = 2, S_NRES = 3, S_NDSTR = 4, S_ERR = 5, S_SP = 6, S_NALI = 7, S_SITE = 8 };
   int8_t M[64];
   score_matrix(M, p.match, p.mismatch);
   const int gi = -p.gap_init, ge = -p.gap_ext;
@@ -1293,7 +1303,7 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
   SMG_LANE0 {
     // a call that appends to a ResultSet continues that set's running score maxima (rmap.c:881-885 reads them)
     x.state[S_MINSW] = ctl.min_swatscor; x.state[S_SWMAX] = b.prevmax ? b.prevmax[2 * r] : 0; x.state[S_SW2ND] = b.prevmax ? b.prevmax[2 * r + 1] : 0;
-    x.state[S_NRES] = 0; x.state[S_NDSTR] = 0; x.state[S_ERR] = ch.err; x.state[S_SP] = 0; x.state[S_NALI] = 0;
+    x.state[S_NRES] = 0; x.state[S_NDSTR] = 0; x.state[S_ERR] = ch.err; x.state[S_SP] = 0; x.state[S_NALI] = 0; x.state[S_SITE] = ch.err ? ch.err_site : 0;
   }
   // both orientations of the read next to the DP rows (codes are read once per column)
   SMG_PAR_CHUNKS(base, qlen) {
@@ -1321,7 +1331,7 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
     if (x.state[S_ERR]) break;
     if (c.swscor < x.state[S_MINSW]) continue;            // rmap.c:826-828 (all ranked candidates are scored)
     const uint32_t wlen = (uint32_t)(c.re - c.rs + 1);
-    if (wlen > x.wincap || c.qs > c.qe || c.qe >= qlen || (c.flags & RCF_ERR)) { SMG_SYNC(); SMG_LANE0 { x.state[S_ERR] = (wlen > x.wincap) ? SMG_ERR_CAP : SMG_ERR_ASSERT; } SMG_SYNC(); break; }
+    if (wlen > x.wincap || c.qs > c.qe || c.qe >= qlen || (c.flags & RCF_ERR)) { SMG_SYNC(); SMG_LANE0 { x.state[S_ERR] = (wlen > x.wincap) ? SMG_ERR_CAP : SMG_ERR_ASSERT; x.state[S_SITE] = __LINE__; } SMG_SYNC(); break; }
     const uint64_t gbase = (c.sqidx < 0 ? 0ull : ix.sop[c.sqidx]) + c.rs;
     uint8_t *const win = wlen <= x.win_lds_cap ? x.win_lds : x.win;
     uint8_t *const dtmp = wlen <= x.win_lds_cap ? x.dtmp_lds : x.dtmp;
@@ -1351,7 +1361,7 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
     SMG_LANE0 {
       x.state[S_MINSW] = min_swatscor;
       x.state[S_NALI] = 0;
-      if (err0) { x.state[S_ERR] = err0; x.state[S_SP] = 0; }
+      if (err0) { x.state[S_ERR] = err0; x.state[S_SITE] = __LINE__; x.state[S_SP] = 0; }
       else { x.ivstack[0] = 0; x.ivstack[1] = (int)wlen - 1; x.state[S_SP] = 1; }
     }
     SMG_SYNC();
@@ -1362,11 +1372,11 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
       if (sp <= 0 || x.state[S_ERR]) break;
       const int s_left = x.ivstack[2 * (sp - 1)], s_right = x.ivstack[2 * (sp - 1) + 1];
       Band band;
-      int nerr = 0;
+      int nerr = 0, nsite = 0;
       bool skip = false;
-      if (minscorlen < 2) nerr = SMG_ERR_ASSERT;
+      if (minscorlen < 2) { nerr = SMG_ERR_ASSERT; nsite = __LINE__; }
       else if (band_init(band, band_l, band_r, (int)c.qs, (int)c.qe, (int)qlen, s_left, s_right, (int)wlen)) skip = true;
-      else if (band.s_left >= band.s_len || band.band_width < 0) nerr = SMG_ERR_ASSERT;
+      else if (band.s_left >= band.s_len || band.band_width < 0) { nerr = SMG_ERR_ASSERT; nsite = __LINE__; }
       uint64_t dneed = 0;
       uint8_t *dirm = x.dir;
       if (!nerr && !skip) {
@@ -1392,7 +1402,7 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
         if (sg.nstrip > 0 && strip_words(sg, sg.nstrip) * 4 + 16 <= x.dircap) tW = -1;
       }
 #endif
-      if (!nerr && !skip && !tW && dirm == x.dir && dneed > x.dircap) nerr = x.pass == 1 ? SMG_ERR_RETRY : SMG_ERR_CAP;
+      if (!nerr && !skip && !tW && dirm == x.dir && dneed > x.dircap) { nerr = x.pass == 1 ? SMG_ERR_RETRY : SMG_ERR_CAP; nsite = __LINE__; }
       tq0 = phase_clock();
       if (!nerr && !skip) { aph[3]++; aph[7] += (unsigned long long)band.band_width; aph[5] += (unsigned long long)(band.s_len - band.s_left) + (unsigned long long)(band.q_len - band.q_left); }
       if (!nerr && !skip) {
@@ -1455,6 +1465,7 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
 #endif
       SMG_LANE0 {
         int nsp = sp - 1, err = nerr;
+        if (nerr) x.state[S_SITE] = nsite;
         if (!err && !skip && max_scor >= minscore) {
           int qs = tb_qs, rs = tb_rs;
           #if defined(__HIP_DEVICE_COMPILE__)
@@ -1462,25 +1473,25 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
 #else
           const int dn = traceback_scalar(dtmp, dtmpcap, &qs, &rs, band, dirm, max_i, max_j, max_scor, q, win, M, gi, ge, tW);
 #endif
-          if (dn < 0) err = (dn == -2) ? SMG_ERR_CAP : SMG_ERR_ASSERT;
+          if (dn < 0) { err = (dn == -2) ? SMG_ERR_CAP : SMG_ERR_ASSERT; x.state[S_SITE] = __LINE__; }
           const int qe = max_j, re = max_i;
           if (!err && !(qs + minscorlen > qe + 1)) {
             // addALIMETAtoRsltSet (alignment.c:1277): forward DiffStr appended to the scratch string pool
             const int nali = x.state[S_NALI];
-            if ((uint32_t)(res_first + nali) >= x.rescap || (uint32_t)(x.state[S_NDSTR] + dn + 2) > x.dstrcap) err = x.pass == 1 ? SMG_ERR_RETRY : SMG_ERR_CAP;   // the second pass has large result slots
+            if ((uint32_t)(res_first + nali) >= x.rescap || (uint32_t)(x.state[S_NDSTR] + dn + 2) > x.dstrcap) { err = x.pass == 1 ? SMG_ERR_RETRY : SMG_ERR_CAP; x.state[S_SITE] = __LINE__; }   // the second pass has large result slots
             else {
               Result &a = x.res[res_first + nali];
               a.swatscor = max_scor; a.q_start = (uint32_t)qs; a.q_end = (uint32_t)qe; a.s_start = (uint64_t)rs; a.s_end = (uint64_t)re;
               a.stroffs = (uint32_t)x.state[S_NDSTR];
               const int fl = diffstr_reverse(x.dstr + a.stroffs, dtmp, dn);
-              if (fl < 0) err = SMG_ERR_ASSERT;
+              if (fl < 0) { err = SMG_ERR_ASSERT; x.state[S_SITE] = __LINE__; }
               else {
                 a.strlen = (uint32_t)fl;
                 x.state[S_NDSTR] += fl;
                 x.state[S_NALI] = nali + 1;
                 // right interval is pushed first so that the left one is aligned first (alignment.c:1389-1431)
-                if (s_right > re + minscorlen) { if (nsp >= 62) err = SMG_ERR_CAP; else { x.ivstack[2 * nsp] = re + 1; x.ivstack[2 * nsp + 1] = s_right; nsp++; } }
-                if (!err && s_left + minscorlen < rs) { if (nsp >= 62) err = SMG_ERR_CAP; else { x.ivstack[2 * nsp] = s_left; x.ivstack[2 * nsp + 1] = rs - 1; nsp++; } }
+                if (s_right > re + minscorlen) { if (nsp >= 62) { err = SMG_ERR_CAP; x.state[S_SITE] = __LINE__; } else { x.ivstack[2 * nsp] = re + 1; x.ivstack[2 * nsp + 1] = s_right; nsp++; } }
+                if (!err && s_left + minscorlen < rs) { if (nsp >= 62) { err = SMG_ERR_CAP; x.state[S_SITE] = __LINE__; } else { x.ivstack[2 * nsp] = s_left; x.ivstack[2 * nsp + 1] = rs - 1; nsp++; } }
               }
             }
           }
@@ -1545,11 +1556,11 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
     st.nhit = b.hi[2 * r].nhit_rank + b.hi[2 * r + 1].nhit_rank;
     st.nhit_tot = b.hi[2 * r].nhit_tot + b.hi[2 * r + 1].nhit_tot;
     st.err = x.state[S_ERR];
-    st.max1 = ctl.max1; st.pad = 0;
+    st.max1 = ctl.max1; st.err_site = st.err ? x.state[S_SITE] : 0;
     st.nres = st.err ? 0 : nres;
     st.res_off = atomic_add_u64(b.res_count, st.nres);
     st.dstr_off = atomic_add_u64(b.dstr_count, st.err ? 0 : nd);
-    if (st.res_off + st.nres > b.rescap || st.dstr_off + nd > b.dstrcap) { st.err = SMG_ERR_CAP; st.nres = 0; }
+    if (st.res_off + st.nres > b.rescap || st.dstr_off + nd > b.dstrcap) { st.err = SMG_ERR_CAP; st.err_site = __LINE__; st.nres = 0; }
     if (st.err && st.err != SMG_ERR_RETRY) atomic_add_u32((uint32_t *)b.err_flag, 1u);
     if (st.err == SMG_ERR_RETRY && b.align_retry) b.align_retry[atomic_add_u32(b.align_retry_n, 1u)] = r;
     x.state[S_NRES] = (int32_t)st.nres; x.state[S_NDSTR] = st.err ? 0 : (int32_t)nd;

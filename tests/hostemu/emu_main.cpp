@@ -91,8 +91,8 @@ int main(int argc, char **argv) {
   std::vector<ReadStat> stat(n);
   const uint32_t rccap = n * 2048u + 16;
   std::vector<RCand> rcpool(rccap);
-  std::vector<Result> respool((size_t)n * 64 + 16);
-  std::vector<uint8_t> dstrpool((size_t)n * 4096 + 16);
+  std::vector<Result> respool((size_t)n * 4096 + 16);
+  std::vector<uint8_t> dstrpool((size_t)n * 4096 * 64 + 16);
   uint32_t rc_count = 0; unsigned long long res_count = 0, dstr_count = 0; int32_t err_flag = 0;
   Batch b;
   memset((void *)&b, 0, sizeof(b));        // no retry list, no pair context
@@ -114,12 +114,21 @@ int main(int argc, char **argv) {
   uint8_t *cscr_mem = (uint8_t *)malloc(cbytes * (size_t)n);      // one slot per read: state kept for the dump
   struct { uint8_t *p; uint8_t *data() { return p; } } cscr = {cscr_mem};
   const uint32_t wincap = 4 * qmax + 4096; const uint64_t dircap = (uint64_t)wincap * (qmax + 64);
-  std::vector<uint8_t> ascr(align_scratch_bytes(qmax, wincap, dircap, 256, 1u << 16));
+  std::vector<uint8_t> ascr(align_scratch_bytes(qmax, wincap, dircap, 4096, 4096 * (qmax / 4 + 48)));
   std::vector<int> Hrow(qmax + 2), Erow(qmax + 2);
   int8_t M[64];
   score_matrix(M, p.match, p.mismatch);
 
-  unsigned long long nwin_strands = 0, nhbm_strands = 0;
+  // S3 as a stage of its own (k_hits on the device): EMU_SPLIT=1 runs stage_hits ahead of the candidate stage, which then
+  // streams the sorted keys from the pool (HITRUN_SORTED); EMU_HITS_WINDOW sets the keys per window of stage_hits
+  const bool split = getenv("EMU_SPLIT") && atoi(getenv("EMU_SPLIT")) != 0;
+  const uint32_t hitsW = getenv("EMU_HITS_WINDOW") ? (uint32_t)atoi(getenv("EMU_HITS_WINDOW")) : 512u;
+  std::vector<uint64_t> hitpool(split ? (size_t)n * 2 * hcap_strand / 8 + (1u << 20) : 1);
+  std::vector<HitRun> hitrun((size_t)2 * n + 1);
+  unsigned long long hit_count = 0;
+  std::vector<uint8_t> hitlds(hits_lds_bytes(hitsW, CANDS_TAB) + 64);
+  if (split) { b.hitpool = hitpool.data(); b.hitpool_cap = hitpool.size(); b.hitrun = hitrun.data(); b.hit_count = &hit_count; }
+  unsigned long long nwin_strands = 0, nhbm_strands = 0, nsplit_strands = 0;
   for (uint32_t r = 0; r < n; r++) {
     const uint32_t len = (uint32_t)(off[r + 1] - off[r]);
     if (mincover < 1.01) { p.min_cover = (uint32_t)(mincover * len); if (p.min_cover > len) p.min_cover = len; }
@@ -131,7 +140,15 @@ int main(int argc, char **argv) {
       CandsV2Scratch c2 = cands_v2_carve(ldsmem.data(), ldsmem.size(), cscr.data() + cbytes * r, qmax, ix.s, hcap_strand, ngrp, candcap, true);
       c2.window = window;
       unsigned long long ph[16] = {0};
-      if (len > 255) stage_cands_v2<true>(b, ix, p, r, c2, ph);
+      if (split && len <= 255) {
+        HitsScratch hx;
+        hx.lds = hitlds.data(); hx.lds_bytes = hitlds.size(); hx.W = hitsW; hx.tab = CANDS_TAB;
+        unsigned long long hph[4] = {0, 0, 0, 0};
+        stage_hits(b, ix, p, r, 0, hx, hph);
+        stage_hits(b, ix, p, r, 1, hx, hph);
+        nsplit_strands += (hitrun[2 * r].mode == HITRUN_SORTED) + (hitrun[2 * r + 1].mode == HITRUN_SORTED);
+        stage_cands_v2<false, true>(b, ix, p, r, c2, ph);
+      } else if (len > 255) stage_cands_v2<true>(b, ix, p, r, c2, ph);
       else stage_cands_v2<false>(b, ix, p, r, c2, ph);
       nwin_strands += ph[11]; nhbm_strands += ph[14];
     } else {
@@ -155,7 +172,7 @@ int main(int argc, char **argv) {
       rc.flags |= RCF_SCORED;
     }
     stage_replay(b, ix, p, r);
-    AlignScratch ax = align_scratch_carve(ascr.data(), qmax, wincap, dircap, 256, 1u << 16);
+    AlignScratch ax = align_scratch_carve(ascr.data(), qmax, wincap, dircap, 4096, 4096 * (qmax / 4 + 48));
     stage_align(b, ix, p, r, ax);
   }
   std::string out;
@@ -177,7 +194,10 @@ int main(int argc, char **argv) {
     dump_read(out, v, r, names[r].c_str(), with_hl != 0);
     fwrite(out.data(), 1, out.size(), stdout);
   }
-  if (err_flag) fprintf(stderr, "emu: %d reads with errors\n", err_flag);
-  if (getenv("EMU_STATS")) fprintf(stderr, "windowed strands %llu, HBM strands %llu\n", nwin_strands, nhbm_strands);
+  if (err_flag) {
+    fprintf(stderr, "emu: %d reads with errors\n", err_flag);
+    for (uint32_t r = 0; r < n; r++) if (stat[r].err || ch[r].err) fprintf(stderr, "emu: read %u: candidate stage %d, alignment stage %d\n", r, ch[r].err, stat[r].err);
+  }
+  if (getenv("EMU_STATS")) fprintf(stderr, "windowed strands %llu, HBM strands %llu, strands sorted ahead %llu\n", nwin_strands, nhbm_strands, nsplit_strands);
   return 0;
 }

@@ -207,3 +207,62 @@ def test_pairs_with_32_workers_and_blocks_of_4096(tmp_path):
     assert len(a) == len(b) and len(a) > 250_000
     diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
     assert not diff, (len(diff), diff[:3])
+
+
+def satellite_pairs(tmp):
+    """Reference with a satellite-like repeat and read pairs on it: (index prefix, [fastq 1, fastq 2], pairs)."""
+    rng = np.random.default_rng(99)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    rnd = lambda n: acgt[rng.integers(0, 4, size=n)].tobytes()
+    ua, ub = rnd(150), rnd(150)
+    unit = ua + rnd(80) + ub                                   # read 1 lies in ua, read 2 in ub, 230 bases downstream
+    chr1 = b"".join(rnd(int(rng.integers(650, 800))) + unit for _ in range(620)) + rnd(500)
+    chr2 = b"".join(rnd(int(rng.integers(300, 400))) + ub for _ in range(700)) + rnd(500)      # ub is the more frequent one: ua's mate is mapped first
+    chr3 = rnd(200_000)
+    fa = os.path.join(tmp, "ref.fa")
+    with open(fa, "wb") as f:
+        for i, c in enumerate((chr1, chr2, chr3)):
+            f.write(b">chr%d\n" % (i + 1))
+            for o in range(0, len(c), 70):
+                f.write(c[o:o + 70] + b"\n")
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    pairs = []
+    for i in range(12):                                        # repeat pairs, some with a substitution
+        a, b = bytearray(ua[20:120]), bytearray(ub[25:125][::-1].translate(comp))
+        if i % 3 == 1:
+            a[40] = ord("A") if a[40] != ord("A") else ord("C")
+        pairs.append((bytes(a), bytes(b)))
+    for i in range(60):                                        # ordinary pairs from the unique sequence
+        p = int(rng.integers(0, len(chr3) - 400))
+        pairs.append((chr3[p:p + 100], chr3[p + 200:p + 300][::-1].translate(comp)))
+    fqs = [os.path.join(tmp, "r_%d.fq" % w) for w in (1, 2)]
+    for w in (0, 1):
+        with open(fqs[w], "wb") as f:
+            for i, pr in enumerate(pairs):
+                f.write(b"@p%d/%d\n" % (i, w + 1) + pr[w] + b"\n+\n" + b"I" * len(pr[w]) + b"\n")
+    pre = os.path.join(tmp, "idx")
+    subprocess.run([SMALT, "index", "-k", "13", "-s", "6", pre, fa], check=True, capture_output=True)
+    return pre, fqs, pairs
+
+
+@pytest.mark.skipif(not (os.path.exists(SMALT) and os.path.exists(SMALT_GPU)), reason="reference binaries not built (make -C oracle ref ref_gpu)")
+def test_pairs_with_more_than_1023_search_intervals(tmp_path):
+    """A first mate with 620 equally good alignments (a satellite-like repeat) gives its mate more than 1023 search
+    intervals in the restricted round (two per alignment, rmap.c:354-436; the reference has no limit, interval.c:98-121).
+    The interval number has 11 bits in the hit sort key of a restricted call: the pairs map, and both programs print what the
+    unmodified `smalt map` prints."""
+    tmp = str(tmp_path)
+    pre, fqs, pairs = satellite_pairs(tmp)
+    out_ref, out_gpu = os.path.join(tmp, "ref.out"), os.path.join(tmp, "gpu.out")
+    opts = ["-f", "cigar", "-i", "500", "-r", "-1"]
+    subprocess.run([SMALT, "map"] + opts + ["-o", out_ref, pre] + fqs, check=True, capture_output=True)
+    a = open(out_ref).read().split("\n")
+    assert len(a) == 2 * len(pairs) + 1
+    prog = os.path.join(ROOT, "smalt_amd", "smaltgpu-map")
+    env = dict(os.environ, SMALTGPU_INDEX_PREFIX=pre)
+    for cmd, e in (([prog] + opts + ["-o", out_gpu, pre] + fqs, os.environ), ([SMALT_GPU, "map"] + opts + ["-o", out_gpu, pre] + fqs, env)):
+        r = subprocess.run(cmd, capture_output=True, env=e)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        b = open(out_gpu).read().split("\n")
+        diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
+        assert len(a) == len(b) and not diff, (cmd[0], len(diff), diff[:3])

@@ -8,6 +8,7 @@ size-independent properties (the oracle cannot finish this size in seconds):
                         order -- repeat filter, seed budget, the strand-[0] cover deficit of segment.c:1676)
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -138,3 +139,26 @@ def test_strand_symmetry(world):
             same += 1
     assert same_score >= 0.97 * sub.shape[0], same_score
     assert same >= 0.95 * sub.shape[0], same                      # ties between repeat copies may resolve differently
+
+
+def test_bench_two_ranks_on_one_device():
+    """`python bench.py --gpus 2` on the one-GPU box: the program starts its two ranks itself, they share the device (so the
+    collectives run over gloo; with a GPU per rank the backend is nccl = RCCL), rank 0 builds the index and broadcasts the image,
+    the reads of the job are dealt in guided pieces from one cursor, and the reductions give one JSON line.  Small genome so
+    that the two processes' images fit beside each other."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--reads", "131072", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                        "--no-host-buffers", "--nchr", "4", "--chr-mbp", "25"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["job_reads_per_step"] == 262144
+    lo, hi = line["config"]["reads_taken_min_max_per_rank"]
+    assert lo > 0 and abs(lo + hi - 262144) < 1            # the two ranks' pieces add up to the job
+    assert line["config"]["mapped_fraction"] > 0.999
+    assert line["config"]["index_broadcast_ms"] > 0 and set(line["config"]["index_broadcast_by_array"]) >= {"idx", "pos", "packed"}

@@ -14,17 +14,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="session")
 def emu_bin():
     out = os.path.join(ROOT, "tests", "hostemu", "emu")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-o", out, os.path.join(ROOT, "tests", "hostemu", "emu_main.cpp")], check=True)
+    tmp = "%s.%d" % (out, os.getpid())             # pytest-xdist workers build at the same time: never run a half-written file
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", tmp, os.path.join(ROOT, "tests", "hostemu", "emu_main.cpp")], check=True)
+    os.replace(tmp, out)
     return out
 
 
-@pytest.mark.parametrize("window", [0, 160], ids=["w-default", "w160"])
+@pytest.mark.parametrize("window,split", [(0, 0), (160, 0), (0, 1), (160, 1)], ids=["w-default", "w160", "split", "split-w160"])
 @pytest.mark.parametrize("entry", gu.MANIFEST, ids=[e["tag"] for e in gu.MANIFEST])
-def test_stage_logic_matches_reference_dump(entry, window, emu_bin, oracle_built, tmp_path):
+def test_stage_logic_matches_reference_dump(entry, window, split, emu_bin, oracle_built, tmp_path):
     """window=160: strands with more hits stream through the candidate stage in windows of ascending
-    diagonal (and fall back to the HBM working set when a hit region exceeds the window)."""
+    diagonal (and fall back to the HBM working set when a hit region exceeds the window).
+    split: S3 as a stage of its own (stage_hits = kernel k_hits: gather + sort into the batch-wide pool, here with windows of
+    320 keys), the candidate stage streaming the sorted keys in chunks of `window` (or the LDS working set)."""
     fx = gu.unpack(entry, tmp_path)
-    env = dict(os.environ, EMU_WINDOW=str(window))
+    env = dict(os.environ, EMU_WINDOW=str(window), EMU_SPLIT=str(split), EMU_HITS_WINDOW="400")
     out = subprocess.run([emu_bin] + entry["opts"].split() + [fx["prefix"], fx["fq"]], check=True, capture_output=True, text=True, env=env).stdout
     a, b = out.split("\n"), fx["expected"].split("\n")
     for i, (x, y) in enumerate(zip(a, b)):

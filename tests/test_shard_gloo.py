@@ -130,6 +130,14 @@ def test_bench_starts_its_own_ranks_and_deals_sub_batches():
         assert sorted(a + b) == list(range(23)) and a and b
         if extra:
             assert a == list(range(12)) and b == list(range(12, 23))
+        # guided dealing (the N > 1 job): the pieces of both ranks tile the job's reads exactly once, and they get smaller
+        # towards the end
+        ga, gb = line["guided"]
+        allp = sorted([tuple(x) for x in ga + gb])
+        assert allp[0][0] == 0 and sum(c for _, c in allp) == 1000003 and ga and gb
+        assert all(allp[i][0] + allp[i][1] == allp[i + 1][0] for i in range(len(allp) - 1))
+        if not extra:
+            assert max(c for _, c in allp) == 65536 and allp[-1][1] <= 8192
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py")], env=env, capture_output=True, text=True, timeout=300)
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["dealt"] == [list(range(23))]
