@@ -278,7 +278,7 @@ def paired_main(args):
     L = api.lib()
     handles = [C.c_void_p(L.smaltgpu_pairs_create()) for _ in range(nmappers)]
     L.smaltgpu_pairs_host_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
-    host_ms = np.zeros(7)
+    host_ms = np.zeros(8)
     nblk = (npairs + sub - 1) // sub
     kms = np.zeros((5, 16))
     work = np.zeros((5, 32), dtype=np.uint64)
@@ -329,8 +329,8 @@ def paired_main(args):
                         work[:] += np.array(wk, dtype=np.uint64).reshape(5, 32)
                         calls[:] += np.array(cl, dtype=np.uint64)
                         round_ms[:] += np.array(rm)
-                        hm = (C.c_double * 7)()
-                        L.smaltgpu_pairs_host_times(handle, hm, 7)
+                        hm = (C.c_double * 8)()
+                        L.smaltgpu_pairs_host_times(handle, hm, 8)
                         host_ms[:] += np.array(hm)
         th = [threading.Thread(target=drive, args=(i,)) for i in range(nstream)]
         for t in th:
@@ -383,7 +383,7 @@ def paired_main(args):
         "gpu_busy_fraction": gpu_ms / (dt * 1e3 / args.steps),
         "round_wall_ms_per_step": {rname[r]: float(round_ms[r]) / args.steps for r in range(4)},
         "host_ms_per_step": dict(zip(["behind A: post-call pass + search intervals", "behind B: post-call pass", "proper-pair probe", "behind C: post-call pass", "plan of D",
-                                      "behind D: post-call pass", "hit totals (wall, incl. the device)"], [float(x) / args.steps for x in host_ms])),
+                                      "behind D: post-call pass", "hit totals (wall, incl. the device)", "whole calls (wall)"], [float(x) / args.steps for x in host_ms])),
     }
     # the same job on two mappers (HIP streams) taking the blocks in turn: the host work between the rounds of one block runs
     # while the device works on the other block.  Not `value`: kernels of two blocks share the device, so their event durations

@@ -172,9 +172,19 @@ typedef struct smaltgpu_callctx {
                                   * (rmap.c:881-885); stat[].swatscor_max / _2ndmax return the pair after the call */
   int32_t fine_index;            /* != 0: seed against the on-the-fly index of each read's intervals (needs iv_off);
                                   * hit info is collected in the long form (initRMAPINFO, rmap.c:2024) */
+  const uint32_t *hitlist_len;   /* per read, or NULL: length of the longest read that the reference's hit list has held up to and
+                                  * including this call.  The list's capacity only grows (initHitList, hashhit.c:1280-1282) and decides
+                                  * where the allocation-boundary protocol sets in (hashhit.c:1497), so a serial `smalt map` over reads
+                                  * of different lengths depends on their order; NULL = every read as if it were the first
+                                  * (smaltgpu_mapper_set_history keeps this array for the caller) */
 } smaltgpu_callctx;
 int smaltgpu_map_batch_ctx(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
                            const smaltgpu_params *par, const smaltgpu_callctx *ctx, smaltgpu_batch_out *out);
+/* Serial-order mode of a mapper (off by default): smaltgpu_map_batch / smaltgpu_map_batch_ctx calls without ctx->hitlist_len take the
+ * reads of consecutive calls as ONE serial run of `smalt map -n 0` -- the hit-list capacity of a read is that of the longest read
+ * of length >= k seen so far, carried from call to call (rmap.c:1123 creates the list once per thread; reads shorter than k return
+ * before they reach it, rmap.c:1274).  on = 0 switches the mode off, any call with on != 0 starts a new run. */
+int smaltgpu_mapper_set_history(smaltgpu_mapper *m, int on);
 /* calcTotalNumberOfHits (rmap.c:1076) of every read: k-mer hits over both strands counting only words with at most
  * par->ktuple_maxhit hits -- what rmapPair compares to decide which mate is mapped first (rmap.c:1866-1870). */
 int smaltgpu_hit_totals(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
@@ -235,7 +245,7 @@ int smaltgpu_pairs_info(const smaltgpu_pairs *p, uint32_t *npairs, const smaltgp
  * work counters (work[5][32]) summed over the block's batches; either may be NULL.  For bench.py's roofline object. */
 int smaltgpu_pairs_timers(const smaltgpu_pairs *p, double *kernel_ms, uint64_t *work);
 /* host wall time [ms] of the work between the rounds of the block: passes behind round A (with the search intervals), behind B, the
- * proper-pair probe, behind C, the plan of round D, behind D, and the hit-totals batches; returns the number of entries (7) */
+ * proper-pair probe, behind C, the plan of round D, behind D, the hit-totals batches, and the whole call; returns the number of entries (8) */
 int smaltgpu_pairs_host_times(const smaltgpu_pairs *p, double *ms, int n);
 /* the index a mapper was created on, and the batch it was sized for (smaltgpu_map_pairs takes blocks of up to max_batch_reads pairs) */
 const smaltgpu_index *smaltgpu_mapper_index(const smaltgpu_mapper *m);

@@ -56,7 +56,7 @@ class Interval(C.Structure):
 
 class CallCtx(C.Structure):
     _fields_ = [("iv_off", C.POINTER(C.c_uint64)), ("iv", C.POINTER(Interval)), ("min_swatscor", C.POINTER(C.c_int32)),
-                ("prev_max", C.POINTER(C.c_int32)), ("fine_index", C.c_int32)]
+                ("prev_max", C.POINTER(C.c_int32)), ("fine_index", C.c_int32), ("hitlist_len", C.POINTER(C.c_uint32))]
 
 
 class PostResult(C.Structure):
@@ -283,6 +283,11 @@ class Mapper:
         if self.h:
             lib().smaltgpu_mapper_free(self.h)
             self.h = None
+
+    def set_history(self, on: bool = True):
+        """Serial-order mode (smaltgpu_mapper_set_history): consecutive map_batch calls form one serial run of `smalt map -n 0`
+        as far as the hit-list capacity goes; calling it again starts a new run."""
+        _check(lib().smaltgpu_mapper_set_history(self.h, 1 if on else 0))
 
     def set_debug(self, level: int):
         _check(lib().smaltgpu_set_debug(self.h, level))

@@ -361,7 +361,10 @@ struct smaltgpu_mapper {
     int ensure(size_t n) { if (n <= cap) return 0; if (p) (void)hipFree(p); p = nullptr; cap = 0; size_t c = n + n / 2 + 256; if (hipMalloc(&p, c) != hipSuccess) return -1; cap = c; return 0; }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
   };
-  DevBuf cx_ivoff, cx_iv, cx_minsw, cx_prevmax, cx_fineidx, cx_finepos, cx_fineoff;
+  DevBuf cx_ivoff, cx_iv, cx_minsw, cx_prevmax, cx_fineidx, cx_finepos, cx_fineoff, cx_alloclen;
+  bool history = false;                      // serial-order mode (smaltgpu_mapper_set_history)
+  uint32_t hist_longest = 0;                 // longest read of length >= k of the run so far
+  std::vector<uint32_t> h_alloclen;
   std::vector<uint32_t> h_ivoff, h_fineoff;
   std::vector<HitInfoHdr> h_hi;
   bool last_fine = false;
@@ -599,7 +602,7 @@ extern "C" void smaltgpu_mapper_free(smaltgpu_mapper *m) {
                 m->sw_rows, m->align_scr, m->align_scr2};
   for (void *p : ps) if (p) (void)hipFree(p);
   m->h_stat.release(); m->h_res.release(); m->h_dstr.release();
-  m->cx_ivoff.release(); m->cx_iv.release(); m->cx_minsw.release(); m->cx_prevmax.release(); m->cx_fineidx.release(); m->cx_finepos.release(); m->cx_fineoff.release();
+  m->cx_ivoff.release(); m->cx_iv.release(); m->cx_minsw.release(); m->cx_prevmax.release(); m->cx_fineidx.release(); m->cx_finepos.release(); m->cx_fineoff.release(); m->cx_alloclen.release();
   if (m->ev_fetch) (void)hipEventDestroy(m->ev_fetch);
   for (int i = 0; i <= T_NUM; i++) if (m->ev[i]) (void)hipEventDestroy(m->ev[i]);
   if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -632,7 +635,7 @@ static int check_par(const smaltgpu_mapper *m, const smaltgpu_params *p) {
 
 // the device pipeline over reads already in HBM
 // cx: the per-read context of one of rmapPair's rounds, already on the device (upload_ctx), or null
-struct CtxDev { const uint32_t *iv_off; const IvRec *iv; const int32_t *min_sw, *prevmax; uint32_t *fine_idx, *fine_pos; const uint32_t *fine_off; };
+struct CtxDev { const uint32_t *iv_off; const IvRec *iv; const int32_t *min_sw, *prevmax; uint32_t *fine_idx, *fine_pos; const uint32_t *fine_off, *alloc_len; };
 
 static int run_pipeline(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_off, uint32_t n,
                         const smaltgpu_params *par, const CtxDev *cx = nullptr, bool seed_only = false) {
@@ -641,6 +644,7 @@ static int run_pipeline(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_
   MapPar p = to_par(par);
   b.iv_off = cx ? cx->iv_off : nullptr; b.iv = cx ? cx->iv : nullptr; b.min_sw = cx ? cx->min_sw : nullptr; b.prevmax = cx ? cx->prevmax : nullptr;
   b.fine_idx = cx ? cx->fine_idx : nullptr; b.fine_pos = cx ? cx->fine_pos : nullptr; b.fine_off = cx ? cx->fine_off : nullptr;
+  b.alloc_len = cx ? cx->alloc_len : nullptr;
   if (b.fine_idx) p.flags |= FLG_NOSHRTINFO;            // initRMAPINFO, not the short form (rmap.c:2024)
   m->last_fine = b.fine_idx != nullptr;
   m->last_par = p; m->last_n = n;
@@ -843,6 +847,12 @@ static int upload_ctx(smaltgpu_mapper *m, const smaltgpu_callctx *ctx, uint32_t 
     if (n) HIPCHK(hipMemcpyAsync(m->cx_prevmax.p, ctx->prev_max, (size_t)n * 8, hipMemcpyHostToDevice, s));
     cd->prevmax = (const int32_t *)m->cx_prevmax.p;
   }
+  if (ctx->hitlist_len) {
+    for (uint32_t i = 0; i < n; i++) if (ctx->hitlist_len[i] > m->max_len) return fail(SMALTGPU_EARG, "hitlist_len of read %u exceeds the mapper's max_read_len", i);
+    if (m->cx_alloclen.ensure((size_t)(n ? n : 1) * 4)) return fail(SMALTGPU_ENOMEM, "device memory");
+    if (n) HIPCHK(hipMemcpyAsync(m->cx_alloclen.p, ctx->hitlist_len, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    cd->alloc_len = (const uint32_t *)m->cx_alloclen.p;
+  }
   return SMALTGPU_OK;
 }
 
@@ -888,6 +898,7 @@ static int remap_overflowed(smaltgpu_mapper *m, const uint8_t *bases, const uint
   std::vector<uint64_t> so, civo;
   std::vector<smaltgpu_interval> civ;
   std::vector<int32_t> cms, cpm;
+  std::vector<uint32_t> chl;
   uint32_t npermanent = 0, nbatches = 0;
   while (!todo.empty()) {
     std::vector<uint32_t> L;
@@ -904,16 +915,18 @@ static int remap_overflowed(smaltgpu_mapper *m, const uint8_t *bases, const uint
     smaltgpu_callctx sub;
     if (ctx) {                                          // the same reads' slice of the round's context
       sub = *ctx;
-      civo.assign(1, 0); civ.clear(); cms.clear(); cpm.clear();
+      civo.assign(1, 0); civ.clear(); cms.clear(); cpm.clear(); chl.clear();
       for (uint32_t i : L) {
         if (ctx->iv_off) { civ.insert(civ.end(), ctx->iv + ctx->iv_off[i], ctx->iv + ctx->iv_off[i + 1]); civo.push_back(civ.size()); }
         if (ctx->min_swatscor) cms.push_back(ctx->min_swatscor[i]);
         if (ctx->prev_max) { cpm.push_back(ctx->prev_max[2 * (size_t)i]); cpm.push_back(ctx->prev_max[2 * (size_t)i + 1]); }
+        if (ctx->hitlist_len) chl.push_back(ctx->hitlist_len[i]);
       }
       if (civ.empty()) civ.resize(1);
       if (ctx->iv_off) { sub.iv_off = civo.data(); sub.iv = civ.data(); }
       if (ctx->min_swatscor) sub.min_swatscor = cms.data();
       if (ctx->prev_max) sub.prev_max = cpm.data();
+      if (ctx->hitlist_len) sub.hitlist_len = chl.data();
     }
     smaltgpu_batch_out o;
     const int rv = map_range(m, sb.data(), quals ? sq.data() : nullptr, so.data(), (uint32_t)L.size(), par, &o, ctx ? &sub : nullptr);
@@ -1009,9 +1022,29 @@ extern "C" int smaltgpu_map_batch_ctx(smaltgpu_mapper *m, const uint8_t *bases, 
   int rv = check_par(m, par);
   if (rv) return rv;
   out->nreads = 0;
+  smaltgpu_callctx serial;
+  if (m->history && !(ctx && ctx->hitlist_len)) {          // serial-order mode: the capacity of the one hit list of a serial run
+    if (ctx) serial = *ctx; else memset(&serial, 0, sizeof(serial));
+    m->h_alloclen.resize(nreads ? nreads : 1);
+    const uint64_t k = (uint64_t)m->ix->d.k;
+    for (uint32_t i = 0; i < nreads; i++) {
+      const uint64_t len = read_off[i + 1] - read_off[i];
+      if (len >= k && len > m->hist_longest) m->hist_longest = (uint32_t)len;
+      m->h_alloclen[i] = m->hist_longest;
+    }
+    serial.hitlist_len = m->h_alloclen.data();
+    ctx = &serial;
+  }
   rv = map_range(m, bases, quals, read_off, nreads, par, out, ctx);
   if (rv == SMALTGPU_ECAP && out->nreads == nreads && nreads > 0 && !m->debug) return remap_overflowed(m, bases, quals, read_off, nreads, par, out, ctx);
   return rv;
+}
+
+extern "C" int smaltgpu_mapper_set_history(smaltgpu_mapper *m, int on) {
+  if (!m) return fail(SMALTGPU_EARG, "null mapper");
+  m->history = on != 0;
+  m->hist_longest = 0;
+  return SMALTGPU_OK;
 }
 
 // ---- rounds over batches that are resident in HBM (reads and mates of a block of pairs): the round's reads are gathered on the

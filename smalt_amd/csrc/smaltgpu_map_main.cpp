@@ -67,6 +67,7 @@ struct Block {                                  // one block of reads (or pairs)
   smaltgpu_reads_view v, v2;                    // v2: the mates
   smaltgpu_pairs *pairs = nullptr;
   uint32_t maxlen = 0;
+  std::vector<uint32_t> hitlen;                 // serial-order mode: per read the longest read (>= k bases) of the input so far
   int state = 0;                                // 0 free, 1 parsed, 2 mapped + post-processed, 3 end of input
   int worker = -1;
   smaltgpu_batch_out raw;
@@ -216,6 +217,8 @@ int main(int argc, char **argv) {
   const auto t_index = std::chrono::steady_clock::now();
   const char *const *seqnames; const uint64_t *sop; int64_t nseq;
   if (smaltgpu_index_seqnames(ix, &seqnames, &sop, &nseq)) die("index", smaltgpu_last_error());
+  smaltgpu_index_desc idesc;
+  if (smaltgpu_index_info(ix, &idesc)) die("index", smaltgpu_last_error());
   smaltgpu_params par;
   smaltgpu_params_default(&par, ix);
   if (m >= 0) par.min_swatscor = m;
@@ -255,6 +258,10 @@ int main(int argc, char **argv) {
   double t_parse = 0, t_create[MAXWORK] = {0}, t_map[MAXWORK] = {0}, t_post[MAXWORK] = {0};          // seconds per stage (SMALTGPU_MAP_VERBOSE)
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 
+  // SMALTGPU_SERIAL_ORDER=1 (single reads): the output of a serial `smalt map -n 0` also where it depends on the order of reads of
+  // different lengths (the capacity of the reference's hit list follows the longest read so far)
+  const bool serial_order = getenv("SMALTGPU_SERIAL_ORDER") && atoi(getenv("SMALTGPU_SERIAL_ORDER")) != 0;
+  uint32_t longest_so_far = 0;
   std::thread parser([&] {
     double bytes_per_read = 0.0;
     for (uint64_t k = 0;; k++) {
@@ -294,6 +301,16 @@ int main(int argc, char **argv) {
       b.maxlen = 1;
       for (uint32_t i = 0; i < b.v.nreads; i++) { const uint32_t l = (uint32_t)(b.v.read_off[i + 1] - b.v.read_off[i]); if (l > b.maxlen) b.maxlen = l; }
       if (paired) for (uint32_t i = 0; i < b.v2.nreads; i++) { const uint32_t l = (uint32_t)(b.v2.read_off[i + 1] - b.v2.read_off[i]); if (l > b.maxlen) b.maxlen = l; }
+      b.hitlen.clear();
+      if (serial_order && !paired) {                       // the reference's one hit list only grows (hashhit.c:1280): smaltgpu_callctx.hitlist_len
+        b.hitlen.resize(b.v.nreads);
+        for (uint32_t i = 0; i < b.v.nreads; i++) {
+          const uint32_t l = (uint32_t)(b.v.read_off[i + 1] - b.v.read_off[i]);
+          if (l >= (uint32_t)idesc.k && l > longest_so_far) longest_so_far = l;
+          b.hitlen[i] = longest_so_far;
+        }
+        if (longest_so_far > b.maxlen) b.maxlen = longest_so_far;
+      }
       { std::lock_guard<std::mutex> lk(mu); b.state = 1; n_parsed = k + 1; cv.notify_all(); }
     }
   });
@@ -331,7 +348,10 @@ int main(int argc, char **argv) {
           err = why("mapping the pairs failed");
         t1 = now(); t_map[w] += t1 - t0; t0 = t1;
       } else if (err.empty()) {
-        const int rv = smaltgpu_map_batch(W.mp, b.v.bases, b.v.has_qual ? b.v.quals : nullptr, b.v.read_off, b.v.nreads, &par, &b.raw);
+        smaltgpu_callctx cx;
+        memset(&cx, 0, sizeof(cx));
+        cx.hitlist_len = b.hitlen.empty() ? nullptr : b.hitlen.data();
+        const int rv = smaltgpu_map_batch_ctx(W.mp, b.v.bases, b.v.has_qual ? b.v.quals : nullptr, b.v.read_off, b.v.nreads, &par, cx.hitlist_len ? &cx : nullptr, &b.raw);
         if (rv && !((rv == SMALTGPU_ECAP || rv == SMALTGPU_EINTERNAL) && b.raw.nreads == b.v.nreads)) err = why("mapping the reads failed");
         t1 = now(); t_map[w] += t1 - t0; t0 = t1;
         if (err.empty() && smaltgpu_postprocess(W.post, sop, nseq, &b.raw, b.v.bases, b.v.has_qual ? b.v.quals : nullptr, b.v.read_off, packed, &par,

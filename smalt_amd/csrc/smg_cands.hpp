@@ -606,14 +606,7 @@ SMG_HD inline void stage_hits(const Batch &b, const DevIndex &ix, const MapPar &
               hits_lds_bytes(W, tabn) <= x.lds_bytes;
   if (!mine) { SMG_LANE0 { b.hitrun[rs] = run; } return; }
   int nhits_alloc, nhits_max;
-  {
-    double t = (double)qlen * log((double)qlen) * HITLST_LOGQLEN_FACT;   // hashhit.c:1266
-    long long target = (long long)t;
-    if (target > 0x7fffffffLL) target = 0x7fffffffLL; else if (target < HITLST_MINSIZ) target = HITLST_MINSIZ;
-    long long alloc = HITLST_BLKSZ;
-    if (target > alloc) alloc = ((target + HITLST_BLKSZ - 1) / HITLST_BLKSZ) * HITLST_BLKSZ;
-    nhits_alloc = (int)alloc; nhits_max = (int)target;
-  }
+  hitlist_caps(qlen, b.alloc_len ? b.alloc_len[r] : qlen, &nhits_alloc, &nhits_max);
   const uint32_t ncut = (uint32_t)(p.ncut > 0 ? p.ncut : 0);
   const uint32_t smagic = div_magic(s);
   const SeedRec *seeds = b.seeds + (size_t)rs * b.qmax;
@@ -879,14 +872,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     if (mincov_below_max < (uint32_t)k || (p.flags & FLG_BEST)) mincov_below_max = (uint32_t)(k + 2 * (s - 1));
   }
   int nhits_alloc, nhits_max;
-  {
-    double t = (double)qlen * log((double)qlen) * HITLST_LOGQLEN_FACT;   // hashhit.c:1266
-    long long target = (long long)t;
-    if (target > 0x7fffffffLL) target = 0x7fffffffLL; else if (target < HITLST_MINSIZ) target = HITLST_MINSIZ;
-    long long alloc = HITLST_BLKSZ;
-    if (target > alloc) alloc = ((target + HITLST_BLKSZ - 1) / HITLST_BLKSZ) * HITLST_BLKSZ;
-    nhits_alloc = (int)alloc; nhits_max = (int)target;
-  }
+  hitlist_caps(qlen, b.alloc_len ? b.alloc_len[r] : qlen, &nhits_alloc, &nhits_max);
   const uint32_t ncut = (uint32_t)(p.ncut > 0 ? p.ncut : 0);
   const uint32_t smagic = div_magic(s);
   int err = 0, site = 0;

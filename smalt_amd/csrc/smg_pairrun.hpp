@@ -262,6 +262,7 @@ struct smaltgpu_pairs {
   uint64_t calls[4] = {0, 0, 0, 0};
   double round_ms[4] = {0, 0, 0, 0};
   double totals_ms = 0;                       // host wall time of the hit-totals batches
+  double wall_ms = 0;                         // host wall time of the whole call
   double kernel_ms[5][16];                    // per round (4 = hit totals) and kernel: device time of the block
   uint64_t work[5][32];
 };

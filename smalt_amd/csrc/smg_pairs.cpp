@@ -126,6 +126,7 @@ static int map_pairs(smaltgpu_mapper *m, const smaltgpu_resident_reads *resident
   const smaltgpu_index *ix = smaltgpu_mapper_index(m);
   smaltgpu_index_desc ds;
   if (!ix || smaltgpu_index_info(ix, &ds)) return smaltgpu_set_error(SMALTGPU_EARG, "smaltgpu_map_pairs: the mapper has no index");
+  const auto wall0 = std::chrono::steady_clock::now();
   BlockInput in;
   in.bases[0] = bases1; in.bases[1] = bases2; in.quals[0] = quals1; in.quals[1] = quals2; in.off[0] = read_off1; in.off[1] = read_off2; in.npairs = npairs;
   BlockParams bp;
@@ -143,7 +144,11 @@ static int map_pairs(smaltgpu_mapper *m, const smaltgpu_resident_reads *resident
   if (smaltgpu_mapper_capacity(m, &cap_reads, &maxlen, &cap_bases)) return SMALTGPU_EARG;
   // Sub-blocks: the block is cut into up to four pieces that two runners take in turn; the device calls of a piece hold the
   // mapper (DeviceExec::gate), its host work (post-call passes, probe, intervals) runs while the device works for another piece.
-  const uint32_t nsub = npairs >= 65536 ? 4u : (npairs >= 8192 ? 2u : 1u);
+  // SMALTGPU_PAIR_SUBBLOCKS = 2 or 4 splits a large block into sub-blocks that take turns on the mapper (off by default: four
+  // sub-blocks of a 2^20-pair block measured 7 % slower than the whole block -- smaller device calls cost more than the overlap
+  // gains; a caller that wants the host phases hidden runs two blocks on two mappers, as bench.py's two_streams line does)
+  static const uint32_t want_sub = getenv("SMALTGPU_PAIR_SUBBLOCKS") ? (uint32_t)atoi(getenv("SMALTGPU_PAIR_SUBBLOCKS")) : 1u;
+  const uint32_t nsub = (want_sub >= 4 && npairs >= 65536) ? 4u : ((want_sub >= 2 && npairs >= 8192) ? 2u : 1u);
   std::vector<PairBlock> sub(nsub);
   std::vector<int> sub_rc(nsub, SMALTGPU_OK);
   std::mutex gate;
@@ -211,6 +216,7 @@ static int map_pairs(smaltgpu_mapper *m, const smaltgpu_resident_reads *resident
       }
     }
   });
+  out->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
   return SMALTGPU_OK;
 }
 
@@ -231,7 +237,8 @@ extern "C" int smaltgpu_pairs_host_times(const smaltgpu_pairs *p, double *ms, in
   if (!p || !ms) return smaltgpu_set_error(SMALTGPU_EARG, "smaltgpu_pairs_host_times: null argument");
   for (int i = 0; i < n && i < smgpairs::PairBlock::H_NUM; i++) ms[i] = p->blk.host_ms[i];
   if (n > smgpairs::PairBlock::H_NUM) ms[smgpairs::PairBlock::H_NUM] = p->totals_ms;
-  return smgpairs::PairBlock::H_NUM + 1;
+  if (n > smgpairs::PairBlock::H_NUM + 1) ms[smgpairs::PairBlock::H_NUM + 1] = p->wall_ms;
+  return smgpairs::PairBlock::H_NUM + 2;
 }
 
 extern "C" int smaltgpu_pairs_timers(const smaltgpu_pairs *p, double *kernel_ms, uint64_t *work) {

@@ -54,11 +54,28 @@ struct Batch {                          // one block of reads resident in HBM
   const int32_t *prevmax;               // [2 * nreads] running score maxima of the ResultSet the call appends to (rmap.c:881-885)
   uint32_t *fine_idx, *fine_pos;        // on-the-fly k=5 s=1 index of each read over its intervals (rmap.c:495-517): idx[r][FINE_IDX_STRIDE], pos
   const uint32_t *fine_off;             // [nreads + 1] first position of read r in fine_pos
+  const uint32_t *alloc_len;            // [nreads] or null: length of the longest read the reference's one hit list has held up to read r (serial-order mode)
   // ---- S3 split off the candidate stage (k_hits): null when the mapper keeps S3 inside k_cands ----
   HitRun *hitrun;                       // [2 * nreads]
   uint64_t *hitpool; uint64_t hitpool_cap; unsigned long long *hit_count;    // bump-allocated sorted keys
   uint32_t *hits_cursor;                // work-queue cursor of k_hits
 };
+
+// Capacity and ceiling of the reference's hit list for a read of qlen bases (initHitList, hashhit.c:1262-1288).  The ceiling
+// follows the read; the capacity only grows (blocks of 16384, from hashCreateHitList's 16384): it is set by the longest read the
+// list has held so far -- `longest` -- which is the read itself unless the caller runs the serial-order mode (Batch::alloc_len).
+SMG_HD inline void hitlist_caps(uint32_t qlen, uint32_t longest, int *nhits_alloc, int *nhits_max) {
+  auto target_of = [](uint32_t len) {
+    const double t = (double)len * log((double)len) * HITLST_LOGQLEN_FACT;   // hashhit.c:1266
+    long long target = (long long)t;
+    if (target > 0x7fffffffLL) target = 0x7fffffffLL; else if (target < HITLST_MINSIZ) target = HITLST_MINSIZ;
+    return target;
+  };
+  const long long own = target_of(qlen), widest = longest > qlen ? target_of(longest) : own;
+  long long alloc = HITLST_BLKSZ;
+  if (widest > alloc) alloc = ((widest + HITLST_BLKSZ - 1) / HITLST_BLKSZ) * HITLST_BLKSZ;
+  *nhits_alloc = (int)alloc; *nhits_max = (int)own;
+}
 
 // the index a read is seeded against: the mapper's, or the read's own on-the-fly index
 SMG_HD inline DevIndex read_index(const Batch &b, const DevIndex &ix, uint32_t r) {
@@ -428,15 +445,7 @@ SMG_HD inline uint32_t stage_cands(const Batch &b, const DevIndex &ix, const Map
     if (mincov_below_max < (uint32_t)k || (p.flags & FLG_BEST)) mincov_below_max = (uint32_t)(k + 2 * (s - 1));
   }
   int nhits_alloc, nhits_max;
-  {   // initHitList (hashhit.c:1262-1288); the reference keeps its allocation across reads (it only
-      // grows, in blocks of 16384): this is the stateless value it has when a run has one read length.
-    double t = (double)qlen * log((double)qlen) * HITLST_LOGQLEN_FACT;   // hashhit.c:1266
-    long long target = (long long)t;
-    if (target > 0x7fffffffLL) target = 0x7fffffffLL; else if (target < HITLST_MINSIZ) target = HITLST_MINSIZ;
-    long long alloc = HITLST_BLKSZ;
-    if (target > alloc) alloc = ((target + HITLST_BLKSZ - 1) / HITLST_BLKSZ) * HITLST_BLKSZ;
-    nhits_alloc = (int)alloc; nhits_max = (int)target;
-  }
+  hitlist_caps(qlen, b.alloc_len ? b.alloc_len[r] : qlen, &nhits_alloc, &nhits_max);
   const uint32_t ncut = (uint32_t)(p.ncut > 0 ? p.ncut : 0);
   int err = 0;
   uint32_t nkeys = 0;

@@ -100,6 +100,13 @@ int main(int argc, char **argv) {
   b.hi = hi.data(); b.seeds = seeds.data(); b.qmask = qmask.data(); b.ch = ch.data(); b.rcpool = rcpool.data(); b.rccap = rccap;
   b.rc_count = &rc_count; b.ctl = ctl.data(); b.stat = stat.data(); b.respool = respool.data(); b.rescap = respool.size();
   b.res_count = &res_count; b.dstrpool = dstrpool.data(); b.dstrcap = dstrpool.size(); b.dstr_count = &dstr_count; b.err_flag = &err_flag;
+  // EMU_HISTORY=1: the file is one serial run -- the hit list's capacity follows the longest read (>= k bases) so far
+  std::vector<uint32_t> alloc_len(n ? n : 1);
+  if (getenv("EMU_HISTORY") && atoi(getenv("EMU_HISTORY")) != 0) {
+    uint32_t longest = 0;
+    for (uint32_t r = 0; r < n; r++) { const uint32_t len = (uint32_t)(off[r + 1] - off[r]); if (len >= (uint32_t)ix.k && len > longest) longest = len; alloc_len[r] = longest; }
+    b.alloc_len = alloc_len.data();
+  }
   unsigned long long workctr[WK_NWORK] = {0};
   b.work = workctr; b.long_list = nullptr; b.long_cap = 0; b.strip_list = nullptr; b.strip_cap = 0; b.tile_qmax = 512;
 

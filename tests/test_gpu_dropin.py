@@ -266,3 +266,37 @@ def test_pairs_with_more_than_1023_search_intervals(tmp_path):
         b = open(out_gpu).read().split("\n")
         diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
         assert len(a) == len(b) and not diff, (cmd[0], len(diff), diff[:3])
+
+
+@pytest.mark.skipif(not os.path.exists(SMALT), reason="reference binary not built (make -C oracle ref)")
+def test_serial_order_mode_prints_what_a_serial_run_prints(tmp_path):
+    """`smalt map -n 0` keeps one hit list for all reads, and the list only grows with the longest read so far (hashhit.c:1280):
+    the fixture of tests/golden/make_golden_history.py has 100-base reads whose alignments depend on whether the 260-base read
+    came before them.  SMALTGPU_SERIAL_ORDER=1 makes smaltgpu-map carry that length from read to read (in blocks of 16 reads
+    here, so that it is carried across blocks and workers); the output is that of the unmodified program."""
+    import gzip
+    import json
+    import golden_util as gu
+    entry = json.load(open(os.path.join(gu.GOLD, "manifest_history.json")))
+    tmp = str(tmp_path)
+    paths = {}
+    for ext in ("fa", "fq"):
+        paths[ext] = os.path.join(tmp, "h." + ext)
+        with gzip.open(os.path.join(gu.GOLD, "%s.%s.gz" % (entry["tag"], ext)), "rb") as g, open(paths[ext], "wb") as f:
+            f.write(g.read())
+    pre = os.path.join(tmp, "idx")
+    subprocess.run([SMALT, "index", "-k", str(entry["k"]), "-s", str(entry["s"]), pre, paths["fa"]], check=True, capture_output=True)
+    opts = ["-f", "cigar", "-r", "-1", "-d", "-1"] + entry["opts"].split()
+    out_ref, out_gpu = os.path.join(tmp, "ref.out"), os.path.join(tmp, "gpu.out")
+    subprocess.run([SMALT, "map"] + opts + ["-o", out_ref, pre, paths["fq"]], check=True, capture_output=True)
+    a = open(out_ref).read().split("\n")
+    prog = os.path.join(ROOT, "smalt_amd", "smaltgpu-map")
+    outs = {}
+    for mode in ("1", "0"):
+        env = dict(os.environ, SMALTGPU_SERIAL_ORDER=mode)
+        r = subprocess.run([prog] + opts + ["-B", "16", "-o", out_gpu, pre, paths["fq"]], capture_output=True, env=env)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs[mode] = open(out_gpu).read().split("\n")
+    diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, outs["1"])) if x != y]
+    assert len(a) == len(outs["1"]) and not diff, (len(diff), diff[:3])
+    assert outs["0"] != a                       # the fixture does depend on the order

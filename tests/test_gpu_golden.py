@@ -53,3 +53,42 @@ def test_gpu_matches_reference_dump(entry, oracle_built, tmp_path):
     for i, (x, y) in enumerate(zip(a, b)):
         assert x == y, "line %d" % (i + 1)
     assert len(a) == len(b)
+
+
+@pytest.mark.parametrize("history,batches", [(True, 1), (True, 3), (False, 1)], ids=["serial-order", "serial-order-3-calls", "stateless"])
+def test_serial_order_mode_follows_the_hit_list_of_a_serial_run(history, batches, oracle_built, tmp_path):
+    """tests/golden/make_golden_history.py: reads of 100 bases that reach the allocation boundary of their hit list (hashhit.c:1497)
+    unless a longer read was mapped before them (initHitList only ever grows the list, hashhit.c:1280).  With
+    smaltgpu_mapper_set_history the mapper reproduces the reference run serially over the file -- also when the file is mapped in
+    several calls, the longest length is carried between them; without it every read is mapped as the first read of a run
+    (second dump of the fixture: the reference run on each read alone)."""
+    import gzip
+    import json
+    import os
+
+    from smalt_amd import api
+    entry = json.load(open(os.path.join(gu.GOLD, "manifest_history.json")))
+    fx = gu.unpack(entry, tmp_path)
+    expected = fx["expected"] if history else gzip.open(os.path.join(gu.GOLD, entry["tag"] + ".refdump_fresh.txt.gz"), "rt").read()
+    reads = gu.read_fastq(fx["fq"])
+    ix = api.Index.load(fx["prefix"], 0)
+    mp = api.Mapper(ix, 2048, max(len(r[1]) for r in reads))      # pools for 2048 average reads: the repeat reads have thousands of candidates each
+    got = []
+    try:
+        mp.set_debug(2)
+        if history:
+            mp.set_history(True)
+        par = params_from_opts(ix, entry["opts"])
+        step = (len(reads) + batches - 1) // batches
+        for b0 in range(0, len(reads), step):
+            part = reads[b0:b0 + step]
+            res, stats = mp.map_batch([r[1] for r in part], [r[2] for r in part], par)
+            assert all(s["err"] == 0 for s in stats)
+            got += [mp.dump_read(i, part[i][0]).replace("READ %d " % i, "READ %d " % (b0 + i), 1) for i in range(len(part))]
+    finally:
+        mp.close()
+        ix.close()
+    a, b = "".join(got).split("\n"), expected.split("\n")
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x == y, "line %d" % (i + 1)
+    assert len(a) == len(b)

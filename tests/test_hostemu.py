@@ -36,6 +36,27 @@ def test_stage_logic_matches_reference_dump(entry, window, split, emu_bin, oracl
     assert len(a) == len(b)
 
 
+@pytest.mark.parametrize("history", [1, 0], ids=["serial-order", "stateless"])
+@pytest.mark.parametrize("split", [0, 1], ids=["fused", "split"])
+def test_hit_list_capacity_follows_the_serial_run(history, split, emu_bin, oracle_built, tmp_path):
+    """tests/golden/make_golden_history.py: 100-base reads on a 430-copy repeat reach the allocation boundary of the reference's hit
+    list (hashhit.c:1497, :1730-1741) unless a longer read has grown the list before them (hashhit.c:1280-1282).  With the lengths
+    of the longest earlier read per read (Batch::alloc_len, EMU_HISTORY=1) the stage logic gives the dump of the reference run
+    serially over the file; without, the dump of the reference run on each read alone."""
+    import gzip
+    import json
+    entry = json.load(open(os.path.join(gu.GOLD, "manifest_history.json")))
+    fx = gu.unpack(entry, tmp_path)
+    expected = fx["expected"] if history else gzip.open(os.path.join(gu.GOLD, entry["tag"] + ".refdump_fresh.txt.gz"), "rt").read()
+    assert fx["expected"] != expected or history
+    env = dict(os.environ, EMU_HISTORY=str(history), EMU_SPLIT=str(split), EMU_HITS_WINDOW="400")
+    out = subprocess.run([emu_bin] + entry["opts"].split() + [fx["prefix"], fx["fq"]], check=True, capture_output=True, text=True, env=env).stdout
+    a, b = out.split("\n"), expected.split("\n")
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x == y, "line %d" % (i + 1)
+    assert len(a) == len(b)
+
+
 def _mutate(rng, src, sub, ins, dele):
     out = bytearray()
     for ch in src:
