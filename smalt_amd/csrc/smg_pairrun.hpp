@@ -39,8 +39,35 @@ struct Round {                              // one batch of mapping calls: read 
   const int32_t *prev_max;                                   // ROUND_APPEND, ROUND_FINE: (max, second) per call
 };
 
+// The tables of a block at rest: byte runs (Table::pack) in arenas, one arena per worker thread and post-call pass -- a pass only
+// appends to its own arenas and reads those of earlier passes, and a block re-uses the arenas of the block before it: no
+// allocation per read (two vectors per pair cost 50 ms per block of 262 144 pairs in malloc/free alone).
+struct RestStore {
+  struct Ref { uint32_t arena, len; uint64_t at; };
+  std::vector<Ref> ref;                       // per read id (2 * pair + mate)
+  std::vector<std::vector<uint8_t>> arena;
+  size_t used = 0;                            // arenas handed out in this block
+  void reset(size_t nreads) { ref.assign(nreads, Ref{0, 0, 0}); used = 0; }
+  size_t open_pass(int nthreads) {            // -> first arena of the pass; call before its threads start
+    const size_t first = used;
+    used += (size_t)nthreads;
+    if (arena.size() < used) arena.resize(used);
+    for (size_t a = first; a < used; a++) arena[a].clear();
+    return first;
+  }
+  const uint8_t *data(size_t id) const { return ref[id].len ? arena[ref[id].arena].data() + ref[id].at : nullptr; }
+  size_t size(size_t id) const { return ref[id].len; }
+  void clear(size_t id) { ref[id].len = 0; }
+  void put(size_t id, size_t a, const smgpost::Table &tb) {
+    std::vector<uint8_t> &buf = arena[a];
+    const size_t at = buf.size();
+    tb.pack(buf, true);
+    ref[id] = Ref{(uint32_t)a, (uint32_t)(buf.size() - at), (uint64_t)at};
+  }
+};
+
 struct PairBlock {
-  std::vector<std::vector<uint8_t>> packed;   // 2 * npairs tables at rest
+  RestStore packed;                           // 2 * npairs tables at rest
   std::vector<PairPlan> plan;
   std::vector<uint32_t> nrounds;              // mapping calls per round kind, for the caller's statistics
   std::string error;
@@ -68,6 +95,7 @@ struct PairBlock {
     std::vector<std::string> bad((size_t)(bp.nthreads < 1 ? 1 : bp.nthreads));
     const smgpost::Reference ref{bp.sop, bp.nseq, bp.packed_host};
     const smgpost::Penalties pen{bp.map.match, bp.map.mismatch, bp.map.gap_init, bp.map.gap_ext};
+    const size_t arena0 = packed.open_pass(bp.nthreads < 1 ? 1 : bp.nthreads);
     spread(rd.n, bp.nthreads, [&](uint32_t lo, uint32_t hi, int t) {
       Table tb;
       char msg[256];
@@ -75,8 +103,7 @@ struct PairBlock {
         const uint32_t id = rd.ids[i], w = id & 1, pr = id >> 1;
         const smaltgpu_readstat &st = o.stat[i];
         if (st.errcode) { snprintf(msg, sizeof(msg), "pair %u, mate %u, round %d: the mapping call failed on the device (code %d, site %d)", pr, w + 1, (int)rd.kind, st.errcode, st.errsite); if (bad[(size_t)t].empty()) bad[(size_t)t] = msg; continue; }
-        std::vector<uint8_t> &rest = packed[id];
-        tb.unpack(rest.data(), rest.size());
+        tb.unpack(packed.data(id), packed.size(id));
         tb.n_ali_done = st.n_ali_done; tb.n_ali_tot = st.n_ali_tot; tb.n_hits_used = st.n_hits_used; tb.n_hits_tot = st.n_hits_tot;     // rmap.c:1337
         tb.take_call(o.res + o.res_off[i], (uint32_t)(o.res_off[i + 1] - o.res_off[i]), o.diffstr, st.swatscor_max, st.swatscor_2ndmax);
         if (st.max1scor >= 1) {                                        // a call without a score-pass hit returns before the pass (rmap.c:1376)
@@ -92,7 +119,7 @@ struct PairBlock {
           }
         }
         if (!after(i, pr, tb, t)) { snprintf(msg, sizeof(msg), "pair %u, mate %u: alignment set is inconsistent", pr, w + 1); if (bad[(size_t)t].empty()) bad[(size_t)t] = msg; }
-        tb.pack(rest);
+        packed.put(id, arena0 + (size_t)t, tb);
       }
     });
     for (const std::string &b : bad) if (!b.empty()) { error = b; return false; }
@@ -103,7 +130,7 @@ struct PairBlock {
     const uint32_t n = in.npairs;
     npairs = n;
     error.clear();
-    packed.assign((size_t)2 * n, std::vector<uint8_t>());
+    packed.reset((size_t)2 * n);
     plan.assign(n, PairPlan());
     nrounds.assign(4, 0);
     for (double &h : host_ms) h = 0;
@@ -170,10 +197,10 @@ struct PairBlock {
         Probe probe;
         for (uint32_t i = lo; i < hi; i++) {
           const uint32_t p = ids_b[i] >> 1;
-          A.unpack(packed[2 * p].data(), packed[2 * p].size());
-          B.unpack(packed[2 * p + 1].data(), packed[2 * p + 1].size());
+          A.unpack(packed.data(2 * p), packed.size(2 * p));
+          B.unpack(packed.data(2 * p + 1), packed.size(2 * p + 1));
           if (plan_after_b(plan[p], probe, A, B, len_of(in, 2 * p), len_of(in, 2 * p + 1), bp.d_min, bp.d_max, bp.lib, bp.every_pair) < 0) { broken[(size_t)t] = 1; continue; }
-          if (plan[p].wants_c && plan[p].proper_found < 1) packed[2 * p + (plan[p].first ^ 1u)].clear();
+          if (plan[p].wants_c && plan[p].proper_found < 1) packed.clear(2 * p + (plan[p].first ^ 1u));
         }
       });
       for (int b : broken) if (b) { error = "a pair's alignment sets are not in order for pairing, or the insert range is empty"; return false; }
@@ -191,7 +218,7 @@ struct PairBlock {
       prev_max.assign((size_t)2 * nc, 0);
       spread(nc, nt, [&](uint32_t lo, uint32_t hi, int) {
         Table tb;
-        for (uint32_t i = lo; i < hi; i++) { const auto &rest = packed[ids[i]]; tb.unpack(rest.data(), rest.size()); prev_max[2 * (size_t)i] = tb.score_max; prev_max[2 * (size_t)i + 1] = tb.score_2nd; }
+        for (uint32_t i = lo; i < hi; i++) { tb.unpack(packed.data(ids[i]), packed.size(ids[i])); prev_max[2 * (size_t)i] = tb.score_max; prev_max[2 * (size_t)i + 1] = tb.score_2nd; }
       });
       Round rc{ROUND_APPEND, ids.data(), nc, nullptr, nullptr, nullptr, prev_max.data()};
       if (!exec.map(rc, &o, error)) return false;
@@ -212,8 +239,8 @@ struct PairBlock {
           const uint32_t p = ids[i] >> 1;
           PairPlan &pl = plan[p];
           if (pl.lone) continue;
-          A.unpack(packed[2 * p].data(), packed[2 * p].size());
-          B.unpack(packed[2 * p + 1].data(), packed[2 * p + 1].size());
+          A.unpack(packed.data(2 * p), packed.size(2 * p));
+          B.unpack(packed.data(2 * p + 1), packed.size(2 * p + 1));
           plan_after_c(pl, A, B, len_of(in, 2 * p), len_of(in, 2 * p + 1), bp.k);
           if (!pl.wants_d) continue;
           const Table &first = pl.first ? B : A, &second = pl.first ? A : B;

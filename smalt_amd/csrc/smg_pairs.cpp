@@ -2,9 +2,7 @@
 // them (replaces rmapPair, rmap.c:1744-2112, for a block).  Host code: every round gathers its reads into one
 // batch for smaltgpu_map_batch_ctx, worker threads do the post-call passes and the decisions between the rounds.
 // Compiled with g++ -ffp-contract=off like smg_post.cpp (mapping qualities are double arithmetic).
-#include <atomic>
 #include <chrono>
-#include <mutex>
 #include "smg_pairrun.hpp"
 
 extern "C" int smaltgpu_set_error(int code, const char *msg);
@@ -20,20 +18,6 @@ struct DeviceExec {
   uint32_t cap_reads;
   uint64_t cap_bases;
   const smaltgpu_resident_reads *resident = nullptr;      // the block's reads in HBM: rounds are gathered on the device
-  // Several sub-blocks take turns on the one mapper (map_pairs): a device call holds the gate from its launch to the copy of its
-  // results out of the mapper's buffers, so that the host work behind a round of one sub-block runs beside the device work of another
-  std::mutex *gate = nullptr;
-  std::vector<smaltgpu_result> k_res; std::vector<uint64_t> k_off; std::vector<uint8_t> k_str; std::vector<smaltgpu_readstat> k_stat;
-  void keep(smaltgpu_batch_out *o) {
-    const uint32_t n = o->nreads;
-    const uint64_t nres = o->res_off[n];
-    size_t nstr = 0;
-    for (uint64_t j = 0; j < nres; j++) { const size_t e = (size_t)o->res[j].stroffs + o->res[j].strlen; if (e > nstr) nstr = e; }
-    k_res.assign(o->res, o->res + nres); k_off.assign(o->res_off, o->res_off + n + 1); k_str.assign(o->diffstr, o->diffstr + nstr); k_stat.assign(o->stat, o->stat + n);
-    if (k_res.empty()) k_res.resize(1);
-    if (k_str.empty()) k_str.resize(1);
-    o->res = k_res.data(); o->res_off = k_off.data(); o->diffstr = k_str.data(); o->stat = k_stat.data();
-  }
   std::vector<uint8_t> bases, quals;
   std::vector<uint64_t> off;
   double ms[4] = {0, 0, 0, 0};
@@ -70,8 +54,6 @@ struct DeviceExec {
     return ok;
   }
   bool totals_inner(const uint32_t *ids, uint32_t n, uint32_t *hits, std::string &err) {
-    std::unique_lock<std::mutex> turn;
-    if (gate) turn = std::unique_lock<std::mutex>(*gate);
     for (uint32_t lo = 0; lo < n;) {                   // in pieces the mapper can take
       uint32_t hi = lo;
       uint64_t nb = 0;
@@ -90,8 +72,6 @@ struct DeviceExec {
     return true;
   }
   bool map(const Round &rd, smaltgpu_batch_out *o, std::string &err) {
-    std::unique_lock<std::mutex> turn;
-    if (gate) turn = std::unique_lock<std::mutex>(*gate);
     const auto t0 = std::chrono::steady_clock::now();
     if (rd.n > cap_reads) { rc = SMALTGPU_EARG; err = "the block holds more pairs than the mapper's batch size"; return false; }
     smaltgpu_callctx cx;
@@ -106,7 +86,6 @@ struct DeviceExec {
     // a read that failed on its own carries its code in stat[].errcode; the runner names it
     if (rv && !((rv == SMALTGPU_ECAP || rv == SMALTGPU_EINTERNAL) && o->nreads == rd.n)) return fail_with(err, rv);
     tally(rd.kind);
-    if (gate) keep(o);
     ms[rd.kind] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return true;
   }
@@ -142,64 +121,17 @@ static int map_pairs(smaltgpu_mapper *m, const smaltgpu_resident_reads *resident
   uint32_t cap_reads = 0, maxlen = 0;
   uint64_t cap_bases = 0;
   if (smaltgpu_mapper_capacity(m, &cap_reads, &maxlen, &cap_bases)) return SMALTGPU_EARG;
-  // Sub-blocks: the block is cut into up to four pieces that two runners take in turn; the device calls of a piece hold the
-  // mapper (DeviceExec::gate), its host work (post-call passes, probe, intervals) runs while the device works for another piece.
-  // SMALTGPU_PAIR_SUBBLOCKS = 2 or 4 splits a large block into sub-blocks that take turns on the mapper (off by default: four
-  // sub-blocks of a 2^20-pair block measured 7 % slower than the whole block -- smaller device calls cost more than the overlap
-  // gains; a caller that wants the host phases hidden runs two blocks on two mappers, as bench.py's two_streams line does)
-  static const uint32_t want_sub = getenv("SMALTGPU_PAIR_SUBBLOCKS") ? (uint32_t)atoi(getenv("SMALTGPU_PAIR_SUBBLOCKS")) : 1u;
-  const uint32_t nsub = (want_sub >= 4 && npairs >= 65536) ? 4u : ((want_sub >= 2 && npairs >= 8192) ? 2u : 1u);
-  std::vector<PairBlock> sub(nsub);
-  std::vector<int> sub_rc(nsub, SMALTGPU_OK);
-  std::mutex gate;
-  std::mutex tally_mu;
+  // (the host phases between the rounds are not overlapped inside one call: a block cut into pieces that take turns on the mapper
+  //  measured slower than the whole block; a caller hides them by running two blocks on two mappers, see bench.py's two_streams)
   memset(out->kernel_ms, 0, sizeof(out->kernel_ms)); memset(out->work, 0, sizeof(out->work));
-  for (int r = 0; r < 4; r++) { out->round_ms[r] = 0; out->calls[r] = 0; }
-  out->totals_ms = 0;
-  std::atomic<uint32_t> next(0);
-  auto runner = [&]() {
-    for (;;) {
-      const uint32_t j = next.fetch_add(1);
-      if (j >= nsub) return;
-      const uint32_t lo = (uint32_t)((uint64_t)npairs * j / nsub), hi = (uint32_t)((uint64_t)npairs * (j + 1) / nsub);
-      BlockInput sin = in;
-      sin.off[0] = in.off[0] + lo; sin.off[1] = in.off[1] + lo; sin.npairs = hi - lo;
-      smaltgpu_resident_reads sres;
-      if (resident) {
-        sres = *resident;
-        for (int w = 0; w < 2; w++) { sres.d_read_off[w] = resident->d_read_off[w] + lo; sres.read_off[w] = resident->read_off[w] + lo; sres.nreads[w] = hi - lo; }
-      }
-      BlockParams sbp = bp;
-      sbp.nthreads = nsub > 1 ? (bp.nthreads + 1) / 2 : bp.nthreads;
-      DeviceExec ex{m, sin, sbp.map, cap_reads, cap_bases};
-      ex.resident = resident ? &sres : nullptr;
-      ex.gate = nsub > 1 ? &gate : nullptr;
-      memset(ex.kernel_ms, 0, sizeof(ex.kernel_ms)); memset(ex.work, 0, sizeof(ex.work));
-      const bool ok = sub[j].run(ex, sin, sbp);
-      if (!ok) sub_rc[j] = ex.rc != SMALTGPU_OK ? ex.rc : SMALTGPU_EINTERNAL;
-      std::lock_guard<std::mutex> lk(tally_mu);
-      for (int r = 0; r < 4; r++) { out->round_ms[r] += ex.ms[r]; out->calls[r] += sub[j].nrounds.size() == 4 ? sub[j].nrounds[(size_t)r] : 0; }
-      for (int r = 0; r < 5; r++) { for (int i = 0; i < 16; i++) out->kernel_ms[r][i] += ex.kernel_ms[r][i]; for (int i = 0; i < 32; i++) out->work[r][i] += ex.work[r][i]; }
-      out->totals_ms += ex.totals_wall;
-    }
-  };
-  if (nsub == 1) runner();
-  else { std::thread t2(runner); runner(); t2.join(); }
-  // one block again
-  PairBlock &B = out->blk;
-  B.npairs = npairs; B.error.clear();
-  B.packed.assign((size_t)2 * npairs, std::vector<uint8_t>());
-  B.plan.assign(npairs, PairPlan());
-  B.nrounds.assign(4, 0);
-  for (double &h : B.host_ms) h = 0;
-  for (uint32_t j = 0; j < nsub; j++) {
-    if (sub_rc[j] != SMALTGPU_OK) return smaltgpu_set_error(sub_rc[j], ("smaltgpu_map_pairs: " + sub[j].error).c_str());
-    const uint32_t lo = (uint32_t)((uint64_t)npairs * j / nsub);
-    for (size_t i = 0; i < sub[j].packed.size(); i++) B.packed[(size_t)2 * lo + i].swap(sub[j].packed[i]);
-    for (size_t i = 0; i < sub[j].plan.size(); i++) B.plan[(size_t)lo + i] = sub[j].plan[i];
-    for (int r = 0; r < 4 && sub[j].nrounds.size() == 4; r++) B.nrounds[(size_t)r] += sub[j].nrounds[(size_t)r];
-    for (int h = 0; h < PairBlock::H_NUM; h++) B.host_ms[h] += sub[j].host_ms[h];
-  }
+  DeviceExec ex{m, in, bp.map, cap_reads, cap_bases};
+  ex.resident = resident;
+  memset(ex.kernel_ms, 0, sizeof(ex.kernel_ms)); memset(ex.work, 0, sizeof(ex.work));
+  const bool ok = out->blk.run(ex, in, bp);
+  for (int r = 0; r < 4; r++) { out->round_ms[r] = ex.ms[r]; out->calls[r] = out->blk.nrounds.size() == 4 ? out->blk.nrounds[(size_t)r] : 0; }
+  memcpy(out->kernel_ms, ex.kernel_ms, sizeof(out->kernel_ms)); memcpy(out->work, ex.work, sizeof(out->work));
+  out->totals_ms = ex.totals_wall;
+  if (!ok) return smaltgpu_set_error(ex.rc != SMALTGPU_OK ? ex.rc : SMALTGPU_EINTERNAL, ("smaltgpu_map_pairs: " + out->blk.error).c_str());
   // the summary: flags, rounds, surviving alignments
   out->info.assign(npairs ? npairs : 1, smaltgpu_pair_info());
   PairBlock::spread(npairs, bp.nthreads, [&](uint32_t lo, uint32_t hi, int) {
@@ -209,9 +141,9 @@ static int map_pairs(smaltgpu_mapper *m, const smaltgpu_resident_reads *resident
       f.pairflg = pl.state;
       f.rounds = (uint8_t)((!pl.idle && !pl.lone ? 3 : 0) | ((pl.wants_c || pl.lone) && !pl.idle ? 4 : 0) | (pl.wants_d && !pl.lone ? 8 : 0));
       for (int w = 0; w < 2; w++) {
-        const std::vector<uint8_t> &rest = out->blk.packed[2 * (size_t)p + (size_t)w];
+        const size_t id = 2 * (size_t)p + (size_t)w;
         uint32_t nlive = 0;
-        if (rest.size() >= 8) memcpy(&nlive, rest.data() + 4, 4);          // second header word of Table::pack
+        if (out->blk.packed.size(id) >= 8) memcpy(&nlive, out->blk.packed.data(id) + 4, 4);          // second header word of Table::pack
         f.nali[w] = (uint16_t)(nlive > 65535 ? 65535 : nlive);
       }
     }

@@ -541,8 +541,8 @@ struct Table {
   }
 
   // A table between two passes, as one run of bytes (a block of pairs keeps two of these per pair, not two Tables)
-  void pack(std::vector<uint8_t> &o) const {
-    o.clear();
+  void pack(std::vector<uint8_t> &o, bool append = false) const {
+    if (!append) o.clear();
     const uint32_t head[13] = {rows(), (uint32_t)by_score.size(), (uint32_t)segment_begin.size(), (uint32_t)strings.size(), set_bits, (uint32_t)nsegments,
                                (uint32_t)n_ali_done, (uint32_t)n_ali_tot, (uint32_t)score_max, (uint32_t)score_2nd, n_hits_used, n_hits_tot, (uint32_t)by_segment.size()};
     put(o, head, 13);

@@ -712,9 +712,8 @@ struct PairJob {
 // everything for pair p up to the choice; -> number of random draws the choice needs (counting mode: dr.values == nullptr)
 bool pair_entries(const PairJob &jb, uint32_t p, Table &A, Table &B, smgpairs::Join &join, std::vector<Entry> &entries, smgpairs::Draws &dr) {
   const smgpairs::PairBlock &blk = jb.pairs->blk;
-  const std::vector<uint8_t> &ra = blk.packed[2 * (size_t)p], &rb = blk.packed[2 * (size_t)p + 1];
-  A.unpack(ra.data(), ra.size());
-  B.unpack(rb.data(), rb.size());
+  A.unpack(blk.packed.data(2 * (size_t)p), blk.packed.size(2 * (size_t)p));
+  B.unpack(blk.packed.data(2 * (size_t)p + 1), blk.packed.size(2 * (size_t)p + 1));
   const smgpairs::PairPlan &pl = blk.plan[p];
   join.pairs.clear();
   if (!pl.idle) {                         // a pair of two mates shorter than a word returns before the pairing (rmap.c:1833-1834)

@@ -46,6 +46,7 @@ pj={"round":RN,"reads_per_launch":131072,"unit":"bytes per launch",
  "source":"profiles/%s_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE, separate passes; FETCH_SIZE as reported = 64 B per line touched for the random 4-8 byte reads of these kernels, see profiles/%s_hbm_calibration.txt)" % (R, R),
  "kernels":{"sw_full":{"fetch":g(f,'k_sw_full16<8, 19, 248>','FETCH_SIZE'),"write":g(w,'k_sw_full16<8, 19, 248>','WRITE_SIZE')},
             "cands":{"fetch":g(f,'k_cands','FETCH_SIZE'),"write":g(w,'k_cands','WRITE_SIZE')},
+            "hits":{"fetch":g(f,'k_hits','FETCH_SIZE'),"write":g(w,'k_hits','WRITE_SIZE')},
             "seed":{"fetch":g(f,'k_seed','FETCH_SIZE'),"write":g(w,'k_seed','WRITE_SIZE')},
             "align":{"fetch":g(f,'k_align','FETCH_SIZE'),"write":g(w,'k_align','WRITE_SIZE')}}}
 json.dump(pj,open('profiles/pmc_traffic.json','w'),indent=1)
