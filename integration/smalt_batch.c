@@ -41,9 +41,8 @@ static int processArgBlockGpu(ErrMsg *errmsgp,
 
   n = blockp->n_iobf;
   if (n < 1) return ERRCODE_SUCCESS;
-  /* not on the GPU path: split reads, complexity weighting, and pairs with a cover threshold (-c: the interval-restricted
-   * rounds of rmapPair exist in the library for the default -c 0 only) */
-  if ((macop->rmapflg & (RMAPFLG_SPLIT | RMAPFLG_CMPLXW)) || macop->tupcovmin < 0 || (blockp->iobfp[0].isPaired && macop->tupcovmin > 0.0))
+  /* not on the GPU path: split reads and complexity weighting */
+  if ((macop->rmapflg & (RMAPFLG_SPLIT | RMAPFLG_CMPLXW)) || macop->tupcovmin < 0)
     return processArgBlock(errmsgp,
 #ifdef THREADS_DEBUG
                            readno,

@@ -1149,7 +1149,7 @@ extern "C" long smaltgpu_dump_read(smaltgpu_mapper *m, uint32_t i, const char *n
       fetch(st, b.stat + i, 1) || fetch(slot, m->cand_scr_dbg + m->cand_bytes * i, m->cand_bytes)) return SMALTGPU_ENODEV;
   const uint32_t ngrp = (m->last_par.flags & FLG_SEQBYSEQ) ? (uint32_t)d.nseq : 1u;
   const int dk = m->last_fine ? (int)FINE_K : d.k, dsx = m->last_fine ? (int)FINE_S : d.s;
-  const bool v2 = cands_v2_applicable(m->last_par, dk, dsx, (uint32_t)(m->h_off[i + 1] - m->h_off[i]));
+  const bool v2 = cands_v2_applicable(m->last_par, dk, dsx, (uint32_t)(m->h_off[i + 1] - m->h_off[i]), b.iv_off != nullptr);
   CandScratch cx = cand_scratch_carve(slot.data(), m->qmax, dsx, m->cg.hcap, ngrp, m->cg.segcap, m->cg.candcap);
   CandsV2Scratch c2 = cands_v2_carve(nullptr, 0, slot.data(), m->qmax, dsx, m->cg.hcap_strand, ngrp, m->cg.candcap, true);
   std::vector<RCand> rc; std::vector<Result> res; std::vector<uint8_t> dstr;

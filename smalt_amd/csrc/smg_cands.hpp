@@ -563,9 +563,14 @@ SMG_HD inline void iv_serials(const DevIndex &ix, const IvRec &v, uint32_t *plo,
   *plo = (uint32_t)a; *phi = (uint32_t)b;
 }
 
-// true when the parallel form applies to this read
-SMG_HD inline bool cands_v2_applicable(const MapPar &p, int k, int s, uint32_t qlen) {
-  return qlen < (1u << KEY_QBITS) && read_min_cover(p, qlen) < (uint32_t)(k + s);     // calcMinKtup (rmap.c:240-247) gives min_ktup == 1
+// true when the parallel form applies to this read.  It has no filter on the number of hits of a hit region (min_ktup,
+// segment.c:781-800), so it needs that filter to be void: either the cover threshold is below k + s (calcMinKtup, rmap.c:240-247,
+// gives min_ktup == 1), or the hit list is filled per sequence or per search interval (`restricted`) -- those lists keep their
+// read-offset mask blank (hashBlankHitList before every fill, rmap.c:294, :461), and segLstFillHits takes one off min_ktup for
+// every offset that is not marked as hit (segment.c:781-788), which brings any min_ktup <= read length down to 1.  The cover
+// threshold itself, (min_ktup - 1) * s + k, applies in every case.
+SMG_HD inline bool cands_v2_applicable(const MapPar &p, int k, int s, uint32_t qlen, bool restricted) {
+  return qlen < (1u << KEY_QBITS) && (read_min_cover(p, qlen) < (uint32_t)(k + s) || (p.flags & FLG_SEQBYSEQ) != 0 || restricted);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -602,7 +607,7 @@ SMG_HD inline void stage_hits(const Batch &b, const DevIndex &ix, const MapPar &
   P32 g_pfx = gt, g_poff = gt + tabn, g_qo = gt + 2 * tabn, g_len = gt + 3 * tabn, g_cur = gt + 4 * tabn;
   const HitInfoHdr hdr = b.hi[rs];
   const uint32_t n_use = hdr.seed_rank > 0 ? hdr.seed_rank : hdr.n_seeds;
-  bool mine = qlen >= (uint32_t)k && qlen < 256u && !b.iv_off && cands_v2_applicable(p, k, s, qlen) && n_use < tabn && W > tabn + 128u &&
+  bool mine = qlen >= (uint32_t)k && qlen < 256u && !b.iv_off && cands_v2_applicable(p, k, s, qlen, false) && n_use < tabn && W > tabn + 128u &&
               hits_lds_bytes(W, tabn) <= x.lds_bytes;
   if (!mine) { SMG_LANE0 { b.hitrun[rs] = run; } return; }
   int nhits_alloc, nhits_max;
@@ -863,7 +868,8 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     SMG_LANE0 { ch.ncand = ch.n_sort = ch.n_mincover = ch.max_cover = ch.max2nd_cover = 0; ch.cover_deficit[0] = ch.cover_deficit[1] = 0; ch.rc_off = 0; ch.err = 0; ch.err_site = 0; ch.nhits[0] = ch.nhits[1] = 0; ch.n_reserved = 0; }
     return 0;
   }
-  const uint32_t min_cover = (uint32_t)k;                         // (min_ktup - 1) * s + k with min_ktup == 1
+  uint32_t min_cover = read_min_cover(p, qlen);                   // calcMinKtup (rmap.c:240-247)
+  { const uint32_t min_ktup = (min_cover >= (uint32_t)(k + s)) ? (min_cover - (uint32_t)k) / (uint32_t)s : 1u; min_cover = (min_ktup - 1) * (uint32_t)s + (uint32_t)k; }
   const int mismatchdiff = p.match - p.mismatch;
   uint32_t mincov_below_max;
   if (p.below_max < 0) mincov_below_max = qlen - 1;

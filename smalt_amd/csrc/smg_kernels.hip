@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(64, WAVES) k_cands(Batch b, DevIndex ix, MapPa
     const uint32_t r = g.pass == 2 ? b.cands_retry[it] : it;
     uint8_t *base = gscratch + g.slot_bytes * (g.debug ? r : blockIdx.x);
     const DevIndex rix = read_index(b, ix, r);
-    if (cands_v2_applicable(p, rix.k, rix.s, read_len(b, r))) {
+    if (cands_v2_applicable(p, rix.k, rix.s, read_len(b, r), b.iv_off != nullptr)) {
       CandsV2Scratch x = cands_v2_carve(lds + LDS_GUARD, lds_bytes, base, b.qmax, rix.s, g.hcap_strand, g.ngrp, g.candcap, g.debug != 0);
       x.window = g.window; x.lds_hits = g.lds_hits; x.tab = g.tab; x.pass = g.pass;
       nhit += stage_cands_v2<LONGK, SPLIT>(b, rix, p, r, x, ph);

@@ -143,7 +143,7 @@ int main(int argc, char **argv) {
     SeedScratch sx = seed_scratch_carve(sscr.data(), qmax, ix.s);
     stage_seed(b, ix, p, r, 0, sx);
     stage_seed(b, ix, p, r, 1, sx);
-    if (cands_v2_applicable(p, ix.k, ix.s, len) && !(force && !strcmp(force, "v1"))) {
+    if (cands_v2_applicable(p, ix.k, ix.s, len, false) && !(force && !strcmp(force, "v1"))) {
       CandsV2Scratch c2 = cands_v2_carve(ldsmem.data(), ldsmem.size(), cscr.data() + cbytes * r, qmax, ix.s, hcap_strand, ngrp, candcap, true);
       c2.window = window;
       unsigned long long ph[16] = {0};
@@ -193,7 +193,7 @@ int main(int argc, char **argv) {
     for (int st = 0; st < 2; st++) { v.hi[st] = hi[2 * r + st]; v.seeds[st] = seeds.data() + (size_t)(2 * r + st) * qmax; v.qmask[st] = qmask.data() + (size_t)(2 * r + st) * qmax; }
     v.ch = ch[r]; v.rc = rcpool.data() + ch[r].rc_off;
     v.ctl = ctl[r]; v.st = stat[r]; v.res = respool.data() + stat[r].res_off; v.dstr = dstrpool.data() + stat[r].dstr_off; v.ngrp = ngrp;
-    if (cands_v2_applicable(p, ix.k, ix.s, v.qlen) && !(force && !strcmp(force, "v1"))) {
+    if (cands_v2_applicable(p, ix.k, ix.s, v.qlen, false) && !(force && !strcmp(force, "v1"))) {
       CandsV2Scratch c2 = cands_v2_carve(nullptr, 0, cscr.data() + cbytes * r, qmax, ix.s, hcap_strand, ngrp, candcap, true);
       cands_v2_records(crec, c2, v.ch.ncand <= candcap ? v.ch.ncand : 0, v.qlen > 255); v.cand = crec.data(); v.sort_idx = c2.sort_idx; v.sort_keys = c2.sort_keys; v.hitwords = c2.dbg_words; v.grp_first = c2.dbg_first; v.grp_cnt = c2.dbg_cnt;
     } else { v.cand = cx.cand; v.sort_idx = cx.sort_idx; v.sort_keys = cx.sort_keys; v.hitwords = cx.keys; v.grp_first = cx.grp_first; v.grp_cnt = cx.grp_cnt; }

@@ -145,6 +145,9 @@ def _pair_data(tmp, nchr, chrlen, npairs, rlen, seed, rep=0.3, ins=(300, 30)):
     (13, 6, 3, 300_000, 100, (300, 30), ["-f", "cigar", "-i", "500", "-n", "3", "-O", "-r", "-1"]),   # worker threads
     (13, 6, 600, 2_000, 100, (300, 30), ["-f", "sam", "-i", "500"]),                            # >= 512 reference sequences: concatenated mode
     (13, 6, 2, 250_000, 100, (300, 30), ["-f", "cigar", "-i", "500", "-x"]),                    # exhaustive search (long hit info for both mates)
+    (13, 6, 2, 250_000, 100, (300, 30), ["-f", "cigar", "-i", "500", "-x", "-c", "0.4"]),       # cover threshold (fraction of each mate) in all four rounds
+    (13, 6, 3, 300_000, 150, (300, 30), ["-f", "sam", "-i", "500", "-x", "-c", "45"]),          # cover threshold in bases (the reference accepts -c with -x only)
+    (13, 6, 600, 2_000, 100, (300, 30), ["-f", "cigar", "-i", "500", "-x", "-c", "0.5"]),       # cover threshold in concatenated mode: plain rounds take the sequential candidate stage
 ])
 def test_smalt_map_pairs_prints_the_same(k, s, nchr, chrlen, rlen, ins, opts, tmp_path):
     """Paired reads: rmapPair's rounds (rare mate, restricted mate, unrestricted re-map, re-map over the on-the-fly k=5 index)
