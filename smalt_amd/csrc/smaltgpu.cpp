@@ -471,6 +471,7 @@ extern "C" int smaltgpu_mapper_create_ex(smaltgpu_mapper **out, const smaltgpu_i
     b.work = (unsigned long long *)(m->d_counters + 64);
     b.hit_count = (unsigned long long *)(m->d_counters + 328);
     b.hits_cursor = (uint32_t *)(m->d_counters + 336);
+    b.strip_cursor = (uint32_t *)(m->d_counters + 340);
   }
   // scratch geometry -------------------------------------------------------------------
   m->seed_bytes = (seed_scratch_bytes(m->qmax, d.s) + 255) & ~(size_t)255;
@@ -555,8 +556,9 @@ extern "C" int smaltgpu_mapper_create_ex(smaltgpu_mapper **out, const smaltgpu_i
   DA(m->sw_rows, (size_t)m->sw_threads * 2 * m->sw_rowlen);
   {
     m->wincap = 4 * m->qmax + 1024;
-    m->strip_grid = 2048;
-    if ((uint64_t)m->strip_grid * m->wincap * 18 > (4ull << 30)) m->strip_grid = (uint32_t)((4ull << 30) / ((uint64_t)m->wincap * 18));
+    m->strip_grid = 5120;                              // workgroups (one wave each) of the strip kernels: five per SIMD (96 registers); 2048: 5.2, 4096: 6.0, 5120: 6.2 TCUPS at 8 kbp
+    if (const char *e = getenv("SMALTGPU_STRIP_GRID")) { const long v = atol(e); if (v >= 64 && v <= 16384) m->strip_grid = (uint32_t)v; }   // tuning hook
+    if ((uint64_t)m->strip_grid * m->wincap * 18 > (8ull << 30)) m->strip_grid = (uint32_t)((8ull << 30) / ((uint64_t)m->wincap * 18));
     if (!rv) rv = dalloc((uint8_t **)&m->strip_bnd, (size_t)m->strip_grid * 2 * m->wincap * 8);
     DA(m->strip_win, (size_t)m->strip_grid * m->wincap * 2);      // code pairs of the packed strip kernel
     m->dircap = (uint64_t)(m->qmax + 64) * (m->wincap + 8);

@@ -917,7 +917,10 @@ __global__ void __launch_bounds__(64) k_sw_strip16(Batch b, DevIndex ix, MapPar 
   uint2 *bnd = bnd_all + (size_t)blockIdx.x * 2 * wcap;
   uint16_t *win = win_all + (size_t)blockIdx.x * wcap;
   unsigned long long cells = 0, ntasks_done = 0;
-  for (uint32_t tp = blockIdx.x; tp < npair; tp += gridDim.x) {
+  __shared__ uint32_t qslot;
+  // pairs from a cursor, not by a static stride: windows of 8 kbp reads differ in length, and the launch has more workgroups
+  // than are resident at a time
+  for (uint32_t tp = next_item(b.strip_cursor, &qslot); tp < npair; tp = next_item(b.strip_cursor, &qslot)) {
     RCand c[2];
     bool live[2] = {false, false};
     uint32_t qlen[2] = {0, 0}, wlen[2] = {0, 0}, tix[2] = {0, 0};

@@ -44,6 +44,7 @@ struct Batch {                          // one block of reads resident in HBM
   Result *respool; uint64_t rescap; unsigned long long *res_count;
   uint8_t *dstrpool; uint64_t dstrcap; unsigned long long *dstr_count;
   int32_t *err_flag;                    // batch-wide first error
+  uint32_t *strip_cursor;               // work-queue cursor of the packed strip kernel (pairs of strip-list entries)
   uint32_t *next_item;                  // [5] work-queue cursors of the persistent kernels (seed, cands, align, align pass 2, cands pass 2)
   uint32_t *align_retry, *align_retry_n; // reads the first K3 pass deferred to the second one (SMG_ERR_RETRY), and how many
   uint32_t *cands_retry, *cands_retry_n; // the same for the candidate stage (reads whose hits overflow a first-pass slot)
