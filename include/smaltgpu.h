@@ -145,6 +145,9 @@ typedef struct smaltgpu_mapper_opts {
 int smaltgpu_mapper_create_ex(smaltgpu_mapper **out, const smaltgpu_index *ix, uint32_t max_batch_reads,
                               uint32_t max_read_len, const smaltgpu_mapper_opts *opts);
 void smaltgpu_mapper_free(smaltgpu_mapper *m);
+/* host threads a mapper may use for its own host work (the copy of a batch's results into read order in smaltgpu_fetch_end);
+ * default 1 -- the reference's worker owns one thread (threads.c).  smaltgpu_map_pairs sets it from pair_opts.nthreads. */
+int smaltgpu_mapper_set_host_threads(smaltgpu_mapper *m, int nthreads);
 
 /* Map a block of reads (the unit processArgBlock smalt.c:1221 hands to a worker).  `bases`:
  * concatenated ASCII reads, `quals`: concatenated phred+33 or NULL, `read_off`: nreads+1

@@ -10,6 +10,7 @@
 #include <string.h>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/smaltgpu.h"
 #include "smg_dump.hpp"
@@ -362,6 +363,7 @@ struct smaltgpu_mapper {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
   };
   DevBuf cx_ivoff, cx_iv, cx_minsw, cx_prevmax, cx_fineidx, cx_finepos, cx_fineoff, cx_alloclen;
+  int host_threads = 1;                      // smaltgpu_mapper_set_host_threads
   bool history = false;                      // serial-order mode (smaltgpu_mapper_set_history)
   uint32_t hist_longest = 0;                 // longest read of length >= k of the run so far
   std::vector<uint32_t> h_alloclen;
@@ -768,22 +770,38 @@ extern "C" int smaltgpu_fetch_end(smaltgpu_mapper *m, smaltgpu_batch_out *out) {
   uint64_t w = 0;
   int first_err = 0;
   uint32_t first_err_read = 0, nerr = 0;
-  for (uint32_t i = 0; i < n; i++) {
+  for (uint32_t i = 0; i < n; i++) {                       // where each read's results go (reads finish in any order on the device)
     const ReadStat &st = m->h_stat[i];
     m->h_res_off[i] = w;
-    smaltgpu_readstat &os = m->o_stat[i];
-    os.swatscor_max = st.swmax; os.swatscor_2ndmax = st.sw2nd; os.n_ali_done = st.nseg; os.n_ali_tot = st.nseg_tot;
-    os.n_hits_used = st.nhit; os.n_hits_tot = st.nhit_tot; os.errcode = st.err; os.nres = st.nres; os.max1scor = st.max1; os.errsite = st.err_site;
+    w += st.nres;
     if (st.err) { if (!first_err) { first_err = st.err; first_err_read = i; } nerr++; }
-    for (uint32_t j = 0; j < st.nres; j++) {
-      const Result &r = m->h_res[st.res_off + j];
-      smaltgpu_result &o = m->o_res[w++];
-      o.swatscor = r.swatscor; o.q_start = r.q_start; o.q_end = r.q_end; o.s_start = r.s_start; o.s_end = r.s_end;
-      o.sidx = r.sidx; o.reverse = (r.reverse ? SMALTGPU_RES_REVERSE : 0u) | (r.pad ? SMALTGPU_RES_CANDFIRST : 0u);
-      o.stroffs = (uint32_t)(st.dstr_off + r.stroffs); o.strlen = r.strlen;
-    }
   }
   m->h_res_off[n] = w;
+  auto copy_range = [m](uint32_t lo, uint32_t hi) {
+    for (uint32_t i = lo; i < hi; i++) {
+      const ReadStat &st = m->h_stat[i];
+      smaltgpu_readstat &os = m->o_stat[i];
+      os.swatscor_max = st.swmax; os.swatscor_2ndmax = st.sw2nd; os.n_ali_done = st.nseg; os.n_ali_tot = st.nseg_tot;
+      os.n_hits_used = st.nhit; os.n_hits_tot = st.nhit_tot; os.errcode = st.err; os.nres = st.nres; os.max1scor = st.max1; os.errsite = st.err_site;
+      uint64_t at = m->h_res_off[i];
+      for (uint32_t j = 0; j < st.nres; j++) {
+        const Result &r = m->h_res[st.res_off + j];
+        smaltgpu_result &o = m->o_res[at++];
+        o.swatscor = r.swatscor; o.q_start = r.q_start; o.q_end = r.q_end; o.s_start = r.s_start; o.s_end = r.s_end;
+        o.sidx = r.sidx; o.reverse = (r.reverse ? SMALTGPU_RES_REVERSE : 0u) | (r.pad ? SMALTGPU_RES_CANDFIRST : 0u);
+        o.stroffs = (uint32_t)(st.dstr_off + r.stroffs); o.strlen = r.strlen;
+      }
+    }
+  };
+  int nt = m->host_threads;
+  if ((uint32_t)nt > n / 8192 + 1) nt = (int)(n / 8192 + 1);
+  if (nt <= 1) copy_range(0, n);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(copy_range, (uint32_t)((uint64_t)n * t / nt), (uint32_t)((uint64_t)n * (t + 1) / nt));
+    copy_range(0, (uint32_t)((uint64_t)n / nt));
+    for (std::thread &x : th) x.join();
+  }
   out->nreads = n; out->res_off = m->h_res_off.data(); out->res = m->o_res.data(); out->diffstr = m->h_dstr.data(); out->stat = m->o_stat.data();
   if (first_err) return fail(first_err, "%u of %u reads hit a device-side limit (-5%s) or assertion (-6); first: read %u code %d (see stat[].errcode)", nerr, n,
                              m->pool_overflow ? ": a batch-wide work pool overflowed" : "", first_err_read, first_err);
@@ -1040,6 +1058,12 @@ extern "C" int smaltgpu_map_batch_ctx(smaltgpu_mapper *m, const uint8_t *bases, 
   rv = map_range(m, bases, quals, read_off, nreads, par, out, ctx);
   if (rv == SMALTGPU_ECAP && out->nreads == nreads && nreads > 0 && !m->debug) return remap_overflowed(m, bases, quals, read_off, nreads, par, out, ctx);
   return rv;
+}
+
+extern "C" int smaltgpu_mapper_set_host_threads(smaltgpu_mapper *m, int nthreads) {
+  if (!m) return fail(SMALTGPU_EARG, "null mapper");
+  m->host_threads = nthreads < 1 ? 1 : (nthreads > 64 ? 64 : nthreads);
+  return SMALTGPU_OK;
 }
 
 extern "C" int smaltgpu_mapper_set_history(smaltgpu_mapper *m, int on) {

@@ -338,7 +338,7 @@ int main(int argc, char **argv) {
         const uint32_t cr = b.v.nreads > (uint32_t)batch ? b.v.nreads : (uint32_t)batch, cl = (b.maxlen + 31u) & ~31u;
         smaltgpu_mapper_opts mo = {0, (uint32_t)(per_dev <= 2 ? 28 : 18)};      // the mappers of a device share its memory: candidate slots of 18-28 GB each
         if (smaltgpu_mapper_create_ex(&W.mp, ixs[(size_t)(w % ndev)], cr, cl > W.cap_len ? cl : W.cap_len, &mo)) err = why("cannot create a mapper");
-        else { W.cap_reads = cr; W.cap_len = cl > W.cap_len ? cl : W.cap_len; }
+        else { W.cap_reads = cr; W.cap_len = cl > W.cap_len ? cl : W.cap_len; if (!paired) smaltgpu_mapper_set_host_threads(W.mp, nthreads > 4 ? nthreads / 4 : 1); }
       }
       t1 = now(); t_create[w] += t1 - t0; t0 = t1;
       if (err.empty() && paired) {

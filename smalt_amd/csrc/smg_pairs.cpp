@@ -18,6 +18,7 @@ struct DeviceExec {
   uint32_t cap_reads;
   uint64_t cap_bases;
   const smaltgpu_resident_reads *resident = nullptr;      // the block's reads in HBM: rounds are gathered on the device
+  int nthreads = 1;                                       // host threads for the gather of a round's reads
   std::vector<uint8_t> bases, quals;
   std::vector<uint64_t> off;
   double ms[4] = {0, 0, 0, 0};
@@ -38,12 +39,14 @@ struct DeviceExec {
     off[n] = tot;
     bases.resize(tot + 1);
     if (with_quals()) quals.resize(tot + 1);
-    for (uint32_t i = 0; i < n; i++) {
-      const uint32_t w = ids[i] & 1, p = ids[i] >> 1;
-      const uint64_t len = off[i + 1] - off[i];
-      memcpy(bases.data() + off[i], in.bases[w] + in.off[w][p], len);
-      if (with_quals()) memcpy(quals.data() + off[i], in.quals[w] + in.off[w][p], len);
-    }
+    PairBlock::spread(n, nthreads, [&](uint32_t lo, uint32_t hi, int) {
+      for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t w = ids[i] & 1, p = ids[i] >> 1;
+        const uint64_t len = off[i + 1] - off[i];
+        memcpy(bases.data() + off[i], in.bases[w] + in.off[w][p], len);
+        if (with_quals()) memcpy(quals.data() + off[i], in.quals[w] + in.off[w][p], len);
+      }
+    });
   }
   bool fail_with(std::string &err, int code) { rc = code; err = smaltgpu_last_error(); if (err.empty()) err = "the device call failed without a message"; return false; }
   double totals_wall = 0;
@@ -126,11 +129,14 @@ static int map_pairs(smaltgpu_mapper *m, const smaltgpu_resident_reads *resident
   memset(out->kernel_ms, 0, sizeof(out->kernel_ms)); memset(out->work, 0, sizeof(out->work));
   DeviceExec ex{m, in, bp.map, cap_reads, cap_bases};
   ex.resident = resident;
+  ex.nthreads = bp.nthreads;
+  smaltgpu_mapper_set_host_threads(m, bp.nthreads);        // the copy of a round's results into read order (smaltgpu_fetch_end)
   memset(ex.kernel_ms, 0, sizeof(ex.kernel_ms)); memset(ex.work, 0, sizeof(ex.work));
   const bool ok = out->blk.run(ex, in, bp);
   for (int r = 0; r < 4; r++) { out->round_ms[r] = ex.ms[r]; out->calls[r] = out->blk.nrounds.size() == 4 ? out->blk.nrounds[(size_t)r] : 0; }
   memcpy(out->kernel_ms, ex.kernel_ms, sizeof(out->kernel_ms)); memcpy(out->work, ex.work, sizeof(out->work));
   out->totals_ms = ex.totals_wall;
+  smaltgpu_mapper_set_host_threads(m, 1);
   if (!ok) return smaltgpu_set_error(ex.rc != SMALTGPU_OK ? ex.rc : SMALTGPU_EINTERNAL, ("smaltgpu_map_pairs: " + out->blk.error).c_str());
   // the summary: flags, rounds, surviving alignments
   out->info.assign(npairs ? npairs : 1, smaltgpu_pair_info());
