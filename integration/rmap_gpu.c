@@ -33,6 +33,7 @@ extern int resultSetAppendRaw(ResultSet *rsp, unsigned n, const smaltgpu_result 
                               int swatscor_max, int swatscor_2ndmax);
 
 enum { GPU_MAXMAPPERS = 256 };
+static int g_max_intervals = 2048;              /* search intervals a restricted device call takes per read (SMALTGPU_MAX_INTERVALS lowers it: test hook) */
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 enum { GPU_MAXDEV = 16 };
 static smaltgpu_index *g_ixdev[GPU_MAXDEV];      /* one index image per device, shared by the mappers on it */
@@ -49,6 +50,8 @@ static struct {
   smaltgpu_post *post; smaltgpu_post_out pout; int have_post;   /* result post-processing of the last batch by the library (N1) */
   uint64_t *sop; int64_t nseq;
   struct GpuPair_ *pairs; int npairs, cap_pairs; /* paired blocks (rmapGpuPairBatch): per-pair state incl. its own two ResultSets */
+  struct { int ktuple_maxhit, min_swatscor; double tupcovmin; UCHAR min_basqval; short target_depth, max_depth; RMAPFLG_t rmapflg;
+           const ScoreMatrix *scormtxp; const HashTable *htp; const SeqSet *ssp; const SeqCodec *codecp; } pair_args;   /* for pairs left to the CPU */
   ResultSet *save_rsr, *save_rsm;
 } g_map[GPU_MAXMAPPERS];
 static int g_nmap = 0;
@@ -60,9 +63,13 @@ enum { TM_STAGE, TM_GPU, TM_POST, TM_INJECT, TM_REFPOST, TM_FILTER, TM_N };
 static double g_tm[GPU_MAXMAPPERS][TM_N], g_t_ready = 0.0;      /* g_t_ready: the index images are on the devices */
 static const char *const TM_NAME[TM_N] = {"stage", "gpu_wait", "lib_post", "inject", "ref_post", "filter"};
 static double tmNow(void) { struct timespec ts; if (!g_timing) return 0.0; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+static int g_most_intervals = 0;                /* largest number of search intervals any read had (diagnostic, under g_lock) */
+static long g_pairs_on_cpu = 0;                 /* pairs beyond the interval limit, mapped by the reference's rmapPair (counted under g_lock) */
 static void tmReport(void)
 {
   int i, j;
+  fprintf(stderr, "smaltgpu timing: pairs left to the reference's rmapPair (more search intervals than a device call takes): %ld\n", g_pairs_on_cpu);
+  fprintf(stderr, "smaltgpu timing: most search intervals of a read: %d\n", g_most_intervals);
   fprintf(stderr, "smaltgpu timing: window    %8.3f s from the index being resident to exit\n", tmNow() - g_t_ready);
   for (j = 0; j < TM_N; j++) { double t = 0.0; for (i = 0; i < g_nmap; i++) t += g_tm[i][j]; fprintf(stderr, "smaltgpu timing: %-9s %8.3f thread-s over %d workers\n", TM_NAME[j], t, g_nmap); }
 }
@@ -76,6 +83,7 @@ static void gpuReadConfig(void)
   g_libpost = !getenv("SMALTGPU_REF_POST");
   g_prefix = getenv("SMALTGPU_INDEX_PREFIX");
   if (getenv("SMALTGPU_TIMING")) { g_timing = 1; atexit(tmReport); }
+  if (getenv("SMALTGPU_MAX_INTERVALS") && atoi(getenv("SMALTGPU_MAX_INTERVALS")) > 0 && atoi(getenv("SMALTGPU_MAX_INTERVALS")) < g_max_intervals) g_max_intervals = atoi(getenv("SMALTGPU_MAX_INTERVALS"));
   g_nphys = g_ndev = smaltgpu_device_count();
   if (e && atoi(e) > 0) g_ndev = atoi(e);        /* more than there are GPUs: images share devices (rehearsal of the N-device path on one GPU) */
   if (g_ndev > GPU_MAXDEV) g_ndev = GPU_MAXDEV;
@@ -351,6 +359,7 @@ typedef struct GpuPair_ {
   unsigned char lone, lone_w;  /* exactly one mate (lone_w) is long enough: it is mapped alone */
   int fpp_err;                 /* return code of resultSetFindProperPairs (rmap.c:1956-1961, :2050) */
   unsigned char need_c, need_d;
+  unsigned char on_cpu;        /* more search intervals than a restricted device call takes: the reference's own rmapPair maps this pair */
   RSLTPAIRFLG_t pairflg;
   int mapq1, swscor1, swscor2_restricted, n_proper, minsw_d;
 } GpuPair;
@@ -481,6 +490,11 @@ int rmapGpuPairBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, SeqFast
   if (tupcovmin < 1.01) { par.min_cover = 0; par.min_cover_frac = tupcovmin; }      /* smalt.c:1113-1147: per read and per mate */
   else { par.min_cover = (uint32_t)tupcovmin; par.min_cover_frac = 0.0; }
 
+  g_map[slot].pair_args.ktuple_maxhit = ktuple_maxhit; g_map[slot].pair_args.min_swatscor = min_swatscor; g_map[slot].pair_args.tupcovmin = tupcovmin;
+  g_map[slot].pair_args.min_basqval = min_basqval; g_map[slot].pair_args.target_depth = target_depth; g_map[slot].pair_args.max_depth = max_depth;
+  g_map[slot].pair_args.rmapflg = rmapflg; g_map[slot].pair_args.scormtxp = scormtxp; g_map[slot].pair_args.htp = htp; g_map[slot].pair_args.ssp = ssp;
+  g_map[slot].pair_args.codecp = codecp;
+
   /* ---- which mate first: k-mer hit totals of all 2n reads (rmap.c:1866-1905) ---- */
   for (i = 0; i < n; i++) {
     GpuPair *pp = pairs + i;
@@ -490,7 +504,7 @@ int rmapGpuPairBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, SeqFast
       resultSetBlank(pp->rs[w]);
     }
     pp->sq[0] = reads[i]; pp->sq[1] = mates[i];
-    pp->pairflg = RSLTPAIRFLG_PAIRED; pp->first = 0; pp->skip = pp->lone = pp->need_c = pp->need_d = 0;
+    pp->pairflg = RSLTPAIRFLG_PAIRED; pp->first = 0; pp->skip = pp->lone = pp->need_c = pp->need_d = pp->on_cpu = 0;
     pp->mapq1 = pp->swscor1 = pp->swscor2_restricted = pp->n_proper = pp->minsw_d = pp->fpp_err = 0;
     all[2 * i] = reads[i]; all[2 * i + 1] = mates[i];
   }
@@ -525,6 +539,11 @@ int rmapGpuPairBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, SeqFast
     if ((errcode = setupInterValFromResultSet(rmp->ivr, d_min, d_max, pp->sq[w], pp->sq[!w], htp, ssp, pp->rs[w]))) ERRMSGNO(errmsgp, errcode);
     interValPrune(rmp->ivr);
     nv = interValNum(rmp->ivr);
+    /* The interval number has 11 bits in the hit sort key of a restricted device call (2048 intervals -- one per alignment of
+     * the first mate up to the maximum depth; the reference has no limit, interval.c:98-121, and split alignments can add some).  A pair beyond that is not an error of the block: it takes part in the round with an empty
+     * restriction and rmapGpuPairFinish maps it with the reference's own rmapPair on this worker's thread. */
+    if (g_timing && nv > g_most_intervals) { pthread_mutex_lock(&g_lock); if (nv > g_most_intervals) g_most_intervals = nv; pthread_mutex_unlock(&g_lock); }
+    if (nv > g_max_intervals) { pp->on_cpu = 1; nv = 0; }
     iv_off[i] = niv;
     if (niv + (size_t)nv > cap_iv) { cap_iv = 2 * (niv + (size_t)nv) + 64; if (!(iv = realloc(iv, cap_iv * sizeof(*iv)))) ERRMSGNO(errmsgp, ERRCODE_NOMEM); }
     for (v = 0; v < nv; v++) {
@@ -545,6 +564,7 @@ int rmapGpuPairBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, SeqFast
   for (i = 0; i < ns; i++) {
     GpuPair *pp = pairs + sel[i];
     const int w2 = !pp->first;
+    if (pp->on_cpu) continue;
     errcode = resultSetFindProperPairs(rmp->pairp, d_min, d_max, MAXNUM_PAIRS_TOTAL, 0, pairlibcode, pp->rs[0], pp->rs[1]);
     if ((errcode) && errcode != ERRCODE_PAIRNUM) ERRMSGNO(errmsgp, errcode);
     pp->fpp_err = errcode;
@@ -591,6 +611,7 @@ int rmapGpuPairBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, SeqFast
       (void)seqFastqGetConstSequence(pp->sq[w1], &rlen, NULL);
       if (ktup > rlen) continue;
       nv = interValNum(rmp->ivr);
+      if (nv > g_max_intervals) { pp->on_cpu = 1; continue; }      /* as in round B: the reference's rmapPair takes the pair */
       iv_off[nd] = niv;
       if (niv + (size_t)nv > cap_iv) { cap_iv = 2 * (niv + (size_t)nv) + 64; if (!(iv = realloc(iv, cap_iv * sizeof(*iv)))) ERRMSGNO(errmsgp, ERRCODE_NOMEM); }
       for (v = 0; v < nv; v++) {
@@ -628,6 +649,20 @@ int rmapGpuPairFinish(ErrMsg *errmsgp, RMap *rmp, int i, RSLTPAIRFLG_t *pairflgp
   if ((slot = gpuMapperForBatch(rmp, 1, 1, 1, 0)) < 0 || i < 0 || i >= g_map[slot].npairs) ERRMSGNO(errmsgp, ERRCODE_ASSERT);
   pp = g_map[slot].pairs + i;
   rmapBlank(rmp);
+  if (pp->on_cpu) {                 /* the whole pair by the reference's own code, into the RMap's own sets (nothing to release) */
+    uint32_t len[2], cov[2];
+    int w;
+    pthread_mutex_lock(&g_lock); g_pairs_on_cpu++; pthread_mutex_unlock(&g_lock);
+    for (w = 0; w < 2; w++) {       /* cover thresholds per mate as processMapArgs derives them (smalt.c:1115-1147) */
+      (void)seqFastqGetConstSequence(pp->sq[w], &len[w], NULL);
+      if (g_map[slot].pair_args.tupcovmin < 1.01) { cov[w] = (uint32_t)(g_map[slot].pair_args.tupcovmin * len[w]); if (cov[w] > len[w]) cov[w] = len[w]; }
+      else cov[w] = (uint32_t)g_map[slot].pair_args.tupcovmin;
+    }
+    return rmapPair(errmsgp, rmp, pp->sq[0], pp->sq[1], pairflgp, d_min, d_max, pairlibcode, g_map[slot].pair_args.ktuple_maxhit, cov[0], cov[1],
+                    g_map[slot].pair_args.min_swatscor, g_map[slot].pair_args.min_basqval, g_map[slot].pair_args.target_depth, g_map[slot].pair_args.max_depth,
+                    g_map[slot].pair_args.rmapflg, g_map[slot].pair_args.scormtxp, rsfp, g_map[slot].pair_args.htp, g_map[slot].pair_args.ssp,
+                    g_map[slot].pair_args.codecp);
+  }
   g_map[slot].save_rsr = rmp->rsrp; g_map[slot].save_rsm = rmp->rsmp;
   rmp->rsrp = pp->rs[0]; rmp->rsmp = pp->rs[1];
   *pairflgp = pp->pairflg;

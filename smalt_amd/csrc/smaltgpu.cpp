@@ -830,7 +830,7 @@ static int upload_ctx(smaltgpu_mapper *m, const smaltgpu_callctx *ctx, uint32_t 
     for (uint32_t i = 0; i <= n; i++) m->h_ivoff[i] = (uint32_t)(ctx->iv_off[i] - i0);
     for (uint32_t i = 0; i < n; i++) {
       uint64_t npos = 0;
-      // (a read with more than IV_MAX = 2047 intervals is not an error of the batch: the candidate stage gives that read
+      // (a read with more than IV_MAX = 2048 intervals is not an error of the batch: the candidate stage gives that read
       //  SMALTGPU_ECAP in its stat and every other read is mapped)
       for (uint64_t v = ctx->iv_off[i]; v < ctx->iv_off[i + 1]; v++) {
         const smaltgpu_interval &iv = ctx->iv[v];

@@ -163,7 +163,8 @@ struct ReadStat {
 struct IvRec { int32_t sx; uint32_t lo, hi; };
 enum : int { FINE_K = 5, FINE_S = 1,              // the on-the-fly index of the rescue round (rmap.c:91-92)
              FINE_NKEYS = 1 << (2 * FINE_K), FINE_IDX_STRIDE = FINE_NKEYS + 8,
-             IV_MAX = (1 << 11) - 1 };            // intervals per read: the interval number takes the sequence field of the hit sort key and the bit above it
+             IV_MAX = 1 << 11 };                  // intervals per read: the interval number (0 .. 2047) takes the sequence field of the hit sort key and the bit above it;
+                                                   // rmapPair makes one interval per alignment of the mate mapped first (rmap.c:354-436), i.e. up to max_depth = 2048
                                                   // (KEY_SEQBITS + 1 = 11 bits: the wave-parallel candidate stage keeps the strands apart, so bit 63 is free there)
 
 }  // namespace smg
