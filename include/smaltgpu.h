@@ -175,6 +175,11 @@ typedef struct smaltgpu_callctx {
                                   * (rmap.c:881-885); stat[].swatscor_max / _2ndmax return the pair after the call */
   int32_t fine_index;            /* != 0: seed against the on-the-fly index of each read's intervals (needs iv_off);
                                   * hit info is collected in the long form (initRMAPINFO, rmap.c:2024) */
+  int32_t raw_alignments;        /* != 0: return every alignment of the call, candidate by candidate (SMALTGPU_RES_CANDFIRST marks the first
+                                  * of each), without resultSetAddFromAli's duplicate handling (results.c:1906-1935: an alignment that
+                                  * repeats the one before it is taken off again, and the alignment after it is lost).  For calls that
+                                  * append to a non-empty ResultSet: the first comparison is with the set's last alignment, which only
+                                  * the caller has (smgpost::Table::take_call; resultSetAppendRaw in integration/results_inject.c) */
   const uint32_t *hitlist_len;   /* per read, or NULL: length of the longest read that the reference's hit list has held up to and
                                   * including this call.  The list's capacity only grows (initHitList, hashhit.c:1280-1282) and decides
                                   * where the allocation-boundary protocol sets in (hashhit.c:1497), so a serial `smalt map` over reads

@@ -147,6 +147,7 @@ static void run_batch(struct CombSlot *d, const smaltgpu_index *ix, CombReq **re
         if (c0->minsw) ctx.min_swatscor = d->minsw;
         if (c0->prevmax) ctx.prev_max = d->prevmax;
         ctx.fine_index = c0->kind == GPUCOMB_FINE;
+        ctx.raw_alignments = c0->kind == GPUCOMB_APPEND || c0->kind == GPUCOMB_FINE;      /* these append to sets that hold alignments: resultSetAppendRaw compares */
         if (c0->kind == GPUCOMB_TOTALS) {
           rv = smaltgpu_hit_totals(d->mp, (const uint8_t *)d->bases, has_qual ? (const uint8_t *)d->quals : NULL, d->off, ntot, reqs[0]->par, d->tot);
           for (i = 0, k = 0; i < nreq && !rv; i++) { memcpy(reqs[i]->ctx->tot_out, d->tot + k, (size_t)reqs[i]->n * sizeof(uint32_t)); k += reqs[i]->n; }

@@ -41,28 +41,60 @@ int resultSetInjectRaw(ResultSet *rsp, unsigned n, const smaltgpu_result *res, c
   return ERRCODE_SUCCESS;
 }
 
-/* A mapSingleRead call of rmapPair that APPENDS to a ResultSet (rmap.c:1976-1989, :2019-2039).  `res` are the alignments
- * of the call as the library returns them for a fresh set, `swatscor_max/2ndmax` the set's running maxima after the call
- * (the library was given the maxima before it, smaltgpu_callctx.prev_max).  resultSetAddFromAli (results.c:1852-1942)
- * compares the first alignment of a candidate with the set's last one: if it repeats it, it is popped, and what the same
- * call writes after a popped slot is lost (the array length is not advanced again) -- SMALTGPU_RES_CANDFIRST marks where the
- * next candidate's alignments begin.  Within the call itself the library has applied the same rule already. */
+/* A mapSingleRead call of rmapPair that APPENDS to a ResultSet (rmap.c:1976-1989, :2019-2039).  `res` are ALL alignments of
+ * the call, candidate by candidate (smaltgpu_callctx.raw_alignments; SMALTGPU_RES_CANDFIRST marks the first of each),
+ * `swatscor_max/2ndmax` the set's running maxima after the call (the library was given the maxima before it,
+ * smaltgpu_callctx.prev_max).  They go into the set the way resultSetAddFromAli (results.c:1852-1942) puts a candidate's
+ * alignments there, on the set's own array, so that its slots -- also the ones outside the array's length -- hold what they
+ * hold in the reference: a candidate opens the next slot; an alignment equal to the slot before it gives the slot back and
+ * stays open, anything else is completed and the next alignment opens the slot behind the array's end (after a repeat: the
+ * same slot again, so the alignment behind a repeat is lost). */
 int resultSetAppendRaw(ResultSet *rsp, unsigned n, const smaltgpu_result *res, const unsigned char *dstr,
                        int swatscor_max, int swatscor_2ndmax)
 {
-  unsigned first = 0;
-  const size_t nold = ARRLEN(rsp->resr);
-  if (n > 0 && nold > 0) {
-    const Result *lp = rsp->resr + nold - 1;
-    if ((SEQLEN_t)res[0].s_start == lp->s_start && (SEQLEN_t)res[0].s_end == lp->s_end && res[0].q_start == lp->q_start &&
-        res[0].q_end == lp->q_end && res[0].swatscor == lp->swatscor && res[0].sidx == lp->sidx)        /* isIdenticalResult, results.c:556 */
-      for (first = 1; first < n && !(res[first].reverse & SMALTGPU_RES_CANDFIRST); first++);
+  unsigned i = 0;
+  while (i < n) {
+    unsigned t, j = i + 1;
+    int stays = 0, errcode;
+    Result *slot;
+    while (j < n && !(res[j].reverse & SMALTGPU_RES_CANDFIRST)) j++;
+    ARRNEXTP(slot, rsp->resr);
+    if (!slot) return ERRCODE_NOMEM;
+    BLANK_RESULT(slot);
+    slot->status = 0;
+    rsp->status = 0;
+    for (t = i; t < j; t++) {
+      const smaltgpu_result *a = res + t;
+      if (stays) {
+        ARRNEXTP(slot, rsp->resr);
+        if (!slot) return ERRCODE_NOMEM;
+        slot->status = 0;
+      }
+      slot->swatscor = a->swatscor;
+      slot->q_start = a->q_start; slot->q_end = a->q_end;
+      slot->s_start = (SEQLEN_t)a->s_start; slot->s_end = (SEQLEN_t)a->s_end;
+      slot->sidx = a->sidx;
+      slot->swrank = 0;
+      if (a->sidx == RESULTSET_UNKNOWN_SEQIDX) slot->status |= RSLTFLAG_NOSEQID;
+      stays = ARRLEN(rsp->resr) < 2 || !isIdenticalResult(slot, slot - 1);
+      if (stays) {
+        DiffStr view;
+        slot->stroffs = DIFFSTR_LENGTH(rsp->diffstrp);
+        slot->strlen = (int)a->strlen;
+        memset(&view, 0, sizeof(view));
+        view.dstrp = (DIFFSTR_T *)(dstr + a->stroffs);
+        view.len = (int)a->strlen;
+        if ((errcode = diffStrAppend(rsp->diffstrp, &view))) return errcode;
+        slot->status |= RSLTFLAG_SELECT;
+        if (a->reverse & SMALTGPU_RES_REVERSE) slot->status |= RSLTFLAG_REVERSE;
+        slot->mapscor = 0;
+        slot->rsltx = RSLTX_INITVAL;
+        slot->qsegx = QSEGX_INITVAL;
+      } else if (--ARRLEN(rsp->resr) == 0) rsp->status = 0;
+    }
+    i = j;
   }
-  if (first < n) {
-    const int errcode = resultSetInjectRaw(rsp, n - first, res + first, dstr, swatscor_max, swatscor_2ndmax);
-    if (errcode) return errcode;
-  } else if (n > 0) rsp->status = 0;
-  rsp->swatscor_max = swatscor_max;          /* also what alignments that were popped again raised (results.c:1918) */
+  rsp->swatscor_max = swatscor_max;          /* also what alignments that were lost again raised (results.c:1918) */
   rsp->swatscor_2ndmax = swatscor_2ndmax;
   return ERRCODE_SUCCESS;
 }

@@ -417,6 +417,7 @@ static int gpuPairRound(ErrMsg *errmsgp, int slot, SeqFastq *const *sq, int ns, 
       smaltgpu_callctx ctx;
       memset(&ctx, 0, sizeof(ctx));
       ctx.iv_off = iv_off; ctx.iv = iv; ctx.min_swatscor = minsw; ctx.prev_max = prevmax; ctx.fine_index = kind == GPUCOMB_FINE;
+      ctx.raw_alignments = kind == GPUCOMB_APPEND || kind == GPUCOMB_FINE;
       rv = smaltgpu_map_batch_ctx(g_map[slot].mp, (const uint8_t *)g_map[slot].bases, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
                                   g_map[slot].off, (uint32_t)ns, par, &ctx, out);
       if ((rv == SMALTGPU_ECAP || rv == SMALTGPU_EINTERNAL) && out->nreads == (uint32_t)ns) rv = 0;      /* gpuPairTake reports the read */

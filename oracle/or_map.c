@@ -185,6 +185,7 @@ static void add_results(OrMap *m, const OrAli *a, int nres, uint64_t soffs, uint
       const OrResult *pp = rp - 1;
       is_new = (arrlen < 2 || !(rp->s_start == pp->s_start && rp->s_end == pp->s_end && rp->q_start == pp->q_start &&
                                 rp->q_end == pp->q_end && rp->swatscor == pp->swatscor && rp->sidx == pp->sidx));
+      if (m->par.flags & OR_FLG_RAWRESULTS) is_new = 1;   /* the caller holds the set this call appends to and compares there */
     }
     if (is_new) {
       rp->stroffs = (int) m->ndiff;

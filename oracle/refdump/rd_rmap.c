@@ -223,6 +223,10 @@ int main(int argc, char *argv[])
       errcode = rmapPair(errmsgp, rmp, readp, matep, &pairflg, ins_min, ins_max, pairlib, ncut, covermin, covermin_mate,
 			 minscor, (UCHAR) minbasq, 512, 2048, (RMAPFLG_t) (rmapflg | RMAPFLG_PAIRED), smp, rfp, htp, ssp, codecp);
       g_pm.on = 0;
+      if (getenv("REFDUMP_PAIRPOST")) {      /* debugging aid: the two sets as rmapPair leaves them (after pairing and the filters) */
+	printf("PP %llu read\n", readno); rdDumpPost(stdout, rmp->rsrp);
+	printf("PP %llu mate\n", readno); rdDumpPost(stdout, rmp->rsmp);
+      }
       printf("PE %llu err=%d pairflg=%u ncalls=%d\n", readno, errcode, (unsigned) pairflg, g_pm.callno);
       readno++;
       continue;

@@ -21,7 +21,9 @@ extern "C" {
 #endif
 
 /* ---- flags (values follow rmap.h:53-65 so that dumps are comparable) ---- */
-enum { OR_FLG_BEST = 0x02, OR_FLG_SEQBYSEQ = 0x10, OR_FLG_NOSHRTINFO = 0x20, OR_FLG_SENSITIVE = 0x80 };
+enum { OR_FLG_BEST = 0x02, OR_FLG_SEQBYSEQ = 0x10, OR_FLG_NOSHRTINFO = 0x20, OR_FLG_SENSITIVE = 0x80,
+       OR_FLG_RAWRESULTS = 0x10000 };   /* not a flag of the reference: every alignment of the call is returned, without the duplicate
+                                          * handling of resultSetAddFromAli -- for calls that append to a ResultSet, whose caller applies it */
 /* hit qualifiers, hashhit.h:57-65 */
 enum { OR_HQ_TERM = 0, OR_HQ_NORMHIT = 1, OR_HQ_MULTIHIT = 2, OR_HQ_REPEAT = 3, OR_HQ_NOHIT = 4, OR_HQ_NONSTDNT = 5 };
 enum { OR_IDX_PERFECT = 0, OR_IDX_HASH32MIX = 1 };

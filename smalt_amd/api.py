@@ -56,7 +56,7 @@ class Interval(C.Structure):
 
 class CallCtx(C.Structure):
     _fields_ = [("iv_off", C.POINTER(C.c_uint64)), ("iv", C.POINTER(Interval)), ("min_swatscor", C.POINTER(C.c_int32)),
-                ("prev_max", C.POINTER(C.c_int32)), ("fine_index", C.c_int32), ("hitlist_len", C.POINTER(C.c_uint32))]
+                ("prev_max", C.POINTER(C.c_int32)), ("fine_index", C.c_int32), ("raw_alignments", C.c_int32), ("hitlist_len", C.POINTER(C.c_uint32))]
 
 
 class PostResult(C.Structure):
@@ -315,7 +315,7 @@ class Mapper:
         return self._unpack(out)
 
     def map_batch_ctx(self, reads: Sequence[bytes], quals: Optional[Sequence[bytes]], params: Params, intervals=None, min_swatscor=None,
-                      prev_max=None, fine_index: bool = False):
+                      prev_max=None, fine_index: bool = False, raw_alignments: bool = False):
         """One round of rmapPair over a batch (smaltgpu_map_batch_ctx): intervals = per read a list of (sidx, lo, hi) or None
         for no restriction at all; min_swatscor = per-read thresholds; prev_max = per read (max, 2ndmax) of the ResultSet
         the call appends to; fine_index = seed against the on-the-fly k=5 index of the intervals.
@@ -344,6 +344,7 @@ class Mapper:
             ctx.prev_max = pm
             keep.append(pm)
         ctx.fine_index = 1 if fine_index else 0
+        ctx.raw_alignments = 1 if raw_alignments else 0
         out = BatchOut()
         _check(lib().smaltgpu_map_batch_ctx(self.h, bases, q, off, n, C.byref(params), C.byref(ctx), C.byref(out)))
         res, stats = self._unpack(out)

@@ -639,7 +639,7 @@ static int check_par(const smaltgpu_mapper *m, const smaltgpu_params *p) {
 
 // the device pipeline over reads already in HBM
 // cx: the per-read context of one of rmapPair's rounds, already on the device (upload_ctx), or null
-struct CtxDev { const uint32_t *iv_off; const IvRec *iv; const int32_t *min_sw, *prevmax; uint32_t *fine_idx, *fine_pos; const uint32_t *fine_off, *alloc_len; };
+struct CtxDev { const uint32_t *iv_off; const IvRec *iv; const int32_t *min_sw, *prevmax; uint32_t *fine_idx, *fine_pos; const uint32_t *fine_off, *alloc_len; uint32_t raw; };
 
 static int run_pipeline(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_off, uint32_t n,
                         const smaltgpu_params *par, const CtxDev *cx = nullptr, bool seed_only = false) {
@@ -649,6 +649,7 @@ static int run_pipeline(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_
   b.iv_off = cx ? cx->iv_off : nullptr; b.iv = cx ? cx->iv : nullptr; b.min_sw = cx ? cx->min_sw : nullptr; b.prevmax = cx ? cx->prevmax : nullptr;
   b.fine_idx = cx ? cx->fine_idx : nullptr; b.fine_pos = cx ? cx->fine_pos : nullptr; b.fine_off = cx ? cx->fine_off : nullptr;
   b.alloc_len = cx ? cx->alloc_len : nullptr;
+  b.raw_results = cx ? cx->raw : 0u;
   if (b.fine_idx) p.flags |= FLG_NOSHRTINFO;            // initRMAPINFO, not the short form (rmap.c:2024)
   m->last_fine = b.fine_idx != nullptr;
   m->last_par = p; m->last_n = n;
@@ -867,6 +868,7 @@ static int upload_ctx(smaltgpu_mapper *m, const smaltgpu_callctx *ctx, uint32_t 
     if (n) HIPCHK(hipMemcpyAsync(m->cx_prevmax.p, ctx->prev_max, (size_t)n * 8, hipMemcpyHostToDevice, s));
     cd->prevmax = (const int32_t *)m->cx_prevmax.p;
   }
+  cd->raw = ctx->raw_alignments ? 1u : 0u;
   if (ctx->hitlist_len) {
     for (uint32_t i = 0; i < n; i++) if (ctx->hitlist_len[i] > m->max_len) return fail(SMALTGPU_EARG, "hitlist_len of read %u exceeds the mapper's max_read_len", i);
     if (m->cx_alloclen.ensure((size_t)(n ? n : 1) * 4)) return fail(SMALTGPU_ENOMEM, "device memory");

@@ -80,6 +80,7 @@ struct DeviceExec {
     smaltgpu_callctx cx;
     memset(&cx, 0, sizeof(cx));
     cx.iv_off = rd.iv_off; cx.iv = rd.iv; cx.min_swatscor = rd.min_score; cx.prev_max = rd.prev_max; cx.fine_index = rd.kind == ROUND_FINE;
+    cx.raw_alignments = rd.kind == ROUND_APPEND || rd.kind == ROUND_FINE;      // these rounds append to tables that may hold alignments: Table::take_call compares
     int rv;
     if (resident) rv = smaltgpu_map_batch_ctx_resident(m, resident, rd.ids, rd.n, &par, &cx, o);
     else {

@@ -206,6 +206,7 @@ struct Table {
   // what the mapping call reported beside the alignments (rmap.c:1333-1338) and the running score maxima of the set
   int32_t n_ali_done = 0, n_ali_tot = 0, score_max = 0, score_2nd = 0;
   uint32_t n_hits_used = 0, n_hits_tot = 0;
+  std::vector<uint32_t> slot_;               // take_call's view of the array's slots
   const char *why = "";                                 // set when a pass returns BROKEN
 
   uint32_t rows() const { return (uint32_t)score.size(); }
@@ -522,22 +523,63 @@ struct Table {
     return m;
   }
 
-  // One mapping call's alignments into the table (what resultSetAddFromAli, results.c:1852-1942, leaves when the set is
-  // not empty): the call's first alignment is compared with the set's last row -- same coordinates, score and sequence --
-  // and if it repeats it, it is dropped together with the rest of its candidate (`starts_candidate` marks where the next
-  // candidate's alignments begin).  The running maxima and the counters are the call's.
+  // One mapping call's alignments into the table: what resultSetAddFromAli (results.c:1852-1942), called once per candidate,
+  // leaves in the set -- restated as a machine over the array's slots.  `res` holds EVERY alignment of the call, candidate by
+  // candidate (`reverse & 2` marks the first of each; smaltgpu_callctx.raw_alignments when the table is not empty -- for an
+  // empty table the library's own result is that already).  A candidate opens the slot behind the array's end; each of its
+  // alignments is written into the open slot and compared with the slot before it (coordinates, score, sequence); one that
+  // repeats it hands the slot back: the array shrinks by one and the slot stays open, now outside the array.  Anything else
+  // stays, and the alignment after it opens the slot behind the array's end -- after a repeat that is the same slot again.  So
+  // the alignment that follows a repeat is overwritten by its successor, or left outside the array when the candidate ends: it
+  // is lost, although its score went through the set's maxima (which the call reports: max_after, second_after).
+  // A set with fewer than two entries takes anything.  The running maxima and the counters are the call's.
   template <class Raw> void take_call(const Raw *res, uint32_t n, const uint8_t *pool, int32_t max_after, int32_t second_after) {
-    uint32_t from = 0;
-    if (n && rows()) {
-      const uint32_t last = rows() - 1;
-      if (res[0].s_start == r_lo[last] && res[0].s_end == r_hi[last] && res[0].q_start == q_lo[last] && res[0].q_end == q_hi[last] &&
-          res[0].swatscor == score[last] && (int64_t)res[0].sidx == seq[last])
-        for (from = 1; from < n && !(res[from].reverse & 2u); from++) {}
+    if (n) {
+      const uint32_t n_old = rows();
+      // slots: [0, n_old) the table's rows, behind them indices into res (+ n_old); `length` is the array's length
+      slot_.clear();
+      for (uint32_t r = 0; r < n_old; r++) slot_.push_back(r);
+      uint32_t length = n_old;
+      auto same = [&](uint32_t x, uint32_t y) {            // isIdenticalResult (results.c:556-565) between two slot contents
+        int64_t a[6], b[6];
+        for (int w = 0; w < 2; w++) {
+          const uint32_t v = w ? y : x;
+          int64_t *o = w ? b : a;
+          if (v < n_old) { o[0] = (int64_t)r_lo[v]; o[1] = (int64_t)r_hi[v]; o[2] = q_lo[v]; o[3] = q_hi[v]; o[4] = score[v]; o[5] = seq[v]; }
+          else { const Raw &t = res[v - n_old]; o[0] = (int64_t)t.s_start; o[1] = (int64_t)t.s_end; o[2] = t.q_start; o[3] = t.q_end; o[4] = t.swatscor; o[5] = t.sidx; }
+        }
+        return a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3] && a[4] == b[4] && a[5] == b[5];
+      };
+      for (uint32_t i = 0; i < n;) {
+        uint32_t j = i + 1;
+        while (j < n && !(res[j].reverse & 2u)) j++;
+        uint32_t s = length++;                              // the candidate's slot
+        bool stays = false;
+        for (uint32_t t = i; t < j; t++) {
+          if (stays) { s = length++; stays = false; }
+          if (s >= slot_.size()) slot_.resize((size_t)s + 1, 0);
+          slot_[s] = n_old + t;
+          stays = length < 2 || !same(slot_[s], slot_[s - 1]);
+          if (!stays) length--;
+        }
+        i = j;
+      }
+      // rows that are no longer inside the array (a repeat of a repeat takes an older alignment with it) go, then the new ones come
+      uint32_t keep = 0;
+      while (keep < n_old && keep < length && slot_[keep] == keep) keep++;
+      if (keep < n_old) truncate_rows(keep);
+      for (uint32_t s = keep; s < length; s++) {
+        const Raw &t = res[slot_[s] - n_old];               // (a slot below n_old that was written again holds an alignment of this call)
+        add(t.swatscor, t.q_start, t.q_end, t.s_start, t.s_end, t.sidx, (t.reverse & 1u) != 0, pool + t.stroffs, t.strlen);
+      }
+      set_bits = 0;
     }
-    for (uint32_t i = from; i < n; i++)
-      add(res[i].swatscor, res[i].q_start, res[i].q_end, res[i].s_start, res[i].s_end, res[i].sidx, (res[i].reverse & 1u) != 0, pool + res[i].stroffs, res[i].strlen);
-    if (n) set_bits = 0;
     score_max = max_after; score_2nd = second_after;
+  }
+  void truncate_rows(uint32_t nrows) {
+    score.resize(nrows); quality.resize(nrows); q_lo.resize(nrows); q_hi.resize(nrows); bits.resize(nrows); str_at.resize(nrows); str_len.resize(nrows);
+    r_lo.resize(nrows); r_hi.resize(nrows); seq.resize(nrows); prob.resize(nrows); primary.resize(nrows); segment.resize(nrows); rank.resize(nrows);
+    by_score.clear(); by_segment.clear(); segment_begin.clear(); nsegments = 0;
   }
 
   // A table between two passes, as one run of bytes (a block of pairs keeps two of these per pair, not two Tables)

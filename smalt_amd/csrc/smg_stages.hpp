@@ -55,6 +55,7 @@ struct Batch {                          // one block of reads resident in HBM
   const int32_t *prevmax;               // [2 * nreads] running score maxima of the ResultSet the call appends to (rmap.c:881-885)
   uint32_t *fine_idx, *fine_pos;        // on-the-fly k=5 s=1 index of each read over its intervals (rmap.c:495-517): idx[r][FINE_IDX_STRIDE], pos
   const uint32_t *fine_off;             // [nreads + 1] first position of read r in fine_pos
+  uint32_t raw_results;                 // != 0: every alignment of a call is returned (no duplicate handling: the caller holds the set the call appends to)
   const uint32_t *alloc_len;            // [nreads] or null: length of the longest read the reference's one hit list has held up to read r (serial-order mode)
   // ---- S3 split off the candidate stage (k_hits): null when the mapper keeps S3 inside k_cands ----
   HitRun *hitrun;                       // [2 * nreads]
@@ -1538,6 +1539,10 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
           const Result *pp = rp - 1;
           is_new = (arrlen < 2) || !(nr.s_start == pp->s_start && nr.s_end == pp->s_end && nr.q_start == pp->q_start &&
                                      nr.q_end == pp->q_end && nr.swatscor == pp->swatscor && nr.sidx == pp->sidx);
+          // (a call that appends to a ResultSet returns everything: what repeats the set's last alignment, and what is lost behind
+          //  a repeat, is decided where the set is -- smgpost::Table::take_call; a repeat carries the score of an alignment that is
+          //  in the maxima already, so they come out the same)
+          if (b.raw_results) is_new = true;
           if (is_new) {
             for (uint32_t t = 0; t < nr.strlen; t++) x.dstr[dkeep + t] = x.dstr[nr.stroffs + t];
             nr.stroffs = dkeep; dkeep += nr.strlen;

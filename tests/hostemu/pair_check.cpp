@@ -101,6 +101,7 @@ struct ReplayExec {
       for (RecCall &x : rp.calls) if (!x.used && x.mate == mate && (x.niv >= 0) == restricted && (x.fine != 0) == (rd.kind == ROUND_FINE)) { c = &x; break; }
       if (!c) { snprintf(msg, sizeof(msg), "pair %u: the plan asks for a call (mate %d, round kind %d) the reference did not make", rd.ids[i] >> 1, mate, rd.kind); err = msg; return false; }
       c->used = true;
+      if (getenv("PAIR_TRACE") && (uint32_t)atoi(getenv("PAIR_TRACE")) == (rd.ids[i] >> 1)) fprintf(stderr, "TRACE pair %u: round kind %d, mate %d, %zu new alignments, max1 %d, stats %d %d %d %d\n", rd.ids[i] >> 1, (int)rd.kind, mate, c->res.size(), c->max1, c->rx[3], c->rx[4], c->rx[5], c->rx[6]);
       if (restricted) {
         const uint64_t a = rd.iv_off[i], b = rd.iv_off[i + 1];
         bool same = (int)(b - a) == c->niv;
@@ -167,6 +168,16 @@ int main(int argc, char **argv) {
   for (size_t p = 0; p < rec.size(); p++) {
     const PairPlan &pl = ps->blk.plan[p];
     for (const RecCall &c : rec[p].calls) if (!c.used && !c.res.empty() && !pl.lone) { fprintf(stderr, "pair_check: pair %zu: a call of the reference (mate %d, niv %d, fine %d) was not made\n", p, c.mate, c.niv, c.fine); return 1; }
+  }
+  if (getenv("PAIR_TRACE")) {
+    const size_t p = (size_t)atoi(getenv("PAIR_TRACE"));
+    for (int w = 0; w < 2 && p < rec.size(); w++) {
+      smgpost::Table tb;
+      tb.unpack(ps->blk.packed.data(2 * p + (size_t)w), ps->blk.packed.size(2 * p + (size_t)w));
+      fprintf(stderr, "TRACE pair %zu mate %d at rest: %u rows, stats %d %d %u %u, max %d 2nd %d;", p, w, tb.rows(), tb.n_ali_done, tb.n_ali_tot, tb.n_hits_used, tb.n_hits_tot, tb.score_max, tb.score_2nd);
+      for (uint32_t r = 0; r < tb.rows(); r++) fprintf(stderr, " [score %d quality %d bits %x prob %.6g]", tb.score[r], tb.quality[r], tb.bits[r], tb.prob[r]);
+      fprintf(stderr, "\n");
+    }
   }
   smaltgpu_report_opts ro;
   memset(&ro, 0, sizeof(ro));

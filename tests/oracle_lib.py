@@ -6,6 +6,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ODIR = os.path.join(ROOT, "oracle")
 FLG_BEST, FLG_SEQBYSEQ, FLG_NOSHRTINFO, FLG_SENSITIVE = 0x02, 0x10, 0x20, 0x80     # rmap.h:53-65
+FLG_RAWRESULTS = 0x10000              # oracle only: all alignments of a call, the duplicate handling left to the caller
 
 
 class OrIndex(C.Structure):

@@ -4,9 +4,9 @@ restricted re-map over the on-the-fly k=5 index -- and the dump records every ca
 lines) and its stage state.  A mapper under test (the CPU oracle or the GPU library) is fed each call's arguments and must
 reproduce the call's block.
 
-What a call adds to a ResultSet that already holds alignments follows resultSetAddFromAli (results.c:1852-1942): the first
-new alignment is compared with the set's last one, and if it repeats it, it is dropped together with the other alignments
-of the same candidate (`append_rule`); the set's running score maxima go into the call (the traceback pass raises its
+What a call adds to a ResultSet that already holds alignments follows resultSetAddFromAli (results.c:1852-1942): the call
+returns every alignment of its traceback pass and `append_rule` puts them behind the set with the reference's handling of
+repeats (an alignment equal to the one before it is taken off again, the alignment behind it is lost); the set's running score maxima go into the call (the traceback pass raises its
 threshold to the set's second-best score, rmap.c:881-885) and come out updated."""
 
 
@@ -56,14 +56,40 @@ def same_alignment(a, b):                   # isIdenticalResult, results.c:556-5
     return all(a[k] == b[k] for k in ("s_start", "s_end", "q_start", "q_end", "score", "sidx"))
 
 
-def append_rule(results, cand_first, prev_last):
-    """Results of one call as they end up behind a non-empty set whose last alignment is prev_last."""
-    if prev_last is None or not results or not same_alignment(results[0], prev_last):
-        return list(results)
-    j = 1
-    while j < len(results) and not cand_first[j]:
-        j += 1
-    return list(results[j:])
+def append_rule(results, cand_first, prev_last, prev_count=None):
+    """What a call's RAW alignments (every alignment the traceback pass produced, candidate by candidate) leave behind a
+    ResultSet whose last alignment is prev_last: resultSetAddFromAli (results.c:1852-1942) once per candidate, as a machine over
+    the array's physical slots.  A candidate opens a slot; every alignment is written to the open slot and compared with the slot
+    before it; an alignment that repeats it gives the slot back (the array shrinks by one, the slot stays open and outside the
+    array), anything else stays and the next alignment opens the slot behind the array's end -- which is the same slot again
+    after a repeat, so the alignment that follows a repeat is overwritten (or left outside the array at the end of the
+    candidate): it is lost, although it went through the score maxima.  -> the alignments added (the array behind the old end)"""
+    slots = [prev_last] if prev_last is not None else []
+    if prev_last is not None and prev_count is not None and prev_count > 1:
+        slots = [None] * (prev_count - 1) + [prev_last]
+    n_old = length = len(slots)
+    i = 0
+    while i < len(results):
+        j = i + 1
+        while j < len(results) and not cand_first[j]:
+            j += 1
+        s = length                       # the candidate's first slot
+        length += 1
+        fresh = False
+        for a in results[i:j]:
+            if fresh:
+                s = length
+                length += 1
+                fresh = False
+            if s == len(slots):
+                slots.append(None)
+            slots[s] = a
+            fresh = length < 2 or slots[s - 1] is None or not same_alignment(a, slots[s - 1])
+            if not fresh:
+                length -= 1
+        i = j
+    assert length >= n_old, "the call took an older alignment off the set"
+    return slots[n_old:length]
 
 
 def stage_lines(dump_text):

@@ -45,7 +45,7 @@ def test_gpu_replays_every_call_of_rmappair(entry, oracle_built, tmp_path):
                     res, stats, cf = mp.map_batch_ctx([r[1] for r in rd], [r[2] for r in rd], par,
                                                       intervals=None if what == "plain" else [c["ivs"] for _, c in sub],
                                                       min_swatscor=[c["minscor"] for _, c in sub], prev_max=[c["prevmax"] for _, c in sub],
-                                                      fine_index=(what == "fine"))
+                                                      fine_index=(what == "fine"), raw_alignments=True)     # every alignment: pair_replay.append_rule puts them behind the set
                     for i, (P, c) in enumerate(sub):
                         st = stats[i]
                         assert st["err"] == 0

@@ -28,6 +28,7 @@ def test_oracle_replays_every_call_of_rmappair(entry, oracle_built, tmp_path):
                 p = ol.default_params(ix)
                 p.min_swatscor, p.min_cover, p.min_swatscor_below_max, p.min_basq = c["minscor"], c["mincov"], c["belowmax"], fx["min_basq"]
                 p.flags = c["flags"] & (ol.FLG_BEST | ol.FLG_SEQBYSEQ | ol.FLG_NOSHRTINFO | ol.FLG_SENSITIVE)
+                p.flags |= ol.FLG_RAWRESULTS             # every alignment of the call: pair_replay.append_rule puts them behind the set as the reference does
                 if c["fine"]:
                     fine = ol.build_fine_index(ix, c["ivs"])
                     mf = ol.Mapper(fine)
