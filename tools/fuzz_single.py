@@ -2,7 +2,8 @@
 """Randomised single-end configurations: `smalt map` (the unmodified reference, oracle/_ref) against `smaltgpu-map` (the library
 alone) on the same read file -- reference shape, index word length and stride, read lengths, output format and search options
 drawn per case.  Prints one line per case and the first differing lines; exit status 1 if any case differs.
-usage: fuzz_single.py [ncases] [nreads] [seed]        (GPU box; needs make -C oracle ref)"""
+usage: fuzz_single.py [ncases] [nreads] [seed]        (GPU box; needs make -C oracle ref)
+FUZZ_BOUND=1 compares the bound program (oracle/_ref/smalt_gpu) instead of smaltgpu-map."""
 import os
 import subprocess
 import sys
@@ -69,7 +70,11 @@ def main():
             if r0.returncode:
                 print("case %d: the reference rejects %s" % (case, " ".join(opts)), flush=True)
                 continue
-            r1 = subprocess.run([prog] + opts + ["-B", str(int(rng.integers(100, 2500))), "-o", gpu_out, pre, fq], capture_output=True)
+            if os.environ.get("FUZZ_BOUND"):      # the reference's own program with its mapping worker bound to the library (integration/)
+                thr = ["-n", "3", "-O"] if "-1" in opts[opts.index("-r") + 1] else []       # worker threads only without random draws (they share one generator)
+                r1 = subprocess.run([t.SMALT_GPU, "map"] + opts + thr + ["-o", gpu_out, pre, fq], capture_output=True, env=dict(os.environ, SMALTGPU_INDEX_PREFIX=pre))
+            else:
+                r1 = subprocess.run([prog] + opts + ["-B", str(int(rng.integers(100, 2500))), "-o", gpu_out, pre, fq], capture_output=True)
             if r1.returncode:
                 print("case %d FAILED to run: k=%d s=%d nchr=%d rlen=%d %s: %s" % (case, k, s, nchr, rlen, " ".join(opts), r1.stderr.decode()[-300:]), flush=True)
                 bad += 1
