@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--long", action="store_true", help="BASELINE configs[4] shape: PacBio-shape reads of 8 kbp (3 %% substitutions, 5 %% insertions, 4 %% deletions) vs the 3 Gbp "
                     "reference, k=20 s=13; --reads of them (default 3000 of the config's 100 k: a step must finish within minutes)")
     ap.add_argument("--static-shards", action="store_true", help="N > 1: contiguous shard per rank instead of the shared sub-batch cursor")
+    ap.add_argument("--long-batch", type=int, default=3000, help="--long: reads per device batch (K3 of 8 kbp reads is bound by the latency of single reads: 1000 per batch 418 reads/s, 3000 per batch 444)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-buffers", action="store_true", help="skip the extra PCIe-inclusive measurement of smaltgpu_map_batch on pageable host buffers")
     ap.add_argument("--cpu-sample", type=int, default=150000)
@@ -409,7 +410,7 @@ def paired_main(args):
 
 
 def long_main(args):
-    """BASELINE configs[4] shape.  One step = the whole path over `--reads` long reads resident in HBM, in batches of 1000 reads
+    """BASELINE configs[4] shape.  One step = the whole path over `--reads` long reads resident in HBM, in batches of `--long-batch` reads
     (the scratch of a long read is large: direction matrices, hit slots).  The dominant kernel is the un-banded score pass in its
     strip form (k_sw_strip16: reads and windows beyond the register tiling); its roofline is the same VALU issue peak as the
     headline kernel's, cells = read length x window length per ranked candidate."""
@@ -443,7 +444,7 @@ def long_main(args):
     del ref
     torch.cuda.empty_cache()
     maxlen = max(len(r) for r in reads)
-    batch = min(1000, nreads)
+    batch = min(max(1, args.long_batch), nreads)
     lens = np.array([len(r) for r in reads], dtype=np.int64)
     off = np.zeros(nreads + 1, dtype=np.int64)
     off[1:] = np.cumsum(lens)
