@@ -16,6 +16,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 K, S, NCHR, CHRLEN, RLEN, NREADS = 13, 6, 24, 125_000_000, 150, 24_000
+NPAIRS = 12_000
 
 
 def _results(out, n):
@@ -61,6 +62,7 @@ def world():
     packed = gpuindex.pack_reference(ref)
     idx, pos = gpuindex.build_perfect_index(ref, sop, K, S)
     reads, truth = gpuindex.make_reads_gpu(ref, sop, NREADS, RLEN, 4242)
+    pr1, pr2, ptruth = gpuindex.make_pairs_gpu(ref, sop, NPAIRS, RLEN, 777)
     del ref
     desc = api.IndexDesc()
     desc.k, desc.s, desc.typ, desc.nbits_key, desc.nbits_lo = K, S, 0, 2 * K, 0
@@ -73,7 +75,8 @@ def world():
     torch.cuda.synchronize()
     gix = api.Index.from_desc(desc, 0)
     mp = api.Mapper(gix, NREADS, RLEN)
-    yield dict(gix=gix, mp=mp, reads=reads.cpu().numpy().reshape(NREADS, RLEN), truth=truth.cpu().numpy(), keep=(idx, pos, packed, sop_u64))
+    yield dict(gix=gix, mp=mp, reads=reads.cpu().numpy().reshape(NREADS, RLEN), truth=truth.cpu().numpy(), keep=(idx, pos, packed, sop_u64),
+               pairs=(pr1.cpu().numpy().reshape(NPAIRS, RLEN), pr2.cpu().numpy().reshape(NPAIRS, RLEN)), ptruth=ptruth.cpu().numpy())
     mp.close()
     gix.close()
 
@@ -139,6 +142,82 @@ def test_strand_symmetry(world):
             same += 1
     assert same_score >= 0.97 * sub.shape[0], same_score
     assert same >= 0.95 * sub.shape[0], same                      # ties between repeat copies may resolve differently
+
+def _pair_lines(w, r1, r2, nthreads=8):
+    """One block of pairs through smaltgpu_map_pairs and smaltgpu_report_emit_pairs (CIGAR lines, -i 500, no random draws):
+    -> (lines, pair info array)"""
+    from smalt_amd import api
+    L = api.lib()
+    n = r1.shape[0]
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(r1.shape[1])
+    po = api.PairOpts(0, 500, api.LIB_PE, 0, nthreads)
+    b1, b2 = np.ascontiguousarray(r1).reshape(-1), np.ascontiguousarray(r2).reshape(-1)
+    h, info, calls, ms = w["mp"].map_pairs_raw(b1, off, None, b2, off, None, w["gix"].default_params(), po)
+    views, keep = [], []
+    for which, rd in ((1, r1), (2, r2)):
+        text = b"".join(b"@p%d/%d\n" % (i, which) + rd[i].tobytes() + b"\n+\n" + b"I" * rd.shape[1] + b"\n" for i in range(n))
+        rs = L.smaltgpu_reads_create()
+        v = api.ReadsView()
+        assert L.smaltgpu_reads_parse(rs, text, len(text), 1, 0, nthreads, C.byref(v)) == 0, L.smaltgpu_last_error()
+        views.append(v)
+        keep.append((rs, text))
+    ro = api.ReportOpts()
+    ro.format = api.FMT_CIGAR
+    ro.min_swscor = 18
+    ro.outflags = api.OUT_BEST | api.OUT_SINGLE                  # `-r -1`: ambiguous pairs are reported as such, no draws
+    names = (C.c_char_p * NCHR)(*[b"chr%d" % (i + 1) for i in range(NCHR)])
+    rep = L.smaltgpu_report_create()
+    txt, ln = C.c_void_p(), C.c_uint64()
+    assert L.smaltgpu_report_emit_pairs(rep, h, C.byref(views[0]), C.byref(views[1]), names, NCHR, C.byref(ro), C.byref(po), nthreads, C.byref(txt), C.byref(ln)) == 0, L.smaltgpu_last_error()
+    lines = C.string_at(txt, ln.value).decode().split("\n")
+    info = info.copy()
+    L.smaltgpu_report_free(rep)
+    L.smaltgpu_pairs_free(h)
+    for rs, _ in keep:
+        L.smaltgpu_reads_free(rs)
+    return [x for x in lines if x], info
+
+
+def test_pairs_at_full_reference_size(world):
+    """BASELINE configs[2] shape at full reference size through smaltgpu_map_pairs + smaltgpu_report_emit_pairs, by properties:
+      * truth recovery  -- pairs are simulated as fragments N(300,30) at known positions: both mates land there, labelled as a
+                           proper pair (class A of the CIGAR format), with the fragment's length between them
+      * block invariance -- the same pairs as one block and as three uneven blocks print the same lines
+      * mate symmetry   -- with the two files swapped every pair keeps its two placements (the mates change roles)"""
+    r1, r2 = world["pairs"]
+    lines, info = _pair_lines(world, r1, r2)
+    assert len(lines) == 2 * NPAIRS
+    assert (np.ascontiguousarray(info[:, 2:6]).view(np.uint16).reshape(NPAIRS, 2) > 0).all()          # both mates have alignments
+    good = 0
+    for p in range(NPAIRS):
+        f1, f2 = lines[2 * p].split(), lines[2 * p + 1].split()
+        assert f1[0].startswith("cigar:") and f1[1] == "p%d/1" % p and f2[1] == "p%d/2" % p
+        seq, start, strand, flen = (int(x) for x in world["ptruth"][p])
+        cls = f1[0].split(":")[1]
+        lo = min(int(f1[6]), int(f1[7]), int(f2[6]), int(f2[7]))
+        hi = max(int(f1[6]), int(f1[7]), int(f2[6]), int(f2[7]))
+        if cls == "A" and f1[5] == "chr%d" % (seq + 1) == f2[5] and abs(lo - 1 - start) <= 12 and abs((hi - lo + 1) - flen) <= 24:
+            good += 1
+    assert good >= 0.95 * NPAIRS, good                         # repeats (15 % of the reference) place some pairs elsewhere
+    cuts = [0, 3000, 3001, 9500, NPAIRS]
+    k = 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        part, _ = _pair_lines(world, r1[a:b], r2[a:b])
+        for i, ln in enumerate(part):
+            want = lines[2 * a + i].split()
+            got = ln.split()
+            got[1] = want[1]                                    # the names carry the pair's number within the block
+            assert got == want, (a, i)
+            k += 1
+    assert k == 2 * NPAIRS
+    swapped, _ = _pair_lines(world, r2[:4000], r1[:4000])
+    same = 0
+    for p in range(4000):
+        a1, a2 = lines[2 * p].split(), lines[2 * p + 1].split()
+        b1, b2 = swapped[2 * p].split(), swapped[2 * p + 1].split()
+        if a1[5:8] == b2[5:8] and a2[5:8] == b1[5:8]:
+            same += 1
+    assert same >= 0.97 * 4000, same                          # which mate is mapped first can change what a repeat pair finds
 
 
 def test_bench_two_ranks_on_one_device():
