@@ -55,6 +55,7 @@ struct Batch {                          // one block of reads resident in HBM
   const int32_t *prevmax;               // [2 * nreads] running score maxima of the ResultSet the call appends to (rmap.c:881-885)
   uint32_t *fine_idx, *fine_pos;        // on-the-fly k=5 s=1 index of each read over its intervals (rmap.c:495-517): idx[r][FINE_IDX_STRIDE], pos
   const uint32_t *fine_off;             // [nreads + 1] first position of read r in fine_pos
+  uint32_t totals_only;                 // != 0: the batch stops behind the k-mer lookups (smaltgpu_hit_totals): stage_seed leaves the ranking out
   uint32_t raw_results;                 // != 0: every alignment of a call is returned (no duplicate handling: the caller holds the set the call appends to)
   const uint32_t *alloc_len;            // [nreads] or null: length of the longest read the reference's one hit list has held up to read r (serial-order mode)
   // ---- S3 split off the candidate stage (k_hits): null when the mapper keeps S3 inside k_cands ----
@@ -253,6 +254,14 @@ SMG_HD inline uint32_t stage_seed(const Batch &b, const DevIndex &ix, const MapP
   }
   SMG_SYNC();
 
+  if (b.totals_only) {            // calcTotalNumberOfHits (rmap.c:1076) needs the hit counts only: no ranking, no seed budget
+    uint32_t tot = 0;
+    const uint32_t hc = p.ncut > 0 ? (uint32_t)p.ncut : 0u;
+    SMG_PAR_CHUNKS(base, nseeds) { const uint32_t i = base + SMG_LANE; if (i < nseeds && (!hc || x.key[i] <= hc)) tot += x.key[i]; }
+    tot = wave_sum_u32(tot);
+    SMG_LANE0 { hdr.n_seeds = nseeds; hdr.seed_rank = 0; hdr.status = st ? HI_REVERSE : 0; hdr.qlen = qlen; hdr.nhit_rank = hdr.nhit_tot = 0; hdr.nhit_cut = tot; }
+    return nlook;
+  }
   // (3) rarity ranking + seed budget (sort.c:233 tie order; getHitInfoMaxRank, hashhit.c:769-891).
   // Wave form for reads of up to 256 bases whose seeds and hit counts fit the packed sort element: the unstable
   // quicksort is emulated exactly (smg_wsort.hpp); the budget is a prefix sum over the sorted hit counts; the
