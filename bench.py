@@ -380,6 +380,9 @@ def paired_main(args):
                          ops_per_cell_survey=OPS_PER_CELL_SURVEY, gcups=tcups * 1e3, traffic=None, avg_launch_ms=sw_ms / nlaunch, cells_per_launch=cells / nlaunch,
                          peak_note="256 CU x 4 SIMD x 32 lane-ops/clk x 2.4 GHz; same units as the single-end line; all rounds' K2a launches together; with 2 streams the kernels of two blocks share the device, so the per-launch time includes that sharing"),
         "kernel_ms_per_step_by_round": per_round,
+        "cands_phase_share_by_round": {rname[r]: [round(float(x) / max(1.0, float(work[r, 8:17].sum())), 4) for x in work[r, 8:17]] for r in range(5) if work[r, 8:17].sum() > 0},
+        "cands_phase_ticks_per_read_by_round": {rname[r]: [round(float(x) / max(1.0, float(calls[r])), 1) for x in list(work[r, 8:17]) + [work[r, 21]]] for r in range(4) if calls[r] > 0},
+        "hits_per_read_by_round": {rname[r]: float(work[r, 1]) / max(1.0, float(calls[r]) if r < 4 else 1.0) for r in range(4) if calls[r] > 0},
         "kernel_ms_per_step": {tn[i]: float(kms[:, i].sum()) / args.steps for i in range(ntim)},
         "gpu_busy_fraction": gpu_ms / (dt * 1e3 / args.steps),
         "round_wall_ms_per_step": {rname[r]: float(round_ms[r]) / args.steps for r in range(4)},

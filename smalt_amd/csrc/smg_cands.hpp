@@ -174,8 +174,8 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
 #define SMG_PH(i) { t1 = phase_clock(); ph[i] += t1 - t0; t0 = t1; }
   if (!presorted) {                              // (k_hits delivers the keys of a strand in order)
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (StrandWork<IT>::L && n <= 1024) {          // LDS working set: keys sorted in registers
-    if (n <= 256) wave_sort_u64_reg<4>(w.dat, n);
+  if (n <= 1024 && (StrandWork<IT>::L || n <= 256)) {   // keys sorted in registers: the LDS working set, and short runs of the HBM one (the
+    if (n <= 256) wave_sort_u64_reg<4>(w.dat, n);       // few hits of a restricted call: ten round trips to HBM with the network in memory)
     else if (n <= 512) wave_sort_u64_reg<8>(w.dat, n);
     else wave_sort_u64_reg<16>(w.dat, n);
   } else wave_sort_u64(w.dat, n);
@@ -553,6 +553,38 @@ SMG_HD inline FillDecision fill_decide_iv(const DevIndex &ix, const SeedRec *see
   return d;
 }
 
+// The same decision from counts that were taken for all (seed, interval) pairs at once: tail[n] = positions of the n-th seed (in
+// visiting order) at or behind the interval's first serial, inside[n] = those of them inside the interval.  The protocol's
+// retries then cost no index reads (each retry of fill_decide_iv searches every position list again: 165 of the 240
+// microseconds a read of a restricted round spent in the candidate stage, whenever a repeat seed made the sum of all hit
+// counts exceed the list's capacity).
+SMG_HD inline FillDecision fill_decide_counted(const SeedRec *seeds, const uint32_t *ord, uint32_t n_seeds, const uint32_t *tail, const uint32_t *inside,
+                                               uint32_t nhit_max, int nhits_alloc, uint8_t *qmask) {
+  FillDecision d;
+  uint32_t m = nhit_max;
+  for (;;) {
+    uint32_t total = 0, n;
+    bool aborted = false;
+    for (n = 0; n < n_seeds; n++) {
+      const uint32_t q = seeds[ord ? ord[n] : n].qoffs;
+      if (m > 0 && seeds[n].nhits > m) { qmask[q] = HQ_MULTIHIT; continue; }
+      const uint32_t nh = tail[n];
+      if (nh == 0) continue;
+      if (total + nh > (uint32_t)nhits_alloc) {
+        if (m > 0) { aborted = true; break; }
+        qmask[q] = HQ_MULTIHIT;
+        continue;
+      }
+      total += inside[n];
+    }
+    d.n_used = n;
+    d.m_final = m;
+    m /= 2;
+    if (!(aborted && m > (uint32_t)MINHIT_PER_TUPLE)) break;
+  }
+  return d;
+}
+
 // k-mer serial range [plo, phi) of interval v (hashCollectHitsForSegment, hashhit.c:1711-1717, called with
 // sop[sx] + lo and sop[sx] + hi + 1, rmap.c:462-474)
 SMG_HD inline void iv_serials(const DevIndex &ix, const IvRec &v, uint32_t *plo, uint32_t *phi) {
@@ -898,6 +930,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
     const SeedRec *seeds = b.seeds + (size_t)rs * b.qmax;
     uint8_t *qmask = b.qmask + (size_t)rs * b.qmax;
     if (ivmode) {
+      SMG_PH(0)
       // All seeds take part (use_short_hitinfo = 0), in read-offset order.  Hits are few (the intervals are a few hundred
       // bases), so the strand always takes the HBM working set; what costs is finding each position list's slice.
       const uint32_t n_all = hdr.n_seeds;
@@ -918,12 +951,39 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
           }
           SMG_SYNC();
         }
-        SMG_PAR_CHUNKS(base, niv) {
-          const uint32_t g = base + SMG_LANE;
-          if (g < niv) { uint32_t plo, phi; iv_serials(ix, ivr[g], &plo, &phi); dec[g] = fill_decide_iv(ix, seeds, ord, n_all, plo, phi, ncut, nhits_alloc, qmask); }
+        // counts of every (seed, interval) pair first, all lanes busy, when the sort arrays have room for them behind the decisions
+        // and the offset order; then one lane per interval runs the protocol on the counts
+        const uint64_t ncnt = (uint64_t)n_all * niv;
+        if (ncnt + 2ull * niv <= (uint64_t)x.candcap && ncnt + n_all <= (uint64_t)x.candcap) {
+          uint32_t *tailc = x.sort_keys + 2 * niv, *insc = x.sort_idx + n_all;
+          if (!LONG && x.lds && ncnt * 8 <= (uint64_t)x.lds_bytes) { tailc = (uint32_t *)x.lds; insc = tailc + ncnt; }   // (the LDS working set is idle in a restricted call)
+          SMG_PAR_CHUNKS(base, (uint32_t)ncnt) {
+            const uint32_t pi = base + SMG_LANE;
+            if (pi < (uint32_t)ncnt) {
+              const uint32_t g = pi / n_all, n = pi - g * n_all;
+              const SeedRec sd = seeds[ord ? ord[n] : n];
+              uint32_t plo, phi, a, e;
+              const uint32_t *posp;
+              iv_serials(ix, ivr[g], &plo, &phi);
+              const uint32_t nh = index_positions(ix, sd.posidx, &posp);
+              lower_bounds2_u32(posp, nh, plo, phi, &a, &e);
+              tailc[pi] = nh - a; insc[pi] = e - a;
+            }
+          }
+          SMG_SYNC();
+          SMG_PAR_CHUNKS(base, niv) {
+            const uint32_t g = base + SMG_LANE;
+            if (g < niv) dec[g] = fill_decide_counted(seeds, ord, n_all, tailc + (size_t)g * n_all, insc + (size_t)g * n_all, ncut, nhits_alloc, qmask);
+          }
+        } else {
+          SMG_PAR_CHUNKS(base, niv) {
+            const uint32_t g = base + SMG_LANE;
+            if (g < niv) { uint32_t plo, phi; iv_serials(ix, ivr[g], &plo, &phi); dec[g] = fill_decide_iv(ix, seeds, ord, n_all, plo, phi, ncut, nhits_alloc, qmask); }
+          }
         }
       }
       SMG_SYNC();
+      { t1 = phase_clock(); ph[13] += t1 - t0; t0 = t1; }     // (diagnostic: the decisions ahead of the gather)
       StrandWork<uint32_t> wg = strand_work_carve<uint32_t>(x.hbm, x.hcap_strand);
       uint32_t nkeys = 0;
       const uint32_t npairs = n_all * niv;
@@ -941,8 +1001,9 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
             uint32_t plo, phi;
             iv_serials(ix, ivr[g], &plo, &phi);
             const uint32_t nh = index_positions(ix, sd.posidx, &posp);
-            a = lower_bound_u32(posp, nh, plo);
-            cnt = lower_bound_u32(posp, nh, phi) - a;
+            uint32_t e;
+            lower_bounds2_u32(posp, nh, plo, phi, &a, &e);
+            cnt = e - a;
             qo = sd.qoffs;
           }
         }
@@ -963,6 +1024,7 @@ SMG_HD inline uint32_t stage_cands_v2(const Batch &b, const DevIndex &ix, const 
       }
       if (wave_any(ovf)) { err = SMG_ERR_CAP; site = __LINE__; break; }
       SMG_SYNC();
+      SMG_PH(1)
       uint32_t nproc = nkeys, reg_base = 0;
       const int rv = strand_cands<LONG>(wg, nkeys, st != 0, true, qlen, k, s, min_cover, x.cover8, x.cand, x.candcap, &ncand, &max_cover, &max2nd, ph,
                                         false, &nproc, &reg_base, x.lw, ivr);
