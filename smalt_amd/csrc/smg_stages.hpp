@@ -201,7 +201,14 @@ SMG_HD inline uint32_t stage_seed(const Batch &b, const DevIndex &ix, const MapP
   const uint32_t nk = qlen - (uint32_t)k + 1;
   const uint64_t wordmask = (1ull << (2 * k)) - 1;
 
-  // (1) words + validity of every k-mer start t; ordered compaction of the valid ones
+  // (1) words + validity of every k-mer start t; ordered compaction of the valid ones.  The bases are staged once -- one byte per
+  // base in the stage's scratch: the code, plus 4 if the base cannot be part of a word (non-ACGT, low quality) -- so that a lane
+  // reads its k bases from there and not k code bytes and k quality bytes from memory (the word loop was 46 % of the kernel)
+  SMG_PAR_CHUNKS(base, qlen) {
+    const uint32_t i = base + SMG_LANE;
+    if (i < qlen) { const uint32_t c = codes[i]; x.qbuf[i] = (uint8_t)((c & 3u) | (((c & 4u) || (qual && qual[i] < minqval)) ? 4u : 0u)); }
+  }
+  SMG_SYNC();
   uint32_t nvalid = 0;
   SMG_PAR_CHUNKS(base, nk) {
     uint32_t t = base + SMG_LANE;
@@ -210,8 +217,8 @@ SMG_HD inline uint32_t stage_seed(const Batch &b, const DevIndex &ix, const MapP
     if (t < nk) {
       valid = true;
       for (int i = 0; i < k; i++) {
-        uint32_t c = codes[t + (uint32_t)i];
-        if ((c & 4) || (qual && qual[t + (uint32_t)i] < minqval)) valid = false;
+        const uint32_t c = x.qbuf[t + (uint32_t)i];
+        if (c & 4) valid = false;
         // forward: first base in the top bits; reverse strand: complement of base t+i at bit 2i
         if (st) w |= ((uint64_t)((c ^ 3u) & 3u)) << (2 * i);
         else w = (w << 2) | (c & 3u);
@@ -304,6 +311,28 @@ SMG_HD inline uint32_t stage_seed(const Batch &b, const DevIndex &ix, const MapP
     for (int o = 32; o > 0; o >>= 1) { const uint32_t u = (uint32_t)__shfl_xor((int)nbud, o); if (u < nbud) nbud = u; }
 #endif
     uint32_t nmax = nbud;
+    // the ranks of every sampling frame as a list of its own (all lanes: a seed's frame, its place in the frame's list by
+    // ballot), so that the lane of a frame walks its ~ n/s seeds and not all n (the walk was 40 % of the kernel)
+    const uint32_t smagic = div_magic(s);               // q0 % s without a division (exact for offsets below 2^20)
+    const bool listed = s <= 16;
+    uint32_t fcnt[16];
+#pragma unroll
+    for (int ff = 0; ff < 16; ff++) fcnt[ff] = 0;
+    if (listed) {
+      SMG_PAR_CHUNKS(base, nseeds) {
+        const uint32_t rk = base + SMG_LANE;
+        uint32_t f = 0xffffffffu;
+        if (rk < nseeds) { const uint32_t q0 = x.qbr[rk]; const uint32_t qd = smagic ? (uint32_t)(((uint64_t)q0 * smagic) >> 32) : q0; f = q0 - qd * (uint32_t)s; }
+#pragma unroll
+        for (int ff = 0; ff < 16; ff++) {
+          if (ff < s) {                                  // (wave-uniform)
+            const uint32_t slot = compact_slot(f == (uint32_t)ff, fcnt[ff]);
+            if (f == (uint32_t)ff) x.frame_rank[(uint32_t)ff * x.stride + slot] = rk;
+          }
+        }
+      }
+      SMG_SYNC();
+    }
     SMG_PAR_CHUNKS(base, (uint32_t)s) {                // one lane per sampling frame (:860-882)
       const uint32_t f = base + SMG_LANE;
       if (f < (uint32_t)s) {
@@ -311,14 +340,26 @@ SMG_HD inline uint32_t stage_seed(const Batch &b, const DevIndex &ix, const MapP
         qm_clear(mk);
         uint32_t cover = 0;
         int last = -1;
-        const uint32_t smagic = div_magic(s);           // q0 % s without a division (exact for offsets below 2^20)
-        for (uint32_t rk = 0; rk < nseeds; rk++) {
-          const uint32_t q0 = x.qbr[rk];
-          const uint32_t qd = smagic ? (uint32_t)(((uint64_t)q0 * smagic) >> 32) : q0;
-          if (q0 - qd * (uint32_t)s != f) continue;
-          if (!(cover <= maxcover && (cover < mincover || rk <= nbud))) break;
-          cover += qm_add(mk, q0, (uint32_t)k - 1);      // k-1 bases (hashhit.c:873)
-          last = (int)rk;
+        if (listed) {
+          uint32_t nf = 0;
+#pragma unroll
+          for (int ff = 0; ff < 16; ff++) nf = f == (uint32_t)ff ? fcnt[ff] : nf;
+          const uint32_t *mine = x.frame_rank + (size_t)f * x.stride;
+          for (uint32_t i = 0; i < nf; i++) {
+            const uint32_t rk = mine[i];
+            if (!(cover <= maxcover && (cover < mincover || rk <= nbud))) break;
+            cover += qm_add(mk, x.qbr[rk], (uint32_t)k - 1);      // k-1 bases (hashhit.c:873)
+            last = (int)rk;
+          }
+        } else {
+          for (uint32_t rk = 0; rk < nseeds; rk++) {
+            const uint32_t q0 = x.qbr[rk];
+            const uint32_t qd = smagic ? (uint32_t)(((uint64_t)q0 * smagic) >> 32) : q0;
+            if (q0 - qd * (uint32_t)s != f) continue;
+            if (!(cover <= maxcover && (cover < mincover || rk <= nbud))) break;
+            cover += qm_add(mk, q0, (uint32_t)k - 1);
+            last = (int)rk;
+          }
         }
         if (last >= 0 && (uint32_t)last > nmax) nmax = (uint32_t)last;
       }
