@@ -232,12 +232,14 @@ __global__ void __launch_bounds__(64) k_align(Batch b, DevIndex ix, MapPar p, ui
       stage_align<WIDE>(b, ix, p, b.align_retry[i], x);
       __syncthreads();
     }
+    align_tally_flush(b, x);
     return;
   }
   for (uint32_t r = next_item(cursor, &qslot); r < b.nreads; r = next_item(cursor, &qslot)) {
     stage_align<WIDE>(b, ix, p, r, x);
     __syncthreads();
   }
+  align_tally_flush(b, x);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -794,6 +794,7 @@ struct AlignScratch {
   uint8_t *dir; uint64_t dircap;        // direction matrix in the HBM slot
   uint8_t *dir_lds; uint32_t dir_lds_cap;   // ... and its LDS home for bands that fit (0 on the host build)
   uint8_t *dtmp; uint32_t dtmpcap;      // reversed DiffStr of the current traceback
+  unsigned long long tally[8];          // phase ticks and counts of the reads this workgroup has aligned (flushed to Batch::work once, by the kernel)
   Result *res; uint32_t rescap;
   uint8_t *dstr; uint32_t dstrcap;
   int *ivstack;               // [2 * 64] pending reference intervals
@@ -832,6 +833,7 @@ SMG_HD inline AlignScratch align_scratch_carve(uint8_t *base, uint32_t qmax, uin
   x.dir = base; x.dircap = dircap;
   x.dir_lds = nullptr; x.dir_lds_cap = 0;
   x.win_lds = x.dtmp_lds = nullptr; x.win_lds_cap = 0;
+  for (int i = 0; i < 8; i++) x.tally[i] = 0;
   x.pass = 0;
   return x;
 }
@@ -1637,7 +1639,11 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
     SMG_PAR_CHUNKS(base, nres) { uint32_t i = base + SMG_LANE; if (i < nres) b.respool[ro + i] = x.res[i]; }
     SMG_PAR_CHUNKS(base, nd) { uint32_t i = base + SMG_LANE; if (i < nd) b.dstrpool[dof + i] = x.dstr[i]; }
   }
-  SMG_LANE0 { if (aph[4]) for (int i = 0; i < 8; i++) (void)atomic_add_u64(b.work + WK_ALIGN0 + i, aph[i]); }
+  for (int i = 0; i < 8; i++) x.tally[i] += aph[i];        // (eight atomics per read on eight fixed addresses before: the kernel flushes once)
+}
+SMG_HD inline void align_tally_flush(const Batch &b, AlignScratch &x) {
+  SMG_LANE0 { if (x.tally[4]) for (int i = 0; i < 8; i++) (void)atomic_add_u64(b.work + WK_ALIGN0 + i, x.tally[i]); }
+  for (int i = 0; i < 8; i++) x.tally[i] = 0;
 }
 
 }  // namespace smg

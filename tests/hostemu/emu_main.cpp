@@ -181,6 +181,7 @@ int main(int argc, char **argv) {
     stage_replay(b, ix, p, r);
     AlignScratch ax = align_scratch_carve(ascr.data(), qmax, wincap, dircap, 4096, 4096 * (qmax / 4 + 48));
     stage_align(b, ix, p, r, ax);
+    align_tally_flush(b, ax);
   }
   std::string out;
   std::vector<SegCand> crec;
