@@ -310,7 +310,12 @@ struct smaltgpu_mapper {
   uint32_t hits_W = 0, hits_wg = 0;          // k_hits: keys per window, workgroups (0: S3 stays inside k_cands)
   HitRun *b_hitrun = nullptr;                 // the run table (Batch::hitrun is set per call: restricted calls do not use it)                  // read ids of a round gathered from resident batches (smaltgpu_map_batch_ctx_resident)
   Batch b;
-  uint8_t *d_counters = nullptr;            // rc_count | res_count | dstr_count | err_flag | work[8]
+  // Counters of a batch, one 128-byte line each: atomics on one line are served one after the other (2 ns each), and the pool cursors,
+  // the work-queue cursors of the persistent kernels and the retry counts used to share the first line.
+  enum : size_t { CT_LINE = 128, CT_RC = 0, CT_RES = 1 * CT_LINE, CT_DSTR = 2 * CT_LINE, CT_ERR = 3 * CT_LINE, CT_NEXT = 4 * CT_LINE /* 5 lines */,
+                  CT_ALIGN_RETRY = 9 * CT_LINE, CT_CANDS_RETRY = 10 * CT_LINE, CT_HITS = 11 * CT_LINE, CT_HITS_CURSOR = 12 * CT_LINE, CT_STRIP_CURSOR = 13 * CT_LINE,
+                  CT_WORK = 14 * CT_LINE /* 32 x 8 bytes */, CT_BYTES = 16 * CT_LINE };
+  uint8_t *d_counters = nullptr;
   uint8_t *seed_scr = nullptr; size_t seed_bytes = 0; uint32_t seed_slots = 0;
   uint8_t *cand_scr = nullptr; size_t cand_bytes = 0; uint32_t cand_slots = 0;
   CandGeom cg2; uint8_t *cand_scr2 = nullptr; size_t cand_bytes2 = 0; uint32_t cand_slots2 = 0;   // second pass of the candidate stage: full-size slots
@@ -438,7 +443,7 @@ extern "C" int smaltgpu_mapper_create_ex(smaltgpu_mapper **out, const smaltgpu_i
   DA(b.dstrpool, b.dstrcap);
   DA(b.align_retry, max_batch_reads);
   DA(b.cands_retry, max_batch_reads);
-  DA(m->d_counters, 512);
+  DA(m->d_counters, smaltgpu_mapper::CT_BYTES);
   // S3 as a kernel of its own (k_hits) for mappers of short reads: sorted hit keys of every strand in one pool, 8 bytes per hit.
   // SMALTGPU_HITS_SPLIT=0 keeps S3 inside k_cands; SMALTGPU_HITS_PER_READ sizes the pool (a batch that overflows it is re-mapped in
   // smaller batches like any other pool overflow); SMALTGPU_HITS_WINDOW the keys per window of the kernel.
@@ -463,17 +468,18 @@ extern "C" int smaltgpu_mapper_create_ex(smaltgpu_mapper **out, const smaltgpu_i
     }
   }
   if (!rv) {
-    b.rc_count = (uint32_t *)(m->d_counters + 0);
-    b.res_count = (unsigned long long *)(m->d_counters + 8);
-    b.dstr_count = (unsigned long long *)(m->d_counters + 16);
-    b.err_flag = (int32_t *)(m->d_counters + 24);
-    b.next_item = (uint32_t *)(m->d_counters + 32);
-    b.align_retry_n = (uint32_t *)(m->d_counters + 56);
-    b.cands_retry_n = (uint32_t *)(m->d_counters + 60);
-    b.work = (unsigned long long *)(m->d_counters + 64);
-    b.hit_count = (unsigned long long *)(m->d_counters + 328);
-    b.hits_cursor = (uint32_t *)(m->d_counters + 336);
-    b.strip_cursor = (uint32_t *)(m->d_counters + 340);
+    typedef smaltgpu_mapper M;
+    b.rc_count = (uint32_t *)(m->d_counters + M::CT_RC);
+    b.res_count = (unsigned long long *)(m->d_counters + M::CT_RES);
+    b.dstr_count = (unsigned long long *)(m->d_counters + M::CT_DSTR);
+    b.err_flag = (int32_t *)(m->d_counters + M::CT_ERR);
+    b.next_item = (uint32_t *)(m->d_counters + M::CT_NEXT);           // cursor i at next_item + i * NEXT_ITEM_STRIDE
+    b.align_retry_n = (uint32_t *)(m->d_counters + M::CT_ALIGN_RETRY);
+    b.cands_retry_n = (uint32_t *)(m->d_counters + M::CT_CANDS_RETRY);
+    b.work = (unsigned long long *)(m->d_counters + M::CT_WORK);
+    b.hit_count = (unsigned long long *)(m->d_counters + M::CT_HITS);
+    b.hits_cursor = (uint32_t *)(m->d_counters + M::CT_HITS_CURSOR);
+    b.strip_cursor = (uint32_t *)(m->d_counters + M::CT_STRIP_CURSOR);
   }
   // scratch geometry -------------------------------------------------------------------
   m->seed_bytes = (seed_scratch_bytes(m->qmax, d.s) + 255) & ~(size_t)255;
@@ -656,7 +662,7 @@ static int run_pipeline(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_
   m->last_par = p; m->last_n = n;
   b.nreads = n; b.codes = m->d_codes; b.codes_rc = m->d_codes_rc; b.qual = d_quals; b.read_off = d_off;
   hipStream_t s = m->stream;
-  HIPCHK(hipMemsetAsync(m->d_counters, 0, 512, s));
+  HIPCHK(hipMemsetAsync(m->d_counters, 0, smaltgpu_mapper::CT_BYTES, s));
   int rv = 0;
   const bool seqbyseq = (p.flags & FLG_SEQBYSEQ) != 0;
   const uint32_t ngrp = seqbyseq ? (uint32_t)d.nseq : 1u;
@@ -733,14 +739,14 @@ extern "C" int smaltgpu_fetch_begin(smaltgpu_mapper *m) {
   if (!m) return fail(SMALTGPU_EARG, "null argument");
   HIPCHK(hipSetDevice(m->device));
   const uint32_t n = m->last_n;
-  uint8_t ctr[512];
+  uint8_t ctr[smaltgpu_mapper::CT_BYTES];
   if (!m->ev_fetch) HIPCHK(hipEventCreate(&m->ev_fetch));
   if (m->h_stat.ensure(n ? n : 1)) return fail(SMALTGPU_ENOMEM, "pinned host memory");
-  HIPCHK(hipMemcpyAsync(ctr, m->d_counters, 512, hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipMemcpyAsync(ctr, m->d_counters, smaltgpu_mapper::CT_BYTES, hipMemcpyDeviceToHost, m->stream));
   HIPCHK(hipStreamSynchronize(m->stream));
-  const uint32_t rc_count = *(uint32_t *)(ctr + 0);
-  const uint64_t nres = *(unsigned long long *)(ctr + 8), ndstr = *(unsigned long long *)(ctr + 16);
-  memcpy(m->work, ctr + 64, sizeof(m->work));
+  const uint32_t rc_count = *(uint32_t *)(ctr + smaltgpu_mapper::CT_RC);
+  const uint64_t nres = *(unsigned long long *)(ctr + smaltgpu_mapper::CT_RES), ndstr = *(unsigned long long *)(ctr + smaltgpu_mapper::CT_DSTR);
+  memcpy(m->work, ctr + smaltgpu_mapper::CT_WORK, sizeof(m->work));
   for (int i = 0; i < T_NUM; i++) { float f = 0; (void)hipEventElapsedTime(&f, m->ev[i], m->ev[i + 1]); m->ms[i] = f; }
   m->fetch_open = false;
   // A pool that overflowed leaves SMALTGPU_ECAP in the stat of every read that did not fit (their results are dropped on the

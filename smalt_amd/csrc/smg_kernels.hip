@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(64, WAVES) k_cands(Batch b, DevIndex ix, MapPa
     ix.seqlo = sl;
     __syncthreads();
   }
-  uint32_t *cursor = b.next_item + (g.pass == 2 ? 4 : 1);
+  uint32_t *cursor = b.next_item + NEXT_ITEM_STRIDE * (g.pass == 2 ? 4 : 1);
   // second pass: only the reads the first pass deferred (usually none: the launch ends at once)
   const uint32_t nitem = g.pass == 2 ? *b.cands_retry_n : b.nreads;
   for (uint32_t it = next_item(cursor, &qslot); it < nitem; it = next_item(cursor, &qslot)) {
@@ -206,10 +206,13 @@ __global__ void __launch_bounds__(64, WAVES) k_cands(Batch b, DevIndex ix, MapPa
 // O1: one thread per read
 __global__ void __launch_bounds__(256) k_replay(Batch b, DevIndex ix, MapPar p) {
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long scored = 0;
   if (r < b.nreads) {
     stage_replay(b, read_index(b, ix, r), p, r);
-    atomicAdd(b.work + WK_CELLS_BAND, (unsigned long long)b.ctl[r].n_scored);     // candidates the reference would have scored
+    scored = (unsigned long long)b.ctl[r].n_scored;                               // candidates the reference would have scored
   }
+  for (int o = 32; o > 0; o >>= 1) scored += __shfl_xor(scored, o);               // one atomic per wave, not per read
+  if ((threadIdx.x & 63) == 0 && scored) atomicAdd(b.work + WK_CELLS_BAND, scored);
 }
 
 // K3: one wave per read; hot arrays in LDS, results and oversized direction matrices in the HBM slot
@@ -225,7 +228,7 @@ __global__ void __launch_bounds__(64) k_align(Batch b, DevIndex ix, MapPar p, ui
   __shared__ int2 strip_ring[WIDE ? 256 : 1];
   x.ring = WIDE ? (void *)strip_ring : nullptr;
   __shared__ uint32_t qslot;
-  uint32_t *cursor = b.next_item + (pass == 2 ? 3 : 2);
+  uint32_t *cursor = b.next_item + NEXT_ITEM_STRIDE * (pass == 2 ? 3 : 2);
   if (pass == 2) {                        // only the reads the first pass deferred (usually none: the launch ends at once)
     const uint32_t n = *b.align_retry_n;
     for (uint32_t i = next_item(cursor, &qslot); i < n; i = next_item(cursor, &qslot)) {

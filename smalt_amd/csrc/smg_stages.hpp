@@ -45,7 +45,7 @@ struct Batch {                          // one block of reads resident in HBM
   uint8_t *dstrpool; uint64_t dstrcap; unsigned long long *dstr_count;
   int32_t *err_flag;                    // batch-wide first error
   uint32_t *strip_cursor;               // work-queue cursor of the packed strip kernel (pairs of strip-list entries)
-  uint32_t *next_item;                  // [5] work-queue cursors of the persistent kernels (seed, cands, align, align pass 2, cands pass 2)
+  uint32_t *next_item;                  // work-queue cursors of the persistent kernels (seed, cands, align, align pass 2, cands pass 2), NEXT_ITEM_STRIDE words apart
   uint32_t *align_retry, *align_retry_n; // reads the first K3 pass deferred to the second one (SMG_ERR_RETRY), and how many
   uint32_t *cands_retry, *cands_retry_n; // the same for the candidate stage (reads whose hits overflow a first-pass slot)
   unsigned long long *work;             // [WK_NWORK] work counters (WK_*), one atomic per workgroup
@@ -91,6 +91,7 @@ SMG_HD inline DevIndex read_index(const Batch &b, const DevIndex &ix, uint32_t r
   f.wordidx = f.posidx = nullptr;
   return f;
 }
+enum : int { NEXT_ITEM_STRIDE = 32 };          // a 128-byte line per cursor
 enum : int { WK_LOOKUPS = 0, WK_HITS = 1, WK_CELLS_FULL = 2, WK_TASKS_FULL = 3, WK_CELLS_BAND = 4, WK_NCAND = 5, WK_NKEPT = 6,
               WK_QN_TASKS = 7 /* ranked candidates of reads with non-ACGT codes */, WK_LONG_TASKS = 17 /* windows > SW_SHORT_WMAX */, WK_STRIP_TASKS = 18 /* beyond the register tiling */,
               WK_PHASE0 = 8 /* .. 23: shader-clock ticks per phase of k_cands (diagnostic) */,
