@@ -346,7 +346,10 @@ int smaltgpu_reads_parse(smaltgpu_reads *rs, const char *text, uint64_t len, int
 /* Report: which alignments of a read are printed (resultSetFilterResults, results.c:2592; resultSetAddToReport, results.c:2282;
  * reportAddMap's duplicate test, report.c:545) and the lines themselves (fprintREPALIcigar report.c:711, fprintREPALIsam
  * report.c:762, writeDiffStrCIGAR diffstr.c:298, SAM header report.c:1266). */
-enum { SMALTGPU_FMT_CIGAR = 0, SMALTGPU_FMT_SAM = 1 };                                   /* -f cigar | sam (REPORTFMT_*, report.h:46-52) */
+enum { SMALTGPU_FMT_CIGAR = 0, SMALTGPU_FMT_SAM = 1, SMALTGPU_FMT_SSAHA = 2 };           /* -f cigar | sam | ssaha (REPORTFMT_*, report.h:46-52; fprintREPALIssaha
+                                                                                          * report.c:579).  -f gff ends the reference program with a memory
+                                                                                          * fault on its first read (report.c:1389-1401 drops the block list
+                                                                                          * it has just made), -f bam needs a library this build has not */
 enum { SMALTGPU_REP_SOFTCLIP = 0x02, SMALTGPU_REP_HEADER = 0x04, SMALTGPU_REP_XMISMATCH = 0x08 };   /* REPORTMODIF_* (report.h:54-59) */
 enum { SMALTGPU_OUT_BEST = 0x01, SMALTGPU_OUT_SINGLE = 0x02, SMALTGPU_OUT_RANDSEL = 0x08 };         /* RESULTFLG_* (results.h:55-63) */
 typedef struct smaltgpu_report_opts {
@@ -359,7 +362,8 @@ typedef struct smaltgpu_report_opts {
 typedef struct smaltgpu_report smaltgpu_report;      /* owns the text it hands out */
 smaltgpu_report *smaltgpu_report_create(void);
 void smaltgpu_report_free(smaltgpu_report *rp);
-/* text in front of the first read (the SAM header; empty for the other formats).  seqnames / sop / nseq: smaltgpu_index_seqnames */
+/* text in front of the first read (the SAM header; empty for the other formats); the report keeps the sequence lengths, which
+ * SSAHA lines print: call it once before the emit functions.  seqnames / sop / nseq: smaltgpu_index_seqnames */
 int smaltgpu_report_header(smaltgpu_report *rp, const char *const *seqnames, const uint64_t *sop, int64_t nseq, const smaltgpu_report_opts *op,
                            const char *prognam, const char *version, int argc, const char *const *argv, const char **text, uint64_t *len);
 /* the lines of a batch: post = smaltgpu_postprocess of `raw` (raw may be NULL: it only supplies the per-read error codes),

@@ -82,7 +82,7 @@ class ReportOpts(C.Structure):         # smaltgpu_report_opts
                 ("min_swscor_below_max", C.c_int32), ("min_identity", C.c_double)]
 
 
-FMT_CIGAR, FMT_SAM = 0, 1
+FMT_CIGAR, FMT_SAM, FMT_SSAHA = 0, 1, 2
 REP_SOFTCLIP, REP_HEADER, REP_XMISMATCH = 0x02, 0x04, 0x08
 OUT_BEST, OUT_SINGLE, OUT_RANDSEL = 0x01, 0x02, 0x08
 

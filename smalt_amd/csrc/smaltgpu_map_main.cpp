@@ -41,7 +41,7 @@ const char VERSION[] = "0.2";
 void usage() {
   fprintf(stderr,
           "usage: smaltgpu-map [options] <index prefix> <reads.fq|reads.fa>[.gz] [<mates.fq|mates.fa>[.gz]]\n"
-          "  -f <fmt>   cigar (default) | sam | samsoft, SAM modifiers behind a colon: nohead, clip, x (e.g. sam:nohead,x)\n"
+          "  -f <fmt>   cigar (default) | ssaha | sam | samsoft, SAM modifiers behind a colon: nohead, clip, x (e.g. sam:nohead,x)\n"
           "  -o <file>  output file (default: standard output)\n"
           "  -m <int>   minimum Smith-Waterman score (default: word length + step - 1)\n"
           "  -d <int>   report alignments within <int> of the best score; -1: all (default 0: best only)\n"
@@ -176,7 +176,8 @@ int main(int argc, char **argv) {
     std::string f(fmt), key = f.substr(0, f.find(':'));
     if (key == "cigar") ro.format = SMALTGPU_FMT_CIGAR;
     else if (key == "sam" || key == "samsoft") { ro.format = SMALTGPU_FMT_SAM; ro.modflags = SMALTGPU_REP_HEADER | SMALTGPU_REP_SOFTCLIP; }
-    else die("output format not supported here (cigar, sam, samsoft)", fmt);
+    else if (key == "ssaha") ro.format = SMALTGPU_FMT_SSAHA;
+    else die("output format not supported here (cigar, sam, samsoft, ssaha)", fmt);
     size_t p = f.find(':');
     while (p != std::string::npos && ro.format == SMALTGPU_FMT_SAM) {
       const size_t e = f.find(',', p + 1);

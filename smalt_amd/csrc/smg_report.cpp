@@ -307,6 +307,13 @@ int diff_matches(const uint8_t *d) {                       // diffStrCalcAliLen'
   return m;
 }
 
+int diff_columns(const uint8_t *d) {                       // diffStrCalcAliLen's return value: alignment columns, the closing code not counted
+  int n = 0;
+  unsigned c = 0, t = 0;
+  for (; *d; d++) { dget(*d, &c, &t); n += (int)c + 1; }
+  return t == 3 ? n - 1 : n;
+}
+
 int diff_edit_distance(const uint8_t *d) {                 // diffStrGetLevenshteinDistance (diffstr.c:1496-1510)
   int ed = 0;
   unsigned t = 0, c;
@@ -371,6 +378,7 @@ struct ReadCtx {
   const smaltgpu_report_opts *op;
   const char *const *seqnames;
   int64_t nseq;
+  const uint32_t *seqlen;                // lengths of the reference sequences (SSAHA lines print them): from smaltgpu_report_header
 };
 
 // the alignments of read i in the order the reference's report holds them; draw: the pre-drawn index for a random choice
@@ -461,17 +469,20 @@ int draw_range(const ReadCtx &cx, uint32_t i) {
 // the other mate's printed alignment, the template length and what is known about the pairing (REPPAIR_*) -- null for single reads
 struct PairSide { const Ali *mate; int isize; uint8_t pairflg; };
 
+// the letter behind "cigar:" / "alignment:" (getMapLabelFromFlag, report.c:217-246; unmapped: report.c:624, :746)
+char map_label(const Ali &a, const PairSide *ps) {
+  if (!(a.status & MF_MAPPED)) return (a.status & MF_MULTI) ? 'R' : 'N';
+  uint8_t pf = ps ? ps->pairflg : 0;
+  if (ps && ps->mate && a.sidx == ps->mate->sidx) pf |= RP_CONTIG;         // report.c:1173-1176 (an unprinted mate carries sequence 0)
+  if (a.status & MF_PARTIAL) return 'P';
+  if (pf & RP_MAPPED) return (pf & RP_CONTIG) ? ((pf & RP_PROPER) ? ((pf & RP_WITHIN) ? 'A' : 'B') : 'C') : 'D';
+  return 'S';
+}
+
 bool print_cigar_line(std::string &o, const ReadCtx &cx, uint32_t i, const Ali &a, const PairSide *ps = nullptr) {      // fprintREPALIcigar (report.c:711-760)
   char buf[96];
   const bool mapped = (a.status & MF_MAPPED) != 0;
-  char flagchr;
-  if (mapped) {                                                           // getMapLabelFromFlag (report.c:217-246)
-    uint8_t pf = ps ? ps->pairflg : 0;
-    if (ps && ps->mate && a.sidx == ps->mate->sidx) pf |= RP_CONTIG;       // report.c:1173-1176 (an unprinted mate carries sequence 0)
-    if (a.status & MF_PARTIAL) flagchr = 'P';
-    else if (pf & RP_MAPPED) flagchr = (pf & RP_CONTIG) ? ((pf & RP_PROPER) ? ((pf & RP_WITHIN) ? 'A' : 'B') : 'C') : 'D';
-    else flagchr = 'S';
-  } else flagchr = (a.status & MF_MULTI) ? 'R' : 'N';
+  const char flagchr = map_label(a, ps);
   const int mq = mapped ? (a.mapscor > CIGAR_MAXTAG ? CIGAR_MAXTAG : a.mapscor) : 0;
   snprintf(buf, sizeof(buf), "cigar:%c:%2.2d ", flagchr, mq);
   o += buf;
@@ -487,6 +498,37 @@ bool print_cigar_line(std::string &o, const ReadCtx &cx, uint32_t i, const Ali &
   o += buf;
   if (!put_cigar(o, mapped ? a.dstr : nullptr, false, true, 0, 0, 'H')) return false;
   o.push_back('\n');
+  return true;
+}
+
+// -f ssaha (fprintREPALIssaha, report.c:579-646; line layout report.c:206): label and mapping quality as in the CIGAR line, then
+// score, read, sequence, the read range in the read's own direction, the reference range, F/C, matching columns, their share of
+// the alignment's columns in per cent, read length, sequence length
+bool print_ssaha_line(std::string &o, const ReadCtx &cx, uint32_t i, const Ali &a, const PairSide *ps = nullptr) {
+  char buf[160];
+  const bool mapped = (a.status & MF_MAPPED) != 0;
+  const int mq = mapped ? (a.mapscor > CIGAR_MAXTAG ? CIGAR_MAXTAG : a.mapscor) : 0;
+  snprintf(buf, sizeof(buf), "alignment:%c:%2.2d %-5d ", map_label(a, ps), mq, mapped ? a.swatscor : 0);
+  o += buf;
+  first_word(o, cx.rv->names + cx.rv->name_off[i], false);
+  o.push_back(' ');
+  uint32_t qs = 0, qe = 0, slen = 0;
+  int same = 0;
+  double share = .0;
+  char sense = '*';
+  if (mapped) {
+    if (a.sidx < 0 || a.sidx >= cx.nseq || !a.dstr) return false;
+    first_word(o, cx.seqnames[a.sidx], false);
+    if (a.status & MF_REVERSE) { qs = a.qe; qe = a.qs; sense = 'C'; } else { qs = a.qs; qe = a.qe; sense = 'F'; }
+    slen = cx.seqlen[a.sidx];
+    same = diff_matches(a.dstr);
+    const int cols = diff_columns(a.dstr);
+    share = cols > 0 ? ((double)100 * same) / cols : .0;
+  } else o.push_back('*');
+  const uint32_t qlen = cx.rv->read_off[i + 1] - cx.rv->read_off[i];
+  snprintf(buf, sizeof(buf), " %8u %8u %9u %9u   %c %7d %5.2f %u %u\n", qs, qe, mapped ? (unsigned)a.ss : 0u, mapped ? (unsigned)a.se : 0u, sense, same, share,
+           qlen, slen);
+  o += buf;
   return true;
 }
 
@@ -565,9 +607,26 @@ bool print_sam_line(std::string &o, const ReadCtx &cx, uint32_t i, const Ali &a,
   return true;
 }
 
+bool print_line(std::string &o, const ReadCtx &cx, uint32_t i, const Ali &a, const PairSide *ps) {       // writeREPALI's switch (report.c:1178-1200)
+  switch (cx.op->format) {
+    case SMALTGPU_FMT_SAM: return print_sam_line(o, cx, i, a, ps);
+    case SMALTGPU_FMT_SSAHA: return print_ssaha_line(o, cx, i, a, ps);
+    default: return print_cigar_line(o, cx, i, a, ps);
+  }
+}
+
 }  // namespace
 
-struct smaltgpu_report { std::string text; std::vector<std::string> part; std::vector<int> draw; };
+struct smaltgpu_report { std::string text; std::vector<std::string> part; std::vector<int> draw; std::vector<uint32_t> seqlen; };
+
+namespace {
+int check_format(const smaltgpu_report *rp, const smaltgpu_report_opts *op, int64_t nseq) {
+  if (op->format != SMALTGPU_FMT_CIGAR && op->format != SMALTGPU_FMT_SAM && op->format != SMALTGPU_FMT_SSAHA) return smaltgpu_set_error(SMALTGPU_EARG, "unknown output format");
+  if (op->format == SMALTGPU_FMT_SSAHA && (int64_t)rp->seqlen.size() != nseq)
+    return smaltgpu_set_error(SMALTGPU_EARG, "SSAHA lines carry the sequence lengths: call smaltgpu_report_header on this report first");
+  return SMALTGPU_OK;
+}
+}  // namespace
 
 extern "C" smaltgpu_report *smaltgpu_report_create(void) { return new smaltgpu_report(); }
 extern "C" void smaltgpu_report_free(smaltgpu_report *r) { delete r; }
@@ -577,6 +636,8 @@ extern "C" int smaltgpu_report_header(smaltgpu_report *rp, const char *const *se
   if (!rp || !seqnames || !sop || !op || !text || !len || nseq < 1) return smaltgpu_set_error(SMALTGPU_EARG, "null argument");
   std::string &o = rp->text;
   o.clear();
+  rp->seqlen.resize((size_t)nseq);
+  for (int64_t s = 0; s < nseq; s++) rp->seqlen[(size_t)s] = (uint32_t)(sop[s + 1] - sop[s]);
   if (op->format == SMALTGPU_FMT_SAM && (op->modflags & SMALTGPU_REP_HEADER)) {       // writeSAMHeaderf (report.c:1266-1300)
     char buf[64];
     o += "@HD\tVN:1.3\tSO:unknown\n";
@@ -598,9 +659,9 @@ extern "C" int smaltgpu_report_emit(smaltgpu_report *rp, const smaltgpu_post_out
                                     const char *const *seqnames, int64_t nseq, const smaltgpu_report_opts *op, int nthreads, const char **text, uint64_t *len) {
   if (!rp || !post || !reads || !seqnames || !op || !text || !len) return smaltgpu_set_error(SMALTGPU_EARG, "null argument");
   if (post->nreads != reads->nreads) return smaltgpu_set_error(SMALTGPU_EARG, "results and reads differ in number");
-  if (op->format != SMALTGPU_FMT_CIGAR && op->format != SMALTGPU_FMT_SAM) return smaltgpu_set_error(SMALTGPU_EARG, "unknown output format");
+  if (int e = check_format(rp, op, nseq)) return e;
   const uint32_t n = post->nreads;
-  ReadCtx cx{post, reads, op, seqnames, nseq};
+  ReadCtx cx{post, reads, op, seqnames, nseq, rp->seqlen.data()};
   for (uint32_t i = 0; i < n; i++) {
     if (post->needs_reference[i]) return smaltgpu_set_error(SMALTGPU_EARG, "a read was left to the caller by smaltgpu_postprocess (needs_reference): give it the packed reference");
     if (raw && raw->stat[i].errcode) { char m[96]; snprintf(m, sizeof(m), "read %u carries error code %d", i, raw->stat[i].errcode); return smaltgpu_set_error(SMALTGPU_EINTERNAL, m); }
@@ -622,7 +683,7 @@ extern "C" int smaltgpu_report_emit(smaltgpu_report *rp, const smaltgpu_post_out
     for (uint32_t i = lo; i < hi; i++) {
       if (!select_read(cx, i, rp->draw[i], alis, st)) { bad[(size_t)t] = (int)i; return; }
       for (const Ali &a : alis) {
-        const bool ok = op->format == SMALTGPU_FMT_SAM ? print_sam_line(o, cx, i, a) : print_cigar_line(o, cx, i, a);
+        const bool ok = print_line(o, cx, i, a, nullptr);
         if (!ok) { bad[(size_t)t] = (int)i; return; }
       }
     }
@@ -728,8 +789,7 @@ bool pair_entries(const PairJob &jb, uint32_t p, Table &A, Table &B, smgpairs::J
 bool pair_lines(std::string &o, const PairJob &jb, uint32_t p, const Table &A, const Table &B, const std::vector<Entry> &entries, PairSheet &sh) {
   sh.clear();
   for (const Entry &e : entries) sheet_add(sh, e, A, B);
-  const bool sam = jb.op->format == SMALTGPU_FMT_SAM;
-  auto line = [&](int w, const Ali &a, const PairSide *ps) { return sam ? print_sam_line(o, jb.cx[w], p, a, ps) : print_cigar_line(o, jb.cx[w], p, a, ps); };
+  auto line = [&](int w, const Ali &a, const PairSide *ps) { return print_line(o, jb.cx[w], p, a, ps); };
   for (int w = 0; w < 2; w++) sh.printed[w].assign(sh.side[w].size(), 0);
   for (const PairSheet::Link &ln : sh.links) {                       // reportWrite (report.c:1758-1867): the pairs first ...
     const Ali &a = sh.side[0][(size_t)ln.ia], &b = sh.side[1][(size_t)ln.ib];
@@ -751,8 +811,8 @@ extern "C" int smaltgpu_report_emit_pairs(smaltgpu_report *rp, const smaltgpu_pa
   if (!rp || !pairs || !reads || !mates || !seqnames || !op || !po || !text || !len) return smaltgpu_set_error(SMALTGPU_EARG, "smaltgpu_report_emit_pairs: null argument");
   const uint32_t n = pairs->blk.npairs;
   if (reads->nreads != n || mates->nreads != n) return smaltgpu_set_error(SMALTGPU_EARG, "smaltgpu_report_emit_pairs: reads, mates and mapped pairs differ in number");
-  if (op->format != SMALTGPU_FMT_CIGAR && op->format != SMALTGPU_FMT_SAM) return smaltgpu_set_error(SMALTGPU_EARG, "unknown output format");
-  PairJob jb{pairs, {ReadCtx{nullptr, reads, op, seqnames, nseq}, ReadCtx{nullptr, mates, op, seqnames, nseq}}, op, po};
+  if (int e = check_format(rp, op, nseq)) return e;
+  PairJob jb{pairs, {ReadCtx{nullptr, reads, op, seqnames, nseq, rp->seqlen.data()}, ReadCtx{nullptr, mates, op, seqnames, nseq, rp->seqlen.data()}}, op, po};
   if (nthreads < 1) nthreads = 1;
   if ((uint32_t)nthreads > n / 256 + 1) nthreads = (int)(n / 256 + 1);
   const bool drawing = (op->outflags & SMALTGPU_OUT_RANDSEL) != 0;

@@ -5,7 +5,7 @@ lines with pair classes (A/B/C/D/S/R/N), SAM lines with flags, mate fields and t
 reporting of ambiguous pairs (-r <seed> / -r -1 / default).  One file per (fixture, variant) of manifest_pair_reports.json.
 Data only; needs /root/reference (through oracle/_ref) and is not run by the tests.
 
-    python tests/golden/make_golden_pair_reports.py
+    python tests/golden/make_golden_pair_reports.py [variant ...]    (variants named: only those are made, the others stay as they are)
 """
 import gzip
 import json
@@ -30,6 +30,8 @@ VARIANTS = {
     "sam_all": ["-d", "0", "-f", "sam:nohead"],
     "cigar_ident": ["-r", "3", "-y", "0.95", "-f", "cigar"],
     "cigar_filt": ["-r", "3", "-m", "50", "-y", "0.9", "-f", "cigar"],     # -m changes the mapping itself: whole-program test only
+    "ssaha": ["-r", "3", "-f", "ssaha"],
+    "ssaha_all": ["-d", "0", "-f", "ssaha"],
 }
 REMAP = {"cigar_filt"}
 
@@ -37,7 +39,9 @@ REMAP = {"cigar_filt"}
 def main():
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
     pairs = json.load(open(os.path.join(HERE, "manifest_pairs.json")))
-    man = []
+    only = set(sys.argv[1:])
+    mpath = os.path.join(HERE, "manifest_pair_reports.json")
+    man = [m for m in json.load(open(mpath)) if m["variant"] not in only] if only else []
     with tempfile.TemporaryDirectory() as tmp:
         for e in pairs:
             tag = e["tag"]
@@ -50,6 +54,8 @@ def main():
             pre = os.path.join(tmp, tag)
             subprocess.run([SMALT, "index", "-k", str(e["k"]), "-s", str(e["s"]), pre, paths[".fa"]], check=True, capture_output=True)
             for v, vopts in VARIANTS.items():
+                if only and v not in only:
+                    continue
                 if "-d" in e["opts"].split() and "-d" in vopts:      # the fixture's calls were recorded with its own -d (it decides the best-only flag of the mapping)
                     continue
                 out = os.path.join(tmp, "o.txt")
@@ -60,7 +66,7 @@ def main():
                     g.write(txt)
                 man.append(dict(tag=tag, variant=v, opts=opts, lines=txt.count(b"\n"), remap=v in REMAP))
                 print(tag, v, txt.count(b"\n"), "lines")
-    json.dump(man, open(os.path.join(HERE, "manifest_pair_reports.json"), "w"), indent=1)
+    json.dump(man, open(mpath, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -4,7 +4,7 @@ reference compiled here by oracle/Makefile) prints for the golden inputs -- CIGA
 best alignments (-r), output filters (-m, -y) -- one file per (fixture, command-line variant) of manifest_report.json.
 Data only; needs /root/reference (through oracle/_ref) and is not run by the tests.
 
-    python tests/golden/make_golden_report.py
+    python tests/golden/make_golden_report.py [variant ...]       (variants named: only those are made, the others stay as they are)
 """
 import gzip
 import json
@@ -31,22 +31,28 @@ VARIANTS = {
     "sam_d0": ["-r", "3", "-d", "0", "-f", "samsoft"],
     "cigar_r7": ["-r", "7", "-f", "cigar"],
     "cigar_dall": ["-r", "3", "-d", "-1", "-f", "cigar"],
+    "ssaha": ["-r", "3", "-f", "ssaha"],
+    "ssaha_d0": ["-r", "3", "-d", "0", "-f", "ssaha"],
 }
 # the same reads spelled differently (golden_util.reshape_reads): variant -> (style, options)
 RESHAPED = {"wrapped_sam": ("wrapped", ["-r", "3", "-f", "sam"]), "fasta_sam": ("fasta", ["-r", "3", "-f", "sam"]), "fasta_cigar": ("fasta", ["-r", "3", "-f", "cigar"])}
 # every fixture gets cigar + sam; the others go to a few fixtures to keep the data small
-EXTRA = {"g_k13s6_ties": ["samx", "samclip", "cigar_norand", "cigar_filt", "cigar_d0", "sam_d0", "cigar_r7", "cigar_dall"],
-         "g_k13s6_hash": ["samx", "samclip", "cigar_norand", "cigar_filt", "cigar_d0"], "g_k11s2_d20": ["samx", "cigar_filt"],
-         "g_k11s4_cat": ["samclip", "cigar_norand"], "g_k13s3_short": ["samx", "cigar_d0"]}
+EXTRA = {"g_k13s6_ties": ["samx", "samclip", "cigar_norand", "cigar_filt", "cigar_d0", "sam_d0", "cigar_r7", "cigar_dall", "ssaha", "ssaha_d0"],
+         "g_k13s6_hash": ["samx", "samclip", "cigar_norand", "cigar_filt", "cigar_d0", "ssaha"], "g_k11s2_d20": ["samx", "cigar_filt"],
+         "g_k11s4_cat": ["samclip", "cigar_norand", "ssaha"], "g_k13s3_short": ["samx", "cigar_d0", "ssaha"]}
 
 
 def main():
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
-    man = []
+    only = set(sys.argv[1:])
+    mpath = os.path.join(HERE, "manifest_report.json")
+    man = [m for m in json.load(open(mpath)) if m["variant"] not in only] if only else []
     with tempfile.TemporaryDirectory() as tmp:
         for e in gu.MANIFEST_ALL:
             fx = gu.unpack(e, tmp)
             for v in ["cigar", "sam"] + EXTRA.get(e["tag"], []):
+                if only and v not in only:
+                    continue
                 opts = e["opts"].split()
                 if "-c" in opts and "-x" not in opts:
                     opts = ["-x"] + opts                      # `smalt map` takes -c only together with -x
@@ -62,7 +68,7 @@ def main():
                 remap = "-d" in VARIANTS[v] and VARIANTS[v][VARIANTS[v].index("-d") + 1] != "0"
                 man.append(dict(tag=e["tag"], variant=v, opts=opts + VARIANTS[v], lines=txt.count(b"\n"), remap=remap))
                 print(e["tag"], v, txt.count(b"\n"), "lines")
-            if e["tag"] in ("g_k13s6_hash", "g_k13s6_nq"):
+            if e["tag"] in ("g_k13s6_hash", "g_k13s6_nq") and not only:
                 for v, (style, vopts) in RESHAPED.items():
                     if style == "fasta" and "-q" in e["opts"]:
                         continue          # without base qualities the seeding differs: the raw alignments of the fixture do not apply
@@ -75,7 +81,7 @@ def main():
                         g.write(txt)
                     man.append(dict(tag=e["tag"], variant=v, opts=opts + vopts, lines=txt.count(b"\n"), input=style))
                     print(e["tag"], v, txt.count(b"\n"), "lines")
-    json.dump(man, open(os.path.join(HERE, "manifest_report.json"), "w"), indent=1)
+    json.dump(man, open(mpath, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -188,6 +188,11 @@ int main(int argc, char **argv) {
   if (ro.outflags & SMALTGPU_OUT_RANDSEL) srand48(geti("seed", 1));
   smaltgpu_report *rep = smaltgpu_report_create();
   const char *out; uint64_t len;
+  {                                                  // the report learns the sequence lengths here (SSAHA lines); the header text itself is not compared
+    smaltgpu_report_opts quiet = ro;
+    quiet.modflags &= ~(uint32_t)SMALTGPU_REP_HEADER;
+    if (smaltgpu_report_header(rep, name_ptr.data(), sop.data(), (int64_t)names.size(), &quiet, "pair_check", "0", 0, nullptr, &out, &len)) { fprintf(stderr, "header: %s\n", smaltgpu_last_error()); return 1; }
+  }
   if (smaltgpu_report_emit_pairs(rep, ps, &v[0], &v[1], name_ptr.data(), (int64_t)names.size(), &ro, &po, bp.nthreads, &out, &len)) { fprintf(stderr, "emit: %s\n", smaltgpu_last_error()); return 1; }
   fwrite(out, 1, len, stdout);
   // pair flags for the caller to compare with the reference's (PE lines)

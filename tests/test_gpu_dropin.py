@@ -47,6 +47,7 @@ def _data(tmp, nchr, chrlen, nreads, rlen, seed, with_n=False):
     (13, 6, 700, 1_500, 100, ["-f", "sam", "-n", "2", "-O", "-r", "-1"]),   # >= 512 reference sequences: concatenated mode (hashCollectHitsUsingCutoff, assignSequenceIndex)
     (11, 4, 600, 2_000, 120, ["-f", "cigar", "-d", "-1"]),                   # concatenated mode, all alignments
     (13, 6, 3000, 400, 100, ["-f", "sam", "-n", "2", "-O", "-r", "-1"]),    # a contig set: 3000 reference sequences (no limit on their number in concatenated mode)
+    (13, 6, 3, 300_000, 120, ["-f", "ssaha", "-n", "2", "-O", "-r", "-1"]),  # SSAHA2 lines (fprintREPALIssaha, report.c:579)
 ])
 def test_smalt_map_prints_the_same(k, s, nchr, chrlen, rlen, opts, tmp_path):
     tmp = str(tmp_path)
@@ -148,6 +149,7 @@ def _pair_data(tmp, nchr, chrlen, npairs, rlen, seed, rep=0.3, ins=(300, 30)):
     (13, 6, 2, 250_000, 100, (300, 30), ["-f", "cigar", "-i", "500", "-x", "-c", "0.4"]),       # cover threshold (fraction of each mate) in all four rounds
     (13, 6, 3, 300_000, 150, (300, 30), ["-f", "sam", "-i", "500", "-x", "-c", "45"]),          # cover threshold in bases (the reference accepts -c with -x only)
     (13, 6, 600, 2_000, 100, (300, 30), ["-f", "cigar", "-i", "500", "-x", "-c", "0.5"]),       # cover threshold in concatenated mode: plain rounds take the sequential candidate stage
+    (13, 6, 3, 300_000, 100, (300, 30), ["-f", "ssaha", "-i", "500"]),                          # SSAHA2 lines with the pair classes
 ])
 def test_smalt_map_pairs_prints_the_same(k, s, nchr, chrlen, rlen, ins, opts, tmp_path):
     """Paired reads: rmapPair's rounds (rare mate, restricted mate, unrestricted re-map, re-map over the on-the-fly k=5 index)

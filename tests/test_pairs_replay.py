@@ -54,6 +54,8 @@ def driver_args(opts, k):
             pass
         elif o == "-f":
             key, _, mods = v.partition(":")
+            if key == "ssaha":
+                a["fmt"] = 2
             if key in ("sam", "samsoft"):
                 a["fmt"] = 1
                 mod = 4 | 2

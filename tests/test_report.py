@@ -2,8 +2,8 @@
 `<tag>.<variant>.out.gz` files are what `smalt map` (oracle/_ref/smalt) printed for the golden inputs with the options of
 tests/golden/manifest_report.json (tests/golden/make_golden_report.py).  Host code, no GPU needed: the raw alignments of the
 `*.post.txt.gz` fixtures (what the GPU path delivers, test_postprocess.py) go through smaltgpu_postprocess and
-smaltgpu_report_emit, the reads through smaltgpu_reads_parse; the text must equal the reference's line for line -- CIGAR and SAM
-lines, soft and hard clipping, X operations, mapping qualities, the random choice among equal best alignments (-r <seed>:
+smaltgpu_report_emit, the reads through smaltgpu_reads_parse; the text must equal the reference's line for line -- CIGAR, SSAHA and
+SAM lines, soft and hard clipping, X operations, mapping qualities, the random choice among equal best alignments (-r <seed>:
 drand48 in read order), reads reported unmapped for multiple placements (-r -1), output filters (-m, -y), SAM header."""
 import ctypes as C
 import gzip
@@ -30,6 +30,8 @@ def report_opts(api, opts):
     key, _, mods = fmt.partition(":")
     if key == "cigar":
         ro.format = api.FMT_CIGAR
+    elif key == "ssaha":
+        ro.format = api.FMT_SSAHA
     else:
         ro.format = api.FMT_SAM
         ro.modflags = api.REP_HEADER | api.REP_SOFTCLIP
