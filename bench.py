@@ -468,7 +468,7 @@ def long_main(args):
             try:
                 out = mapper.fetch_results()
             except api.SmaltGpuError as e:
-                if e.code not in (-5, -6):
+                if e.code not in (-5, -6, -8):
                     raise
                 out = None                 # single reads over a device-side limit keep their error code; the others are complete
             if out is not None:

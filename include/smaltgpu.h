@@ -24,8 +24,14 @@ enum {
   SMALTGPU_ENOMEM = -4,     /* host or device allocation failed (ERRCODE_NOMEM) */
   SMALTGPU_ECAP = -5,       /* a work pool overflowed: smaltgpu_map_batch recovers by itself (reads re-mapped in smaller batches);
                              * from smaltgpu_fetch_* / in stat[].errcode it marks the reads to map again */
-  SMALTGPU_EINTERNAL = -6   /* device-side assertion (ERRCODE_ASSERT analogue) */
+  SMALTGPU_EINTERNAL = -6,  /* device-side assertion (ERRCODE_ASSERT analogue) */
+  SMALTGPU_ESCORE = -8      /* in stat[].errcode: the traceback of one of the read's alignments does not add up to the score of its pass.
+                             * The reference stops at such a read with ERRCODE_SWATSCOR (alignment.c:767, "Inconsistency when calculating
+                             * Smith-Waterman scores"): it happens with alignment scores (-S) whose gap extension is much cheaper than
+                             * the opening, because the banded passes do not re-open a gap from a gap cell (alignment.c:1126-1193) */
 };
+/* return values of the mapping calls that mean "the batch is complete, some reads carry a code of their own in stat[].errcode" */
+#define SMALTGPU_IS_READ_ERROR(rv) ((rv) == SMALTGPU_ECAP || (rv) == SMALTGPU_EINTERNAL || (rv) == SMALTGPU_ESCORE)
 
 /* RMAP_FLAGS subset honoured on this path (same values as rmap.h:53-65). */
 enum {

@@ -159,7 +159,7 @@ static void run_batch(struct CombSlot *d, const smaltgpu_index *ix, CombReq **re
     }
     /* pool overflows are recovered inside the library; what can remain is a read that fails on its own (stat[].errcode):
      * the batch is complete for every other read, so hand the slices out and let the owner of that read report it */
-    if ((rv == SMALTGPU_ECAP || rv == SMALTGPU_EINTERNAL) && o.nreads == ntot) rv = 0;
+    if (SMALTGPU_IS_READ_ERROR(rv) && o.nreads == ntot) rv = 0;
   }
   if (rv) for (i = 0; i < nreq; i++) { strncpy(reqs[i]->err, smaltgpu_last_error(), sizeof(reqs[i]->err) - 1); reqs[i]->err[sizeof(reqs[i]->err) - 1] = 0; }
   for (i = 0, r0 = 0; i < nreq; i++) {                    /* every request gets its own copy of its slice */

@@ -195,7 +195,7 @@ int rmapSingle(ErrMsg *errmsgp, RMap *rmp, SeqFastq *readp, int ktuple_maxhit, u
     if (smaltgpu_map_batch(g_map[slot].mp, (const uint8_t *)g_map[slot].bases,
                            (qualp && qlen == rlen) ? (const uint8_t *)g_map[slot].quals : NULL, off, 1, &par, &out))
       ERRMSGNO(errmsgp, ERRCODE_FAILURE);
-    if (out.stat[0].errcode) ERRMSGNO(errmsgp, ERRCODE_FAILURE);
+    if (out.stat[0].errcode) ERRMSGNO(errmsgp, out.stat[0].errcode == SMALTGPU_ESCORE ? ERRCODE_SWATSCOR : ERRCODE_FAILURE);
     if ((errcode = resultSetInjectRaw(rmp->rsrp, (unsigned)(out.res_off[1] - out.res_off[0]), out.res + out.res_off[0], out.diffstr,
                                       out.stat[0].swatscor_max, out.stat[0].swatscor_2ndmax)))
       ERRMSGNO(errmsgp, errcode);
@@ -267,7 +267,7 @@ int rmapGpuBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, int n, int 
     const int rv = smaltgpu_map_batch(g_map[slot].mp, (const uint8_t *)g_map[slot].bases, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
                                       g_map[slot].off, (uint32_t)n, &par, &g_map[slot].out);
     /* a read that fails on its own leaves its code in stat[].errcode; rmapGpuFinish reports it for that read */
-    if (rv && !((rv == SMALTGPU_ECAP || rv == SMALTGPU_EINTERNAL) && g_map[slot].out.nreads == (uint32_t)n)) {
+    if (rv && !(SMALTGPU_IS_READ_ERROR(rv) && g_map[slot].out.nreads == (uint32_t)n)) {
       fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error());
       ERRMSGNO(errmsgp, ERRCODE_FAILURE);
     }
@@ -310,7 +310,10 @@ int rmapGpuFinish(ErrMsg *errmsgp, RMap *rmp, int i, SeqFastq *readp, short max_
   if ((errcode = makeRMAPPROFfromRead(rmp->prp, readp, scormtxp, codecp))) ERRMSGNO(errmsgp, errcode);
   (void)seqFastqGetConstSequence(readp, &rlen, NULL);
   if (rlen < hashTableGetKtupLen(htp, NULL)) return ERRCODE_SUCCESS;                      /* ERRCODE_SHORTSEQ is swallowed (rmap.c:1736) */
-  if (o->stat[i].errcode) { gpuFailOrderly("a read failed on the device"); ERRMSGNO(errmsgp, ERRCODE_FAILURE); }
+  if (o->stat[i].errcode) {                /* the reference's own per-read failure keeps its code (alignment.c:767 -> rmap.c:1417) */
+    gpuFailOrderly("a read failed on the device");
+    ERRMSGNO(errmsgp, o->stat[i].errcode == SMALTGPU_ESCORE ? ERRCODE_SWATSCOR : ERRCODE_FAILURE);
+  }
   double t0 = tmNow(), t1;
   if ((errcode = resultSetInjectRaw(rmp->rsrp, (unsigned)(o->res_off[i + 1] - o->res_off[i]), o->res + o->res_off[i], o->diffstr,
                                     o->stat[i].swatscor_max, o->stat[i].swatscor_2ndmax)))
@@ -420,7 +423,7 @@ static int gpuPairRound(ErrMsg *errmsgp, int slot, SeqFastq *const *sq, int ns, 
       ctx.raw_alignments = kind == GPUCOMB_APPEND || kind == GPUCOMB_FINE;
       rv = smaltgpu_map_batch_ctx(g_map[slot].mp, (const uint8_t *)g_map[slot].bases, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
                                   g_map[slot].off, (uint32_t)ns, par, &ctx, out);
-      if ((rv == SMALTGPU_ECAP || rv == SMALTGPU_EINTERNAL) && out->nreads == (uint32_t)ns) rv = 0;      /* gpuPairTake reports the read */
+      if (SMALTGPU_IS_READ_ERROR(rv) && out->nreads == (uint32_t)ns) rv = 0;      /* gpuPairTake reports the read */
     }
     if (rv) { fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error()); ERRMSGNO(errmsgp, ERRCODE_FAILURE); }
   }
@@ -433,7 +436,7 @@ static int gpuPairTake(ErrMsg *errmsgp, RMap *rmp, GpuPair *pp, int w, const sma
 {
   int errcode;
   ResultSet *rs = pp->rs[w];
-  if (o->stat[i].errcode) { char m[96]; snprintf(m, sizeof(m), "read failed on the device (code %d)", o->stat[i].errcode); gpuFailOrderly(m); ERRMSGNO(errmsgp, ERRCODE_FAILURE); }
+  if (o->stat[i].errcode) { char m[96]; snprintf(m, sizeof(m), "read failed on the device (code %d)", o->stat[i].errcode); gpuFailOrderly(m); ERRMSGNO(errmsgp, o->stat[i].errcode == SMALTGPU_ESCORE ? ERRCODE_SWATSCOR : ERRCODE_FAILURE); }
   resultSetAlignmentStats(rs, o->stat[i].n_ali_done, o->stat[i].n_ali_tot, max_depth, o->stat[i].n_hits_used, o->stat[i].n_hits_tot);
   if ((errcode = resultSetAppendRaw(rs, (unsigned)(o->res_off[i + 1] - o->res_off[i]), o->res + o->res_off[i], o->diffstr,
                                     o->stat[i].swatscor_max, o->stat[i].swatscor_2ndmax)))

@@ -310,7 +310,7 @@ class Mapper:
         bases, q, off = self._pack(reads, quals)
         out = BatchOut()
         rv = lib().smaltgpu_map_batch(self.h, bases, q, off, len(reads), C.byref(params), C.byref(out))
-        if rv != 0 and not (allow_read_errors and rv in (-5, -6) and out.nreads == len(reads)):
+        if rv != 0 and not (allow_read_errors and rv in (-5, -6, -8) and out.nreads == len(reads)):
             _check(rv)
         return self._unpack(out)
 

@@ -811,7 +811,7 @@ extern "C" int smaltgpu_fetch_end(smaltgpu_mapper *m, smaltgpu_batch_out *out) {
     for (std::thread &x : th) x.join();
   }
   out->nreads = n; out->res_off = m->h_res_off.data(); out->res = m->o_res.data(); out->diffstr = m->h_dstr.data(); out->stat = m->o_stat.data();
-  if (first_err) return fail(first_err, "%u of %u reads hit a device-side limit (-5%s) or assertion (-6); first: read %u code %d (see stat[].errcode)", nerr, n,
+  if (first_err) return fail(first_err, "%u of %u reads hit a device-side limit (-5%s), an assertion (-6) or the reference's own score check (-8); first: read %u code %d (see stat[].errcode)", nerr, n,
                              m->pool_overflow ? ": a batch-wide work pool overflowed" : "", first_err_read, first_err);
   return SMALTGPU_OK;
 }
@@ -960,7 +960,7 @@ static int remap_overflowed(smaltgpu_mapper *m, const uint8_t *bases, const uint
     smaltgpu_batch_out o;
     const int rv = map_range(m, sb.data(), quals ? sq.data() : nullptr, so.data(), (uint32_t)L.size(), par, &o, ctx ? &sub : nullptr);
     nbatches++;
-    if (rv && !((rv == SMALTGPU_ECAP || rv == SMALTGPU_EINTERNAL) && o.nreads == L.size())) return rv;
+    if (rv && !(SMALTGPU_IS_READ_ERROR(rv) && o.nreads == L.size())) return rv;
     std::vector<uint32_t> failed;
     for (size_t t = 0; t < L.size(); t++) {
       const uint32_t i = L[t];

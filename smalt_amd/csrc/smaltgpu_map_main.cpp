@@ -51,6 +51,7 @@ void usage() {
           "  -c <num>   minimum k-mer cover (fraction of the read if <= 1, else bases)\n"
           "  -x         more sensitive search (all seeds, deeper candidate lists)\n"
           "  -q <int>   base quality threshold for k-mer words\n"
+          "  -S <spec>  alignment scores, e.g. match=1,subst=-2,gapopen=-4,gapext=-3 (the default; any subset)\n"
           "  -n <int>   host threads for parsing, post-processing and formatting (default: up to 16)\n"
           "  -B <int>   reads per GPU batch (default 262144)\n"
           "  -g <list>  devices, e.g. 0 or 0,1,2,3 (default 0): the index is read once and copied device to device, every device gets\n"
@@ -58,7 +59,7 @@ void usage() {
           "  -i <int>   maximum insert size of read pairs (default 500); -j <int> minimum insert size (default 0)\n"
           "  -l <lib>   pair library: pe (default) | mp | pp\n"
           "with two read files the reads are mapped as pairs (read i of the first with read i of the second file);\n"
-          "split reads (-p), -w and insert-size histograms (-g) go through the bound reference program (INTEGRATION.md)\n");
+          "split reads (-p), -w, -a and insert-size histograms (-g) go through the bound reference program (INTEGRATION.md)\n");
   exit(2);
 }
 
@@ -131,7 +132,7 @@ struct Source {
 }  // namespace
 
 int main(int argc, char **argv) {
-  const char *fmt = "cigar", *oufil = nullptr;
+  const char *fmt = "cigar", *oufil = nullptr, *scorespec = nullptr;
   int m = -1, d = 0, seed = 0, q = 0, nthreads = 0, ins_max = 500, ins_min = 0, lib = SMALTGPU_LIB_PE;
   std::vector<int> devices;
   bool d_given = false, randrepeat = true, exhaustive = false;
@@ -141,8 +142,8 @@ int main(int argc, char **argv) {
   for (; a < argc && argv[a][0] == '-' && argv[a][1]; a++) {
     const char o = argv[a][1];
     if (o == 'x' && !argv[a][2]) { exhaustive = true; continue; }
-    if (argv[a][2] || !strchr("fomdrycqnBgijl", o)) {
-      if (strchr("pwSTFa", o) && !argv[a][2]) die("option not supported by this program (use the bound `smalt map`, INTEGRATION.md)", argv[a]);
+    if (argv[a][2] || !strchr("fomdrycqnBgijlS", o)) {
+      if (strchr("pwTFa", o) && !argv[a][2]) die("option not supported by this program (use the bound `smalt map`, INTEGRATION.md)", argv[a]);
       usage();
     }
     if (a + 1 >= argc) usage();
@@ -160,6 +161,7 @@ int main(int argc, char **argv) {
       case 'i': ins_max = atoi(val); break;
       case 'j': ins_min = atoi(val); break;
       case 'l': lib = !strcmp(val, "pe") ? SMALTGPU_LIB_PE : !strcmp(val, "mp") ? SMALTGPU_LIB_MP : !strcmp(val, "pp") ? SMALTGPU_LIB_PP : 0; if (!lib) die("-l: pe, mp or pp"); break;
+      case 'S': scorespec = val; break;
       case 'B': batch = atol(val); if (batch < 1 || batch > (1L << 20)) die("-B out of range (1 .. 1048576)"); break;
       case 'g': for (const char *c = val; *c;) { devices.push_back(atoi(c)); while (*c && *c != ',') c++; if (*c) c++; } break;
     }
@@ -223,6 +225,30 @@ int main(int argc, char **argv) {
   smaltgpu_params par;
   smaltgpu_params_default(&par, ix);
   if (m >= 0) par.min_swatscor = m;
+  if (scorespec) {               // -S match=1,subst=-2,gapopen=-4,gapext=-3: any subset, in any order (menu.c:671-701, :875-935, smalt.c:539-550)
+    struct { const char *key; int32_t *to; int lo, hi; } slot[4] = {{"match", &par.match, 0, 127}, {"subst", &par.mismatch, -127, 0},
+                                                                   {"gapopen", &par.gap_init, -127, 0}, {"gapext", &par.gap_ext, -127, 0}};
+    const std::string spec(scorespec);
+    for (size_t at = 0; at < spec.size();) {
+      size_t end = spec.find(',', at);
+      if (end == std::string::npos) end = spec.size();
+      const std::string item = spec.substr(at, end - at);
+      at = end + 1;
+      if (item.empty()) continue;
+      const size_t eq = item.find('=');
+      const std::string key = item.substr(0, eq), num = eq == std::string::npos ? "" : item.substr(eq + 1);
+      size_t dg = (!num.empty() && (num[0] == '+' || num[0] == '-')) ? 1 : 0;
+      bool digits = !num.empty();
+      for (size_t c = dg; c < num.size(); c++) if (!isdigit((unsigned char)num[c])) digits = false;
+      if (!digits) die("-S: key=number expected", item.c_str());
+      const int v = atoi(num.c_str());
+      int hit = -1;
+      for (int t = 0; t < 4; t++) if (key == slot[t].key) hit = t;
+      if (hit < 0) die("-S: keys are match, subst, gapopen, gapext", item.c_str());
+      if (v < slot[hit].lo || v > slot[hit].hi) die("-S: value out of range", item.c_str());
+      *slot[hit].to = v;
+    }
+  }
   par.min_swatscor_below_max = d;
   if (d) par.rmapflg &= ~(uint32_t)SMALTGPU_FLG_BEST;
   if (exhaustive) par.rmapflg |= SMALTGPU_FLG_NOSHRTINFO | SMALTGPU_FLG_SENSITIVE;      // smalt.c:531-533
@@ -353,7 +379,7 @@ int main(int argc, char **argv) {
         memset(&cx, 0, sizeof(cx));
         cx.hitlist_len = b.hitlen.empty() ? nullptr : b.hitlen.data();
         const int rv = smaltgpu_map_batch_ctx(W.mp, b.v.bases, b.v.has_qual ? b.v.quals : nullptr, b.v.read_off, b.v.nreads, &par, cx.hitlist_len ? &cx : nullptr, &b.raw);
-        if (rv && !((rv == SMALTGPU_ECAP || rv == SMALTGPU_EINTERNAL) && b.raw.nreads == b.v.nreads)) err = why("mapping the reads failed");
+        if (rv && !(SMALTGPU_IS_READ_ERROR(rv) && b.raw.nreads == b.v.nreads)) err = why("mapping the reads failed");
         t1 = now(); t_map[w] += t1 - t0; t0 = t1;
         if (err.empty() && smaltgpu_postprocess(W.post, sop, nseq, &b.raw, b.v.bases, b.v.has_qual ? b.v.quals : nullptr, b.v.read_off, packed, &par,
                                                 nthreads > 2 ? nthreads / 2 : 1, &b.post)) err = why("post-processing failed");

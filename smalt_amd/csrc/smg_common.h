@@ -20,7 +20,8 @@ enum : uint8_t { HQ_TERM = 0, HQ_NORMHIT = 1, HQ_MULTIHIT = 2, HQ_REPEAT = 3, HQ
 enum : uint32_t { HI_REVERSE = 1, HI_SORTED = 2, HI_RANK = 4 };
 enum : uint8_t { CANDFLG_REVERSE = 1, CANDFLG_MMALI = 4 };                 // segment.h:50-58
 enum : int { SMG_ERR_CAP = -5, SMG_ERR_ASSERT = -6,   // same values as SMALTGPU_ECAP / EINTERNAL
-             SMG_ERR_RETRY = -7 };   // internal: the read waits for the second K3 pass (large direction-matrix slots)
+             SMG_ERR_RETRY = -7,     // internal: the read waits for the second K3 pass (large direction-matrix slots)
+             SMG_ERR_SCORE = -8 };   // = SMALTGPU_ESCORE: a traceback whose score is not the pass's maximum (the reference's ERRCODE_SWATSCOR)
 enum : uint32_t { RCF_REVERSE = 1, RCF_SCORED = 2, RCF_BANDED = 4, RCF_ERR = 8,
                   RCF_QN = 16 /* the read holds non-ACGT codes: K2a in 32-bit lanes */,
                   RCF_BSCORED = 32 /* swscor is the banded (K2b) score */ };

@@ -88,7 +88,7 @@ struct DeviceExec {
       rv = smaltgpu_map_batch_ctx(m, bases.data(), with_quals() ? quals.data() : nullptr, off.data(), rd.n, &par, &cx, o);
     }
     // a read that failed on its own carries its code in stat[].errcode; the runner names it
-    if (rv && !((rv == SMALTGPU_ECAP || rv == SMALTGPU_EINTERNAL) && o->nreads == rd.n)) return fail_with(err, rv);
+    if (rv && !(SMALTGPU_IS_READ_ERROR(rv) && o->nreads == rd.n)) return fail_with(err, rv);
     tally(rd.kind);
     ms[rd.kind] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return true;

@@ -664,7 +664,15 @@ extern "C" int smaltgpu_report_emit(smaltgpu_report *rp, const smaltgpu_post_out
   ReadCtx cx{post, reads, op, seqnames, nseq, rp->seqlen.data()};
   for (uint32_t i = 0; i < n; i++) {
     if (post->needs_reference[i]) return smaltgpu_set_error(SMALTGPU_EARG, "a read was left to the caller by smaltgpu_postprocess (needs_reference): give it the packed reference");
-    if (raw && raw->stat[i].errcode) { char m[96]; snprintf(m, sizeof(m), "read %u carries error code %d", i, raw->stat[i].errcode); return smaltgpu_set_error(SMALTGPU_EINTERNAL, m); }
+    if (raw && raw->stat[i].errcode) {               // the reference stops at a read that fails (rmap.c:1417 -> smalt.c: the message names the read)
+      std::string m = "read '";
+      first_word(m, reads->names + reads->name_off[i], false);
+      char t[160];
+      snprintf(t, sizeof(t), "' (%u of its block) carries error code %d%s", i, raw->stat[i].errcode,
+               raw->stat[i].errcode == SMALTGPU_ESCORE ? ": inconsistency when calculating Smith-Waterman scores (the reference stops at this read with ERRCODE_SWATSCOR)" : "");
+      m += t;
+      return smaltgpu_set_error(raw->stat[i].errcode == SMALTGPU_ESCORE ? SMALTGPU_ESCORE : SMALTGPU_EINTERNAL, m.c_str());
+    }
   }
   // the random choices in read order, as one thread of the reference makes them (drand48 is the C library's shared sequence)
   rp->draw.assign(n ? n : 1, -1);

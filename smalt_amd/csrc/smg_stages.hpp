@@ -1001,7 +1001,7 @@ SMG_HD inline int traceback_scalar(uint8_t *ds, uint32_t dscap, int *qs, int *rs
   SMG_PUT(0, DIFF_M)
 #undef SMG_PUT
   *rs = i + 1; *qs = j + 1;
-  return (checksum != max_scor) ? -1 : (int)n;
+  return (checksum != max_scor) ? -3 : (int)n;      // ERRCODE_SWATSCOR (alignment.c:767): the path's score is not the pass's maximum
 }
 
 #if defined(__HIPCC__)
@@ -1275,7 +1275,7 @@ __device__ inline int traceback_uniform(uint8_t *ds, uint32_t dscap, int *qs, in
 #undef SMG_U
   if (rv) return rv;
   *rs = i + 1; *qs = j + 1;
-  return (checksum != max_scor) ? -1 : n;
+  return (checksum != max_scor) ? -3 : n;
 }
 
 // The same for wider bands.  Columns jmin + c + 64m of lane c that are inside the band at step t differ by 128
@@ -1537,7 +1537,7 @@ SMG_HD inline void stage_align(const Batch &b, const DevIndex &ix, const MapPar 
 #else
           const int dn = traceback_scalar(dtmp, dtmpcap, &qs, &rs, band, dirm, max_i, max_j, max_scor, q, win, M, gi, ge, tW);
 #endif
-          if (dn < 0) { err = (dn == -2) ? SMG_ERR_CAP : SMG_ERR_ASSERT; x.state[S_SITE] = __LINE__; }
+          if (dn < 0) { err = (dn == -2) ? SMG_ERR_CAP : (dn == -3 ? SMG_ERR_SCORE : SMG_ERR_ASSERT); x.state[S_SITE] = __LINE__; }
           const int qe = max_j, re = max_i;
           if (!err && !(qs + minscorlen > qe + 1)) {
             // addALIMETAtoRsltSet (alignment.c:1277): forward DiffStr appended to the scratch string pool

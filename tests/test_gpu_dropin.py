@@ -48,6 +48,7 @@ def _data(tmp, nchr, chrlen, nreads, rlen, seed, with_n=False):
     (11, 4, 600, 2_000, 120, ["-f", "cigar", "-d", "-1"]),                   # concatenated mode, all alignments
     (13, 6, 3000, 400, 100, ["-f", "sam", "-n", "2", "-O", "-r", "-1"]),    # a contig set: 3000 reference sequences (no limit on their number in concatenated mode)
     (13, 6, 3, 300_000, 120, ["-f", "ssaha", "-n", "2", "-O", "-r", "-1"]),  # SSAHA2 lines (fprintREPALIssaha, report.c:579)
+    (13, 6, 3, 300_000, 150, ["-f", "sam", "-S", "match=2,subst=-3,gapopen=-5,gapext=-3"]),   # the user's alignment scores (smalt.c:539-550)
 ])
 def test_smalt_map_prints_the_same(k, s, nchr, chrlen, rlen, opts, tmp_path):
     tmp = str(tmp_path)
@@ -110,6 +111,29 @@ def test_binding_goes_through_the_library_and_threads(tmp_path):
             assert x.split()[0].split(":")[1] in ("R", "S") or int(x.split()[0].split(":")[2]) <= 3, (x, y)
 
 
+@pytest.mark.skipif(not (os.path.exists(SMALT) and os.path.exists(SMALT_GPU)), reason="reference binaries not built (make -C oracle ref ref_gpu)")
+def test_a_read_the_reference_fails_on_fails_here_too(tmp_path):
+    """Error behaviour: with a gap extension much cheaper than the opening (-S ...,gapopen=-5,gapext=-2) the score
+    pass (textbook recurrence, swsimd.c) and the banded traceback pass (restricted recurrence, alignment.c:1029) can disagree
+    on a candidate; the reference stops with ERRCODE_SWATSCOR at that read (rmap.c:1417).  Both programs on the library must
+    stop at the same read instead of printing something -- the bound program with the reference's own message."""
+    tmp = str(tmp_path)
+    fa, fq = _data(tmp, 3, 300_000, 1200, 150, seed=1309, with_n=True)
+    pre = os.path.join(tmp, "idx")
+    subprocess.run([SMALT, "index", "-k", "13", "-s", "6", pre, fa], check=True, capture_output=True)
+    opts = ["-f", "sam", "-S", "match=2,subst=-3,gapopen=-5,gapext=-2", "-r", "3"]
+    r = subprocess.run([SMALT, "map"] + opts + ["-o", os.path.join(tmp, "ref.out"), pre, fq], capture_output=True, text=True)
+    assert r.returncode != 0 and "Inconsistency when calculating Smith-Waterman scores" in r.stdout + r.stderr
+    where = [ln for ln in (r.stdout + r.stderr).split("\n") if "when processing read No." in ln][0].strip()
+    env = dict(os.environ, SMALTGPU_INDEX_PREFIX=pre)
+    g = subprocess.run([SMALT_GPU, "map"] + opts + ["-o", os.path.join(tmp, "gpu.out"), pre, fq], capture_output=True, text=True, env=env)
+    assert g.returncode != 0, "the bound program went on where the reference stops"
+    assert "Inconsistency when calculating Smith-Waterman scores" in g.stdout + g.stderr and where in g.stdout + g.stderr, (where, (g.stdout + g.stderr)[-1500:])
+    n = subprocess.run([os.path.join(ROOT, "smalt_amd", "smaltgpu-map")] + opts + ["-o", os.path.join(tmp, "nat.out"), pre, fq], capture_output=True, text=True)
+    name = where.split("'")[1]
+    assert n.returncode != 0 and name in n.stderr, (name, n.stderr[-1500:])
+
+
 def _pair_data(tmp, nchr, chrlen, npairs, rlen, seed, rep=0.3, ins=(300, 30)):
     from smalt_amd import synth
     ch = synth.make_reference(nchr, chrlen, seed=seed, repeat_frac=rep, n_fam=2, cons_len=400, divergence=0.03)
@@ -150,6 +174,7 @@ def _pair_data(tmp, nchr, chrlen, npairs, rlen, seed, rep=0.3, ins=(300, 30)):
     (13, 6, 3, 300_000, 150, (300, 30), ["-f", "sam", "-i", "500", "-x", "-c", "45"]),          # cover threshold in bases (the reference accepts -c with -x only)
     (13, 6, 600, 2_000, 100, (300, 30), ["-f", "cigar", "-i", "500", "-x", "-c", "0.5"]),       # cover threshold in concatenated mode: plain rounds take the sequential candidate stage
     (13, 6, 3, 300_000, 100, (300, 30), ["-f", "ssaha", "-i", "500"]),                          # SSAHA2 lines with the pair classes
+    (13, 6, 3, 300_000, 100, (300, 30), ["-f", "cigar", "-i", "500", "-S", "subst=-3,gapopen=-6"]),   # the user's alignment scores in all rounds
 ])
 def test_smalt_map_pairs_prints_the_same(k, s, nchr, chrlen, rlen, ins, opts, tmp_path):
     """Paired reads: rmapPair's rounds (rare mate, restricted mate, unrestricted re-map, re-map over the on-the-fly k=5 index)
