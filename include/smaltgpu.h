@@ -191,6 +191,10 @@ typedef struct smaltgpu_callctx {
                                   * where the allocation-boundary protocol sets in (hashhit.c:1497), so a serial `smalt map` over reads
                                   * of different lengths depends on their order; NULL = every read as if it were the first
                                   * (smaltgpu_mapper_set_history keeps this array for the caller) */
+  const uint32_t *seed_range;    /* per read (first, last) base, 0-based and inclusive, or NULL: k-mer words are taken from that stretch of
+                                  * the read only -- the second call of a split read (mapSecondary, rmap.c:1435-1505 -> collectHitInfo with
+                                  * a range, hashhit.c:536-551); a stretch shorter than a word means the whole read, as there.  The
+                                  * alignment passes still see the whole read */
 } smaltgpu_callctx;
 int smaltgpu_map_batch_ctx(smaltgpu_mapper *m, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
                            const smaltgpu_params *par, const smaltgpu_callctx *ctx, smaltgpu_batch_out *out);
@@ -349,6 +353,15 @@ void smaltgpu_reads_free(smaltgpu_reads *rs);
 int smaltgpu_reads_parse(smaltgpu_reads *rs, const char *text, uint64_t len, int is_last, uint32_t max_reads, int nthreads,
                          smaltgpu_reads_view *view);
 
+/* ---- split reads (smalt map -p): rmapSingle with RMAPFLG_SPLIT (rmap.c:1716-1728 -> mapSecondary, rmap.c:1435-1505) for a batch ----
+ * Every read is mapped; where the best alignment of the read's first segment leaves a stretch of at least a word and a step
+ * uncovered, the read is mapped once more with k-mer words from that stretch only (smaltgpu_callctx.seed_range), into the same
+ * alignment set, and the set is put in order again.  The result has the layout of smaltgpu_postprocess (which this call replaces
+ * for split reads) and goes to smaltgpu_report_emit with SMALTGPU_OUT_SPLIT.  par->rmapflg as smalt.c:508 sets it for -p:
+ * NOSHRTINFO | SENSITIVE on top of the usual flags.  n_second_calls (may be NULL): how many reads got the second call. */
+int smaltgpu_map_split(smaltgpu_mapper *m, smaltgpu_post *post, const uint8_t *bases, const uint8_t *quals, const uint64_t *read_off, uint32_t nreads,
+                       const smaltgpu_params *par, const smaltgpu_index *ix, int nthreads, smaltgpu_post_out *out, uint32_t *n_second_calls);
+
 /* Report: which alignments of a read are printed (resultSetFilterResults, results.c:2592; resultSetAddToReport, results.c:2282;
  * reportAddMap's duplicate test, report.c:545) and the lines themselves (fprintREPALIcigar report.c:711, fprintREPALIsam
  * report.c:762, writeDiffStrCIGAR diffstr.c:298, SAM header report.c:1266). */
@@ -357,7 +370,8 @@ enum { SMALTGPU_FMT_CIGAR = 0, SMALTGPU_FMT_SAM = 1, SMALTGPU_FMT_SSAHA = 2 };  
                                                                                           * fault on its first read (report.c:1389-1401 drops the block list
                                                                                           * it has just made), -f bam needs a library this build has not */
 enum { SMALTGPU_REP_SOFTCLIP = 0x02, SMALTGPU_REP_HEADER = 0x04, SMALTGPU_REP_XMISMATCH = 0x08 };   /* REPORTMODIF_* (report.h:54-59) */
-enum { SMALTGPU_OUT_BEST = 0x01, SMALTGPU_OUT_SINGLE = 0x02, SMALTGPU_OUT_RANDSEL = 0x08 };         /* RESULTFLG_* (results.h:55-63) */
+enum { SMALTGPU_OUT_BEST = 0x01, SMALTGPU_OUT_SINGLE = 0x02, SMALTGPU_OUT_SPLIT = 0x04, SMALTGPU_OUT_RANDSEL = 0x08 };   /* RESULTFLG_* (results.h:55-63); SPLIT: the best
+                                                                                          * alignments of the other read segments follow as partial ones (results.c:2250-2278, :2337) */
 typedef struct smaltgpu_report_opts {
   int32_t format;
   uint32_t modflags, outflags;

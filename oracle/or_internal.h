@@ -52,6 +52,7 @@ struct OrMap {
   OrParams par;
   /* interval restriction of the current call (rmapPair); niv < 0: none */
   int prevmax[2];            /* running score maxima of the ResultSet the next call appends to (0, 0: a blank set) */
+  uint32_t seed_range[2];    /* the next call takes its k-mer words from bases [first, last] only (0, 0: the whole read) */
   int niv, niv_next; const int64_t *iv_sx; const uint32_t *iv_lo, *iv_hi;
 };
 

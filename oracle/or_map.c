@@ -307,6 +307,7 @@ int or_map_single_restricted(OrMap *m, const char *bases, const char *quals, uin
 }
 
 void or_map_set_prevmax(OrMap *m, int swmax, int sw2nd) { m->prevmax[0] = swmax; m->prevmax[1] = sw2nd; }
+void or_map_set_seed_range(OrMap *m, uint32_t first, uint32_t last) { m->seed_range[0] = first; m->seed_range[1] = last; }
 
 /* calcTotalNumberOfHits, rmap.c:1076-1081 -> hashCalcHitInfoNumberOfHits, hashhit.c:1171-1197 */
 uint32_t or_map_hit_total(const OrMap *m, int ktuple_maxhit)
@@ -320,7 +321,8 @@ uint32_t or_map_hit_total(const OrMap *m, int ktuple_maxhit)
   return tot;
 }
 
-/* rmapSingle, rmap.c:1648-1742 (RMAPFLG_SPLIT / secondary mapping not restated) */
+/* rmapSingle, rmap.c:1648-1742; the second call of a split read (mapSecondary, rmap.c:1435-1505) is this function again with
+ * or_map_set_seed_range + or_map_set_prevmax and OR_FLG_RAWRESULTS (the caller holds the set it appends to) */
 int or_map_single(OrMap *m, const char *bases, const char *quals, uint32_t len, const OrParams *p)
 {
   const OrIndex *ix = m->ix;
@@ -332,6 +334,8 @@ int or_map_single(OrMap *m, const char *bases, const char *quals, uint32_t len, 
    * threshold to the set's second-best score (rmap.c:881-885), whatever call it came from */
   m->nres = 0; m->ndiff = 0; m->swmax = m->prevmax[0]; m->sw2nd = m->prevmax[1]; m->ncand = 0;
   m->prevmax[0] = m->prevmax[1] = 0;
+  const uint32_t q0 = m->seed_range[0], q1 = m->seed_range[1];
+  m->seed_range[0] = m->seed_range[1] = 0;
   m->nseg = m->nseg_tot = m->nhit = m->nhit_tot = m->max1 = m->max2 = 0;
   m->th_bandwidth_min = m->th_min_swatscor = m->th_scorlen_min = 0;
   m->sc.ncand = 0; m->sc.n_sort = 0;
@@ -350,9 +354,9 @@ int or_map_single(OrMap *m, const char *bases, const char *quals, uint32_t len, 
   m->err = OR_OK;
   if (len < (uint32_t) ix->k) { m->hi[0].n_seeds = m->hi[1].n_seeds = 0; return OR_OK; }   /* ERRCODE_SHORTSEQ swallowed */
 
-  if (p->flags & OR_FLG_NOSHRTINFO) {
-    rv = or_collect_hitinfo(&m->hi[0], ix, 0, 0, p->min_basq, 0, 0, m->read[0], quals? m->qual: NULL, len);
-    if (!rv) rv = or_collect_hitinfo(&m->hi[1], ix, 1, 0, p->min_basq, 0, 0, m->read[0], quals? m->qual: NULL, len);
+  if (p->flags & OR_FLG_NOSHRTINFO) {          /* initRMAPINFO, rmap.c:1027-1044 (with a stretch of the read: mapSecondary, rmap.c:1483) */
+    rv = or_collect_hitinfo(&m->hi[0], ix, 0, 0, p->min_basq, q0, q1, m->read[0], quals? m->qual: NULL, len);
+    if (!rv) rv = or_collect_hitinfo(&m->hi[1], ix, 1, 0, p->min_basq, q0, q1, m->read[0], quals? m->qual: NULL, len);
   } else {
     rv = or_collect_hitinfo_short(&m->hi[0], ix, 0, (uint32_t) ((p->ncut > 0)? p->ncut: 0), HASH_MAXNHITS, p->min_basq, m->read[0], quals? m->qual: NULL, len);
     if (!rv) rv = or_collect_hitinfo_short(&m->hi[1], ix, 1, (uint32_t) ((p->ncut > 0)? p->ncut: 0), HASH_MAXNHITS, p->min_basq, m->read[0], quals? m->qual: NULL, len);

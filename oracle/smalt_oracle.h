@@ -133,6 +133,10 @@ int or_map_single_restricted(OrMap *m, const char *bases, const char *quals, uin
  * traceback pass raises its threshold to the set's second-best score (rmap.c:881-885).  or_map_stats then returns the
  * maxima after the call. */
 void or_map_set_prevmax(OrMap *m, int swmax, int sw2nd);
+/* The next call (with OR_FLG_NOSHRTINFO) takes its k-mer words from bases [first, last] of the read only (0-based, inclusive):
+ * hashCollectHitInfo with a range (hashhit.c:987, :536-551), as mapSecondary (rmap.c:1435-1505) calls it for the part of a
+ * split read that its best alignment leaves uncovered. */
+void or_map_set_seed_range(OrMap *m, uint32_t first, uint32_t last);
 /* calcTotalNumberOfHits (rmap.c:1076) of the last read: what rmapPair compares to pick the mate it maps first */
 uint32_t or_map_hit_total(const OrMap *m, int ktuple_maxhit);
 /* print the stage state of the last read in the refdump line format */

@@ -56,7 +56,7 @@ class Interval(C.Structure):
 
 class CallCtx(C.Structure):
     _fields_ = [("iv_off", C.POINTER(C.c_uint64)), ("iv", C.POINTER(Interval)), ("min_swatscor", C.POINTER(C.c_int32)),
-                ("prev_max", C.POINTER(C.c_int32)), ("fine_index", C.c_int32), ("raw_alignments", C.c_int32), ("hitlist_len", C.POINTER(C.c_uint32))]
+                ("prev_max", C.POINTER(C.c_int32)), ("fine_index", C.c_int32), ("raw_alignments", C.c_int32), ("hitlist_len", C.POINTER(C.c_uint32)), ("seed_range", C.POINTER(C.c_uint32))]
 
 
 class PostResult(C.Structure):
@@ -315,10 +315,11 @@ class Mapper:
         return self._unpack(out)
 
     def map_batch_ctx(self, reads: Sequence[bytes], quals: Optional[Sequence[bytes]], params: Params, intervals=None, min_swatscor=None,
-                      prev_max=None, fine_index: bool = False, raw_alignments: bool = False):
+                      prev_max=None, fine_index: bool = False, raw_alignments: bool = False, seed_range=None):
         """One round of rmapPair over a batch (smaltgpu_map_batch_ctx): intervals = per read a list of (sidx, lo, hi) or None
         for no restriction at all; min_swatscor = per-read thresholds; prev_max = per read (max, 2ndmax) of the ResultSet
-        the call appends to; fine_index = seed against the on-the-fly k=5 index of the intervals.
+        the call appends to; fine_index = seed against the on-the-fly k=5 index of the intervals; seed_range = per read the
+        (first, last) base its k-mer words come from (the second call of a split read).
         -> (results, stats, cand_first flags per result)"""
         bases, q, off = self._pack(reads, quals)
         n = len(reads)
@@ -343,6 +344,10 @@ class Mapper:
             pm = (C.c_int32 * max(1, 2 * n))(*[x for pr_ in prev_max for x in pr_])
             ctx.prev_max = pm
             keep.append(pm)
+        if seed_range is not None:
+            sr = (C.c_uint32 * max(1, 2 * n))(*[x for pr_ in seed_range for x in pr_])
+            ctx.seed_range = sr
+            keep.append(sr)
         ctx.fine_index = 1 if fine_index else 0
         ctx.raw_alignments = 1 if raw_alignments else 0
         out = BatchOut()

@@ -367,7 +367,7 @@ struct smaltgpu_mapper {
     int ensure(size_t n) { if (n <= cap) return 0; if (p) (void)hipFree(p); p = nullptr; cap = 0; size_t c = n + n / 2 + 256; if (hipMalloc(&p, c) != hipSuccess) return -1; cap = c; return 0; }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
   };
-  DevBuf cx_ivoff, cx_iv, cx_minsw, cx_prevmax, cx_fineidx, cx_finepos, cx_fineoff, cx_alloclen;
+  DevBuf cx_ivoff, cx_iv, cx_minsw, cx_prevmax, cx_fineidx, cx_finepos, cx_fineoff, cx_alloclen, cx_seedrange;
   int host_threads = 1;                      // smaltgpu_mapper_set_host_threads
   bool history = false;                      // serial-order mode (smaltgpu_mapper_set_history)
   uint32_t hist_longest = 0;                 // longest read of length >= k of the run so far
@@ -612,7 +612,7 @@ extern "C" void smaltgpu_mapper_free(smaltgpu_mapper *m) {
                 m->sw_rows, m->align_scr, m->align_scr2};
   for (void *p : ps) if (p) (void)hipFree(p);
   m->h_stat.release(); m->h_res.release(); m->h_dstr.release();
-  m->cx_ivoff.release(); m->cx_iv.release(); m->cx_minsw.release(); m->cx_prevmax.release(); m->cx_fineidx.release(); m->cx_finepos.release(); m->cx_fineoff.release(); m->cx_alloclen.release();
+  m->cx_ivoff.release(); m->cx_iv.release(); m->cx_minsw.release(); m->cx_prevmax.release(); m->cx_fineidx.release(); m->cx_finepos.release(); m->cx_fineoff.release(); m->cx_alloclen.release(); m->cx_seedrange.release();
   if (m->ev_fetch) (void)hipEventDestroy(m->ev_fetch);
   for (int i = 0; i <= T_NUM; i++) if (m->ev[i]) (void)hipEventDestroy(m->ev[i]);
   if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -645,7 +645,7 @@ static int check_par(const smaltgpu_mapper *m, const smaltgpu_params *p) {
 
 // the device pipeline over reads already in HBM
 // cx: the per-read context of one of rmapPair's rounds, already on the device (upload_ctx), or null
-struct CtxDev { const uint32_t *iv_off; const IvRec *iv; const int32_t *min_sw, *prevmax; uint32_t *fine_idx, *fine_pos; const uint32_t *fine_off, *alloc_len; uint32_t raw; };
+struct CtxDev { const uint32_t *iv_off; const IvRec *iv; const int32_t *min_sw, *prevmax; uint32_t *fine_idx, *fine_pos; const uint32_t *fine_off, *alloc_len, *seed_range; uint32_t raw; };
 
 static int run_pipeline(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_off, uint32_t n,
                         const smaltgpu_params *par, const CtxDev *cx = nullptr, bool seed_only = false) {
@@ -655,6 +655,7 @@ static int run_pipeline(smaltgpu_mapper *m, const uint8_t *d_bases, const uint8_
   b.iv_off = cx ? cx->iv_off : nullptr; b.iv = cx ? cx->iv : nullptr; b.min_sw = cx ? cx->min_sw : nullptr; b.prevmax = cx ? cx->prevmax : nullptr;
   b.fine_idx = cx ? cx->fine_idx : nullptr; b.fine_pos = cx ? cx->fine_pos : nullptr; b.fine_off = cx ? cx->fine_off : nullptr;
   b.alloc_len = cx ? cx->alloc_len : nullptr;
+  b.seed_range = cx ? cx->seed_range : nullptr;
   b.totals_only = seed_only ? 1u : 0u;
   b.raw_results = cx ? cx->raw : 0u;
   if (b.fine_idx) p.flags |= FLG_NOSHRTINFO;            // initRMAPINFO, not the short form (rmap.c:2024)
@@ -882,6 +883,11 @@ static int upload_ctx(smaltgpu_mapper *m, const smaltgpu_callctx *ctx, uint32_t 
     if (n) HIPCHK(hipMemcpyAsync(m->cx_alloclen.p, ctx->hitlist_len, (size_t)n * 4, hipMemcpyHostToDevice, s));
     cd->alloc_len = (const uint32_t *)m->cx_alloclen.p;
   }
+  if (ctx->seed_range) {
+    if (m->cx_seedrange.ensure((size_t)(n ? n : 1) * 8)) return fail(SMALTGPU_ENOMEM, "device memory");
+    if (n) HIPCHK(hipMemcpyAsync(m->cx_seedrange.p, ctx->seed_range, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    cd->seed_range = (const uint32_t *)m->cx_seedrange.p;
+  }
   return SMALTGPU_OK;
 }
 
@@ -927,7 +933,7 @@ static int remap_overflowed(smaltgpu_mapper *m, const uint8_t *bases, const uint
   std::vector<uint64_t> so, civo;
   std::vector<smaltgpu_interval> civ;
   std::vector<int32_t> cms, cpm;
-  std::vector<uint32_t> chl;
+  std::vector<uint32_t> chl, csr;
   uint32_t npermanent = 0, nbatches = 0;
   while (!todo.empty()) {
     std::vector<uint32_t> L;
@@ -944,18 +950,20 @@ static int remap_overflowed(smaltgpu_mapper *m, const uint8_t *bases, const uint
     smaltgpu_callctx sub;
     if (ctx) {                                          // the same reads' slice of the round's context
       sub = *ctx;
-      civo.assign(1, 0); civ.clear(); cms.clear(); cpm.clear(); chl.clear();
+      civo.assign(1, 0); civ.clear(); cms.clear(); cpm.clear(); chl.clear(); csr.clear();
       for (uint32_t i : L) {
         if (ctx->iv_off) { civ.insert(civ.end(), ctx->iv + ctx->iv_off[i], ctx->iv + ctx->iv_off[i + 1]); civo.push_back(civ.size()); }
         if (ctx->min_swatscor) cms.push_back(ctx->min_swatscor[i]);
         if (ctx->prev_max) { cpm.push_back(ctx->prev_max[2 * (size_t)i]); cpm.push_back(ctx->prev_max[2 * (size_t)i + 1]); }
         if (ctx->hitlist_len) chl.push_back(ctx->hitlist_len[i]);
+        if (ctx->seed_range) { csr.push_back(ctx->seed_range[2 * (size_t)i]); csr.push_back(ctx->seed_range[2 * (size_t)i + 1]); }
       }
       if (civ.empty()) civ.resize(1);
       if (ctx->iv_off) { sub.iv_off = civo.data(); sub.iv = civ.data(); }
       if (ctx->min_swatscor) sub.min_swatscor = cms.data();
       if (ctx->prev_max) sub.prev_max = cpm.data();
       if (ctx->hitlist_len) sub.hitlist_len = chl.data();
+      if (ctx->seed_range) sub.seed_range = csr.data();
     }
     smaltgpu_batch_out o;
     const int rv = map_range(m, sb.data(), quals ? sq.data() : nullptr, so.data(), (uint32_t)L.size(), par, &o, ctx ? &sub : nullptr);

@@ -50,6 +50,7 @@ void usage() {
           "  -y <num>   minimum identity (fraction of the read if <= 1, else bases)\n"
           "  -c <num>   minimum k-mer cover (fraction of the read if <= 1, else bases)\n"
           "  -x         more sensitive search (all seeds, deeper candidate lists)\n"
+          "  -p         split reads (single reads): a second alignment for the part of a read its best alignment leaves uncovered\n"
           "  -q <int>   base quality threshold for k-mer words\n"
           "  -S <spec>  alignment scores, e.g. match=1,subst=-2,gapopen=-4,gapext=-3 (the default; any subset)\n"
           "  -n <int>   host threads for parsing, post-processing and formatting (default: up to 16)\n"
@@ -59,7 +60,7 @@ void usage() {
           "  -i <int>   maximum insert size of read pairs (default 500); -j <int> minimum insert size (default 0)\n"
           "  -l <lib>   pair library: pe (default) | mp | pp\n"
           "with two read files the reads are mapped as pairs (read i of the first with read i of the second file);\n"
-          "split reads (-p), -w, -a and insert-size histograms (-g) go through the bound reference program (INTEGRATION.md)\n");
+          "-w, -a, insert-size histograms (-g) and split reads of PAIRS go through the bound reference program (INTEGRATION.md)\n");
   exit(2);
 }
 
@@ -135,15 +136,16 @@ int main(int argc, char **argv) {
   const char *fmt = "cigar", *oufil = nullptr, *scorespec = nullptr;
   int m = -1, d = 0, seed = 0, q = 0, nthreads = 0, ins_max = 500, ins_min = 0, lib = SMALTGPU_LIB_PE;
   std::vector<int> devices;
-  bool d_given = false, randrepeat = true, exhaustive = false;
+  bool d_given = false, randrepeat = true, exhaustive = false, split = false;
   double minid = 0.0, mincover = 0.0;
   long batch = 262144;
   int a = 1;
   for (; a < argc && argv[a][0] == '-' && argv[a][1]; a++) {
     const char o = argv[a][1];
     if (o == 'x' && !argv[a][2]) { exhaustive = true; continue; }
+    if (o == 'p' && !argv[a][2]) { split = true; continue; }
     if (argv[a][2] || !strchr("fomdrycqnBgijlS", o)) {
-      if (strchr("pwTFa", o) && !argv[a][2]) die("option not supported by this program (use the bound `smalt map`, INTEGRATION.md)", argv[a]);
+      if (strchr("wTFa", o) && !argv[a][2]) die("option not supported by this program (use the bound `smalt map`, INTEGRATION.md)", argv[a]);
       usage();
     }
     if (a + 1 >= argc) usage();
@@ -170,6 +172,7 @@ int main(int argc, char **argv) {
   const char *prefix = argv[a], *readfil = argv[a + 1], *matefil = argc - a == 3 ? argv[a + 2] : nullptr;
   const bool paired = matefil != nullptr;
   if (paired && ins_min > ins_max) die("-j above -i");
+  if (paired && split) die("split reads of pairs (-p with two read files) are not supported by this program (use the bound `smalt map`, INTEGRATION.md)");
   if (nthreads < 1) { nthreads = (int)std::thread::hardware_concurrency(); if (nthreads > 16) nthreads = 16; if (nthreads < 1) nthreads = 1; }
 
   smaltgpu_report_opts ro;
@@ -252,6 +255,7 @@ int main(int argc, char **argv) {
   par.min_swatscor_below_max = d;
   if (d) par.rmapflg &= ~(uint32_t)SMALTGPU_FLG_BEST;
   if (exhaustive) par.rmapflg |= SMALTGPU_FLG_NOSHRTINFO | SMALTGPU_FLG_SENSITIVE;      // smalt.c:531-533
+  if (split) { par.rmapflg |= SMALTGPU_FLG_NOSHRTINFO | SMALTGPU_FLG_SENSITIVE; ro.outflags |= SMALTGPU_OUT_SPLIT; }      // smalt.c:507-511 (RMAPFLG_SPLIT: smaltgpu_map_split)
   par.min_basqval = (uint8_t)q;
   if (mincover < 1.01) { par.min_cover = 0; par.min_cover_frac = mincover; } else { par.min_cover = (uint32_t)mincover; par.min_cover_frac = 0.0; }   // smalt.c:1113-1126
   smaltgpu_pair_opts po;
@@ -374,6 +378,11 @@ int main(int argc, char **argv) {
         if (smaltgpu_map_pairs(W.mp, b.v.bases, q2 ? b.v.quals : nullptr, b.v.read_off, b.v2.bases, q2 ? b.v2.quals : nullptr, b.v2.read_off, b.v.nreads, &par, &po, b.pairs))
           err = why("mapping the pairs failed");
         t1 = now(); t_map[w] += t1 - t0; t0 = t1;
+      } else if (err.empty() && split) {
+        // both calls of every read and the post-call passes between and behind them
+        if (smaltgpu_map_split(W.mp, W.post, b.v.bases, b.v.has_qual ? b.v.quals : nullptr, b.v.read_off, b.v.nreads, &par, ixs[(size_t)(w % ndev)],
+                               nthreads > 2 ? nthreads / 2 : 1, &b.post, nullptr)) err = why("mapping the split reads failed");
+        t1 = now(); t_map[w] += t1 - t0; t0 = t1;
       } else if (err.empty()) {
         smaltgpu_callctx cx;
         memset(&cx, 0, sizeof(cx));
@@ -406,7 +415,7 @@ int main(int argc, char **argv) {
     const char *txt; uint64_t tl;
     t1 = now(); t_wait += t1 - t0; t0 = t1;
     if (paired ? smaltgpu_report_emit_pairs(rep, b.pairs, &b.v, &b.v2, seqnames, nseq, &ro, &po, nthreads, &txt, &tl)
-               : smaltgpu_report_emit(rep, &b.post, &b.raw, &b.v, seqnames, nseq, &ro, nthreads, &txt, &tl)) failure = why("formatting the report failed");
+               : smaltgpu_report_emit(rep, &b.post, split ? nullptr : &b.raw, &b.v, seqnames, nseq, &ro, nthreads, &txt, &tl)) failure = why("formatting the report failed");
     t1 = now(); t_emit += t1 - t0; t0 = t1;
     if (failure.empty() && tl && fwrite(txt, 1, tl, ou) != tl) failure = "write error";
     t_write += now() - t0;

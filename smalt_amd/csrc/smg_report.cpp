@@ -386,6 +386,7 @@ struct ReadCtx {
 bool select_read(const ReadCtx &cx, uint32_t i, int draw, std::vector<Ali> &out, std::vector<uint32_t> &st) {
   const smaltgpu_post_out &po = *cx.po;
   const smaltgpu_report_opts &op = *cx.op;
+  const bool split = (op.outflags & SMALTGPU_OUT_SPLIT) != 0;
   const smaltgpu_post_result *res = po.res + po.res_off[i];
   const int32_t *sortr = po.sortr + po.sort_off[i];
   const int n = (int)(po.sort_off[i + 1] - po.sort_off[i]);
@@ -432,7 +433,7 @@ bool select_read(const ReadCtx &cx, uint32_t i, int draw, std::vector<Ali> &out,
     const bool is_single = n < 2 || res[sortr[1]].swatscor != res[sortr[0]].swatscor;
     int ns = n;
     if (n > 2) { const int thr = res[sortr[1]].swatscor; int k = 2; while (k < n && res[sortr[k]].swatscor == thr) k++; ns = k; }
-    if (res[top].mapscor == 0 && !is_single && ns > 1 && (op.outflags & SMALTGPU_OUT_BEST)) {
+    if (res[top].mapscor == 0 && !is_single && ns > 1 && (op.outflags & SMALTGPU_OUT_BEST) && !split) {
       mateflg |= MF_MULTI;
       if (op.outflags & SMALTGPU_OUT_RANDSEL) {
         if (draw < 0 || draw >= n) return false;
@@ -443,11 +444,30 @@ bool select_read(const ReadCtx &cx, uint32_t i, int draw, std::vector<Ali> &out,
   }
   add(top, top_mapscor, mateflg | MF_PRIMARY);
   if (top >= 0) st[(size_t)top] |= RF_REPORTED;
-  if (op.outflags & SMALTGPU_OUT_SINGLE) return true;
+  if ((op.outflags & SMALTGPU_OUT_SINGLE) && !split) return true;
   for (int k = 1; k < n; k++) {
     const int r = sortr[k];
     if ((op.outflags & SMALTGPU_OUT_BEST) && res[r].swatscor < res[sortr[k - 1]].swatscor) break;
     if (!(st[(size_t)r] & (RF_NOOUTPUT | RF_BELOWRELSW))) { add(r, (r == top) ? top_mapscor : -1, mateflg); st[(size_t)r] |= RF_REPORTED; }
+  }
+  // split reads: the best alignments of every read segment that are not out yet follow as partial alignments
+  // (resultSetAdd2ndaryResultsToReport, results.c:2250-2278)
+  if ((op.outflags & SMALTGPU_OUT_BEST) && split) {
+    const int nseg = po.qsegno[i];
+    const int32_t *by_segment = po.segsrtr + po.sort_off[i], *segment_begin = po.segnor + po.seg_off[i];
+    if (nseg > 0 && (int64_t)(po.seg_off[i + 1] - po.seg_off[i]) != (int64_t)nseg + 1) return false;
+    for (int g = 0; g < nseg; g++) {
+      int last = 0;
+      for (int k = segment_begin[g]; k < segment_begin[g + 1]; k++) {
+        const int r = by_segment[k];
+        if (r < 0 || (uint32_t)r >= nres) return false;
+        if (st[(size_t)r] & RF_NOOUTPUT) continue;
+        if ((st[(size_t)r] & RF_REPORTED) || res[r].swatscor < last) break;            // (best-only is on in this branch)
+        add(r, -1, mateflg | MF_PARTIAL);
+        st[(size_t)r] |= RF_REPORTED;
+        last = res[r].swatscor;
+      }
+    }
   }
   return true;
 }
@@ -456,7 +476,7 @@ bool select_read(const ReadCtx &cx, uint32_t i, int draw, std::vector<Ali> &out,
 int draw_range(const ReadCtx &cx, uint32_t i) {
   const smaltgpu_post_out &po = *cx.po;
   const smaltgpu_report_opts &op = *cx.op;
-  if (!(op.outflags & SMALTGPU_OUT_RANDSEL) || !(op.outflags & SMALTGPU_OUT_BEST)) return 0;
+  if (!(op.outflags & SMALTGPU_OUT_RANDSEL) || !(op.outflags & SMALTGPU_OUT_BEST) || (op.outflags & SMALTGPU_OUT_SPLIT)) return 0;
   const smaltgpu_post_result *res = po.res + po.res_off[i];
   const int32_t *sortr = po.sortr + po.sort_off[i];
   const int n = (int)(po.sort_off[i + 1] - po.sort_off[i]);

@@ -57,6 +57,7 @@ struct Batch {                          // one block of reads resident in HBM
   const uint32_t *fine_off;             // [nreads + 1] first position of read r in fine_pos
   uint32_t totals_only;                 // != 0: the batch stops behind the k-mer lookups (smaltgpu_hit_totals): stage_seed leaves the ranking out
   uint32_t raw_results;                 // != 0: every alignment of a call is returned (no duplicate handling: the caller holds the set the call appends to)
+  const uint32_t *seed_range;           // [2 * nreads] or null: k-mer words are taken from bases [first, last] of the read only (mapSecondary, rmap.c:1435-1505)
   const uint32_t *alloc_len;            // [nreads] or null: length of the longest read the reference's one hit list has held up to read r (serial-order mode)
   // ---- S3 split off the candidate stage (k_hits): null when the mapper keeps S3 inside k_cands ----
   HitRun *hitrun;                       // [2 * nreads]
@@ -201,6 +202,15 @@ SMG_HD inline uint32_t stage_seed(const Batch &b, const DevIndex &ix, const MapP
   }
   const uint32_t nk = qlen - (uint32_t)k + 1;
   const uint64_t wordmask = (1ull << (2 * k)) - 1;
+  // words start at offsets [t_lo, t_hi): the whole read, or the stretch a split-read call names (collectHitInfo, hashhit.c:536-551:
+  // offsets in front of it count as without hits, the word window and the repeat filter start afresh at its first base)
+  uint32_t t_lo = 0, t_hi = nk;
+  if (b.seed_range) {
+    const uint32_t q0 = b.seed_range[2 * r];
+    uint32_t q1 = b.seed_range[2 * r + 1];
+    if (q1 >= qlen) q1 = qlen - 1;
+    if (q0 <= q1 && q1 - q0 + 1 >= (uint32_t)k) { t_lo = q0; t_hi = q1 - (uint32_t)k + 2; }
+  }
 
   // (1) words + validity of every k-mer start t; ordered compaction of the valid ones.  The bases are staged once -- one byte per
   // base in the stage's scratch: the code, plus 4 if the base cannot be part of a word (non-ACGT, low quality) -- so that a lane
@@ -211,11 +221,12 @@ SMG_HD inline uint32_t stage_seed(const Batch &b, const DevIndex &ix, const MapP
   }
   SMG_SYNC();
   uint32_t nvalid = 0;
-  SMG_PAR_CHUNKS(base, nk) {
+  SMG_PAR_CHUNKS(base, t_hi) {
     uint32_t t = base + SMG_LANE;
     bool valid = false;
     uint64_t w = 0;
-    if (t < nk) {
+    if (t < t_lo) qmask[t] = HQ_NOHIT;
+    else if (t < t_hi) {
       valid = true;
       for (int i = 0; i < k; i++) {
         const uint32_t c = x.qbuf[t + (uint32_t)i];
@@ -230,8 +241,8 @@ SMG_HD inline uint32_t stage_seed(const Batch &b, const DevIndex &ix, const MapP
     uint32_t slot = compact_slot(valid, nvalid);
     if (valid) { x.vt[slot] = t; x.vw[slot] = w; }
   }
-  SMG_PAR_CHUNKS(base, qlen - nk + 1) {           // tail offsets + terminator (hashhit.c:652-653)
-    uint32_t t = nk + base + SMG_LANE;
+  SMG_PAR_CHUNKS(base, qlen - t_hi + 1) {         // tail offsets + terminator (hashhit.c:652-653)
+    uint32_t t = t_hi + base + SMG_LANE;
     if (t <= qlen && t < b.qmax) qmask[t] = HQ_TERM;
   }
   SMG_SYNC();

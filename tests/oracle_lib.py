@@ -66,6 +66,7 @@ def lib():
         L.or_map_single_restricted.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint32, C.POINTER(OrParams), C.c_int,
                                                C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.or_map_set_prevmax.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.or_map_set_seed_range.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.or_map_hit_total.restype = C.c_uint32
         L.or_map_hit_total.argtypes = [C.c_void_p, C.c_int]
         L.or_map_dump_str.restype = C.c_long
@@ -131,12 +132,14 @@ class Mapper:
             lib().or_map_free(self.m)
             self.m = None
 
-    def map(self, bases: bytes, quals, params, intervals=None, prevmax=None):
+    def map(self, bases: bytes, quals, params, intervals=None, prevmax=None, seed_range=None):
         """Returns list of dicts (raw result array of the read, reference order).  intervals: list of (sx, lo, hi) =
         one mapSingleRead call of rmapPair with seeding restricted to these windows (rmap.c:438-492); prevmax: running
         score maxima of the ResultSet the call appends to."""
         if prevmax is not None:
             lib().or_map_set_prevmax(self.m, prevmax[0], prevmax[1])
+        if seed_range is not None:              # (first, last) base the k-mer words come from: the second call of a split read
+            lib().or_map_set_seed_range(self.m, seed_range[0], seed_range[1])
         if intervals is None:
             rv = lib().or_map_single(self.m, bases, quals, len(bases), C.byref(params))
         else:
