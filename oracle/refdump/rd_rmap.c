@@ -152,8 +152,10 @@ int main(int argc, char *argv[])
   SeqIO *mfp = NULL;
   SeqFastq *matep = NULL;
 
-  while ((c = getopt(argc, argv, "m:d:c:q:H:S:xnpP:i:j:l:")) != -1) {
+  int split = 0;
+  while ((c = getopt(argc, argv, "m:d:c:q:H:S:xnpsP:i:j:l:")) != -1) {
     switch (c) {
+    case 's': split = 1; rmapflg |= RMAPFLG_SPLIT | RMAPFLG_NOSHRTINFO | RMAPFLG_SENSITIVE; break;      /* smalt map -p (smalt.c:507-511) */
     case 'p': g_with_post = 1; rdPostDump = 1; break;
     case 'P': matefil = optarg; break;
     case 'i': ins_max = atoi(optarg); break;
@@ -228,6 +230,17 @@ int main(int argc, char *argv[])
 	printf("PP %llu mate\n", readno); rdDumpPost(stdout, rmp->rsmp);
       }
       printf("PE %llu err=%d pairflg=%u ncalls=%d\n", readno, errcode, (unsigned) pairflg, g_pm.callno);
+      readno++;
+      continue;
+    }
+    if (split) {         /* split reads: one block per mapSingleRead call (the read's own, then mapSecondary's, rmap.c:1435), as in paired mode */
+      printf("PAIR %llu %s - len=%u,0\n", readno, seqFastqGetSeqName(readp), readlen);
+      g_pm.on = 1; g_pm.pairno = readno; g_pm.callno = 0; g_pm.readp = readp; g_pm.matep = NULL; g_pm.htp = htp;
+      errcode = rmapSingle(errmsgp, rmp, readp, ncut, covermin, minscor, scordiff,
+			   (UCHAR) minbasq, 512, 2048, rmapflg, smp, rfp, htp, ssp, codecp);
+      g_pm.on = 0;
+      printf("PE %llu err=%d pairflg=0 ncalls=%d\n", readno, errcode, g_pm.callno);
+      if (g_with_post) rdDumpPost(stdout, rmp->rsrp);      /* the set as rmapSingle leaves it */
       readno++;
       continue;
     }

@@ -153,6 +153,8 @@ def lib():
         L.smaltgpu_reads_create.restype = C.c_void_p
         L.smaltgpu_reads_free.argtypes = [C.c_void_p]
         L.smaltgpu_reads_parse.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_int, C.c_uint32, C.c_int, C.POINTER(ReadsView)]
+        L.smaltgpu_map_split.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(Params), C.c_void_p, C.c_int,
+                                         C.POINTER(PostOut), C.POINTER(C.c_uint32)]
         L.smaltgpu_report_create.restype = C.c_void_p
         L.smaltgpu_report_free.argtypes = [C.c_void_p]
         L.smaltgpu_report_header.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.c_int64, C.POINTER(ReportOpts), C.c_char_p, C.c_char_p,
@@ -302,6 +304,15 @@ class Mapper:
             t += len(r)
         off[n] = t
         return b"".join(reads), (b"".join(quals) if quals is not None else None), off
+
+    def map_split(self, reads: Sequence[bytes], quals: Optional[Sequence[bytes]], params: Params, post, nthreads: int = 2):
+        """smaltgpu_map_split: both calls of every read (smalt map -p) and the post-call passes.  post: a handle of
+        lib().smaltgpu_post_create() that owns the arrays -> (PostOut, number of reads that got a second call)"""
+        bases, q, off = self._pack(reads, quals)
+        out = PostOut()
+        nsec = C.c_uint32()
+        _check(lib().smaltgpu_map_split(self.h, post, bases, q, off, len(reads), C.byref(params), self.index.h, nthreads, C.byref(out), C.byref(nsec)))
+        return out, nsec.value
 
     def map_batch(self, reads: Sequence[bytes], quals: Optional[Sequence[bytes]], params: Params, allow_read_errors: bool = False):
         """-> (list per read of result dicts in the reference's raw order, list of stat dicts).

@@ -165,3 +165,94 @@ def test_second_call_of_a_split_read_matches_the_oracle(oracle_built, tmp_path):
         gix.close()
         ol.lib().or_index_free(oix)
     assert nres > 200
+
+
+import split_replay as sr  # noqa: E402
+
+
+@pytest.mark.parametrize("entry", sr.MANIFEST, ids=[e["tag"] for e in sr.MANIFEST])
+def test_gpu_replays_both_calls_of_split_reads(entry, oracle_built, tmp_path):
+    """the committed dumps of the reference's own rmapSingle under RMAPFLG_SPLIT (tests/golden/gs_*): every first call in one
+    device batch, every second call (k-mer words from the stretch mapSecondary's rule names) in another; stage state line by
+    line, alignments appended as results.c:1906-1935 does, the set's running maxima"""
+    from smalt_amd import api
+    import pair_replay as pr
+    fx = sr.load_fixture(entry, tmp_path)
+    gix = api.Index.load(fx["prefix"], 0)
+    calls = sr.planned_calls(fx, entry)
+    maxlen = max(len(r[1]) for r in fx["reads"])
+    ndone = 0
+    try:
+        for second in (False, True):
+            sub = [(no, c, rng) for no, c, rng in calls if (rng is not None) == second]
+            assert len(sub) > 20
+            par = gix.default_params()
+            c0 = sub[0][1]
+            assert all((c["mincov"], c["flags"], c["belowmax"], c["minscor"]) == (c0["mincov"], c0["flags"], c0["belowmax"], c0["minscor"]) for _, c, _ in sub)
+            par.min_cover, par.min_swatscor_below_max, par.min_basqval, par.min_swatscor = c0["mincov"], c0["belowmax"], fx["min_basq"], c0["minscor"]
+            par.rmapflg = c0["flags"] & (api.FLG_BEST | api.FLG_SEQBYSEQ | api.FLG_NOSHRTINFO | api.FLG_SENSITIVE)
+            rd = [fx["reads"][no] for no, _, _ in sub]
+            mp = api.Mapper(gix, len(sub), maxlen)
+            mp.set_debug(1)
+            try:
+                res, stats, cf = mp.map_batch_ctx([r[1] for r in rd], [r[2] for r in rd], par, prev_max=[c["prevmax"] for _, c, _ in sub], raw_alignments=True,
+                                                  seed_range=[rng for _, _, rng in sub] if second else None)
+                for i, (no, c, rng) in enumerate(sub):
+                    st = stats[i]
+                    assert st["err"] == 0
+                    lines = pr.stage_lines(mp.dump_read(i, rd[i][0]))
+                    lines[0] = lines[0].replace("READ %d " % i, "READ %d " % no, 1)
+                    try:
+                        pr.check_call(c, lines, res[i], cf[i], (st["swmax"], st["sw2nd"], st["nseg"], st["nseg_tot"], st["nhit"], st["nhit_tot"]))
+                    except AssertionError as e:
+                        raise AssertionError("read %d, stretch %s: %s" % (no, rng, str(e)[:800]))
+                    ndone += 1
+            finally:
+                mp.close()
+    finally:
+        gix.close()
+    assert ndone == entry["calls"]
+
+
+@pytest.mark.parametrize("entry", sr.MANIFEST, ids=[e["tag"] for e in sr.MANIFEST])
+def test_map_split_leaves_the_set_the_reference_leaves(entry, oracle_built, tmp_path):
+    """smaltgpu_map_split over the fixture's reads: the alignment set of every read as rmapSingle returns it (behind the `PE`
+    line of the dump) -- rows with status, mapping quality, probability to the last bit, sequence, segment and rank, the
+    sorted and the per-segment order -- and the number of second calls"""
+    from smalt_amd import api
+    fx = sr.load_fixture(entry, tmp_path)
+    L = api.lib()
+    gix = api.Index.load(fx["prefix"], 0)
+    MASK = ~(0x10 | 0x20 | 0x200)
+    post = L.smaltgpu_post_create()
+    par = gix.default_params()
+    par.rmapflg |= api.FLG_NOSHRTINFO | api.FLG_SENSITIVE
+    par.min_basqval = fx["min_basq"]
+    mp = api.Mapper(gix, len(fx["reads"]), max(len(r[1]) for r in fx["reads"]))
+    try:
+        for nthreads in (1, 3):
+            out, nsec = mp.map_split([r[1] for r in fx["reads"]], [r[2] for r in fx["reads"]], par, post, nthreads)
+            assert nsec == entry["second_calls"]
+            by_no = {R["no"]: R for R in fx["dump"]}
+            for i in range(len(fx["reads"])):
+                a, e = out.res_off[i], out.res_off[i + 1]
+                if i not in by_no or not by_no[i]["post_final"]:
+                    assert a == e
+                    continue
+                st = sr.post_state(by_no[i]["post_final"])
+                assert st["ps"][0] == e - a and st["ps"][2] == out.qsegno[i] and st["ps"][3] == out.setstatus[i], (i, st["ps"], e - a, out.qsegno[i], out.setstatus[i])
+                for k_, w in enumerate(st["rows"]):
+                    r = out.res[a + k_]
+                    got = (r.status & MASK, r.swatscor, r.mapscor, repr(r.prob), r.q_start, r.q_end, r.s_start, r.s_end, r.sidx, r.rsltx, r.qsegx, r.swrank,
+                           bytes(out.diffstr[r.stroffs:r.stroffs + r.strlen]))
+                    exp = (w["status"] & MASK, w["score"], w["mapscor"], repr(w["prob"]), w["q_start"], w["q_end"], w["s_start"], w["s_end"], w["sidx"], w["rsltx"], w["qsegx"],
+                           w["swrank"], w["diffstr"])
+                    assert got == exp, (i, k_, got, exp)
+                assert [out.sortr[x] for x in range(out.sort_off[i], out.sort_off[i + 1])] == st["so"], i
+                if st["ss"] is not None:
+                    assert [out.segsrtr[x] for x in range(out.sort_off[i], out.sort_off[i + 1])] == st["ss"], i
+                    assert [out.segnor[x] for x in range(out.seg_off[i], out.seg_off[i + 1])] == st["sg"], i
+    finally:
+        mp.close()
+        L.smaltgpu_post_free(post)
+        gix.close()
