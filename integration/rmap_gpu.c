@@ -228,7 +228,8 @@ int rmapGpuBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, int n, int 
   smaltgpu_params par;
   for (i = 0; i < n; i++) { (void)seqFastqGetConstSequence(reads[i], &rlen, &cod); tot += rlen; if (rlen > maxlen) maxlen = rlen; }
   pthread_once(&g_once, gpuReadConfig);
-  const int combine = g_combine;                             /* default: blocks of all worker threads form one GPU batch */
+  const int split = (rmapflg & RMAPFLG_SPLIT) != 0;          /* smalt map -p: smaltgpu_map_split runs both calls of every read on this worker's mapper */
+  const int combine = g_combine && !split;                   /* default: blocks of all worker threads form one GPU batch */
   if ((slot = gpuMapperForBatch(rmp, maxlen, (uint32_t)n, tot, !combine)) < 0) { fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error()); ERRMSGNO(errmsgp, ERRCODE_FAILURE); }
   double t0 = tmNow(), t1;
   for (i = 0, tot = 0; i < n; i++) {
@@ -245,13 +246,29 @@ int rmapGpuBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, int n, int 
   matchscor = scoreProfileGetAvgPenalties(&mismatchscor, &gapinitscor, &gapextscor, rmp->prp->scorprofp);
   smaltgpu_params_default(&par, g_ix);
   par.ktuple_maxhit = ktuple_maxhit; par.min_swatscor = min_swatscor; par.min_swatscor_below_max = min_swatscor_below_max;
-  par.min_basqval = min_basqval; par.target_depth = target_depth; par.max_depth = max_depth; par.rmapflg = rmapflg;
+  par.min_basqval = min_basqval; par.target_depth = target_depth; par.max_depth = max_depth; par.rmapflg = rmapflg & ~(RMAPFLG_t)RMAPFLG_SPLIT;
   par.match = matchscor; par.mismatch = mismatchscor; par.gap_init = gapinitscor; par.gap_ext = gapextscor;
   if (tupcovmin < 1.01) { par.min_cover = 0; par.min_cover_frac = tupcovmin; }      /* smalt.c:1113-1126 */
   else { par.min_cover = (uint32_t)tupcovmin; par.min_cover_frac = 0.0; }
   g_map[slot].nbatch = 0;
   g_map[slot].use_comb = combine;
   t1 = tmNow(); g_tm[slot][TM_STAGE] += t1 - t0; t0 = t1;
+  if (split) {
+    /* rmapSingle with RMAPFLG_SPLIT (rmap.c:1716-1728): the read's own call, mapSecondary's call (rmap.c:1435) and the passes of
+     * resultSetSortAndAssignSequence behind each, for the whole block; rmapGpuFinish puts the finished sets into the RMap */
+    if (!g_map[slot].post && !(g_map[slot].post = smaltgpu_post_create())) ERRMSGNO(errmsgp, ERRCODE_NOMEM);
+    g_map[slot].have_post = 0;
+    const int rv = smaltgpu_map_split(g_map[slot].mp, g_map[slot].post, (const uint8_t *)g_map[slot].bases, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
+                                      g_map[slot].off, (uint32_t)n, &par, g_ixdev[slot % g_ndev], 1, &g_map[slot].pout, NULL);
+    if (rv) {
+      fprintf(stderr, "smaltgpu: %s\n", smaltgpu_last_error());
+      ERRMSGNO(errmsgp, rv == SMALTGPU_ESCORE ? ERRCODE_SWATSCOR : ERRCODE_FAILURE);
+    }
+    g_map[slot].have_post = 2;
+    g_map[slot].nbatch = n;
+    g_tm[slot][TM_GPU] += tmNow() - t0;
+    return ERRCODE_SUCCESS;
+  }
   if (combine) {
     char emsg[256] = "";
     const int crv = gpuCombineSubmit(g_ndev, (const smaltgpu_index *const *)g_ixdev, g_map[slot].bases, has_qual ? g_map[slot].quals : NULL, g_map[slot].off,
@@ -310,6 +327,16 @@ int rmapGpuFinish(ErrMsg *errmsgp, RMap *rmp, int i, SeqFastq *readp, short max_
   if ((errcode = makeRMAPPROFfromRead(rmp->prp, readp, scormtxp, codecp))) ERRMSGNO(errmsgp, errcode);
   (void)seqFastqGetConstSequence(readp, &rlen, NULL);
   if (rlen < hashTableGetKtupLen(htp, NULL)) return ERRCODE_SUCCESS;                      /* ERRCODE_SHORTSEQ is swallowed (rmap.c:1736) */
+  if (g_map[slot].have_post == 2) {          /* split reads: the set as rmapSingle leaves it, whole from the library (blank set: every row is new) */
+    const smaltgpu_post_out *po = &g_map[slot].pout;
+    const unsigned nrow = (unsigned)(po->res_off[i + 1] - po->res_off[i]);
+    if (nrow > 0 && (errcode = resultSetInjectPost(rmp->rsrp, nrow, po->res + po->res_off[i], po->diffstr,
+                                                   (unsigned)(po->sort_off[i + 1] - po->sort_off[i]), po->sortr + po->sort_off[i], po->segsrtr + po->sort_off[i],
+                                                   (unsigned)(po->seg_off[i + 1] - po->seg_off[i]), po->segnor + po->seg_off[i], po->qsegno[i], po->setstatus[i])))
+      ERRMSGNO(errmsgp, errcode);
+    if ((errcode = resultSetFilterResults(rmp->rsrp, rsfp, readp))) ERRMSGNO(errmsgp, errcode);
+    return ERRCODE_SUCCESS;
+  }
   if (o->stat[i].errcode) {                /* the reference's own per-read failure keeps its code (alignment.c:767 -> rmap.c:1417) */
     gpuFailOrderly("a read failed on the device");
     ERRMSGNO(errmsgp, o->stat[i].errcode == SMALTGPU_ESCORE ? ERRCODE_SWATSCOR : ERRCODE_FAILURE);

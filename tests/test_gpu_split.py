@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALT = os.path.join(ROOT, "oracle", "_ref", "smalt")
 PROG = os.path.join(ROOT, "smalt_amd", "smaltgpu-map")
+SMALT_GPU = os.path.join(ROOT, "oracle", "_ref", "smalt_gpu")     # the reference program with its mapping worker bound to the library (integration/)
 
 
 def chimeric_reads(ch, nreads, rlen, seed):
@@ -96,6 +97,18 @@ def test_smaltgpu_map_prints_what_smalt_map_prints_for_split_reads(k, s, nchr, c
         b = [ln for ln in open(out_gpu).read().split("\n") if not ln.startswith("@PG")]
         diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
         assert not diff and len(a) == len(b), (len(a), len(b), diff[:3])
+    # the reference's own program bound to the library: blocks of reads through smaltgpu_map_split (integration/rmap_gpu.c), its own report
+    if os.path.exists(SMALT_GPU):
+        env = dict(os.environ, SMALTGPU_INDEX_PREFIX=pre)
+        for extra, more in (([], {}), (["-n", "3", "-O"], {"SMALTGPU_BLOCK_READS": "256"})):
+            r = subprocess.run([SMALT_GPU, "map", "-p"] + opts + extra + ["-o", out_gpu, pre, fq], capture_output=True, env=dict(env, **more))
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            b = [ln for ln in open(out_gpu).read().split("\n") if not ln.startswith("@PG")]
+            diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
+            assert not diff and len(a) == len(b), ("bound program", extra, len(a), len(b), diff[:3])
+        # ... and it does go through the library: without the index prefix it cannot map
+        env.pop("SMALTGPU_INDEX_PREFIX")
+        assert subprocess.run([SMALT_GPU, "map", "-p"] + opts + ["-o", out_gpu, pre, fq], capture_output=True, env=env).returncode != 0
     # negative control: without -p the output is a different one (the comparison above is not blind to the partial alignments)
     r = subprocess.run([PROG] + opts + ["-o", out_gpu, pre, fq], capture_output=True)
     assert r.returncode == 0 and open(out_gpu).read().split("\n") != open(out_ref).read().split("\n")
