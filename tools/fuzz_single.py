@@ -3,7 +3,8 @@
 alone) on the same read file -- reference shape, index word length and stride, read lengths, output format and search options
 drawn per case.  Prints one line per case and the first differing lines; exit status 1 if any case differs.
 usage: fuzz_single.py [ncases] [nreads] [seed]        (GPU box; needs make -C oracle ref)
-FUZZ_BOUND=1 compares the bound program (oracle/_ref/smalt_gpu) instead of smaltgpu-map."""
+FUZZ_BOUND=1 compares the bound program (oracle/_ref/smalt_gpu) instead of smaltgpu-map.
+FUZZ_SPLIT=1: split reads (-p) on chimeric reads (tests/test_gpu_split.py), SSAHA lines and user scores (-S) among the draws."""
 import os
 import subprocess
 import sys
@@ -40,6 +41,13 @@ def main():
         if rng.random() < 0.3:
             opts += ["-y", str(round(float(rng.uniform(0.6, 0.98)), 2))]
         opts += ["-r", str(rng.choice(["-1", "3", "11"]))]
+        split = bool(os.environ.get("FUZZ_SPLIT"))
+        if split:
+            opts = ["-p"] + opts
+            if rng.random() < 0.3:
+                opts[opts.index("-f") + 1] = "ssaha"
+            if rng.random() < 0.3:
+                opts += ["-S", str(rng.choice(["match=2,subst=-3,gapopen=-5,gapext=-3", "subst=-3,gapopen=-6", "match=1,subst=-1,gapopen=-3,gapext=-2", "gapopen=-5,gapext=-4"]))]
         if rng.random() < 0.35:
             opts += ["-d", str(rng.choice(["0", "3", "10", "-1"]))]
         with tempfile.TemporaryDirectory() as tmp:
@@ -48,6 +56,9 @@ def main():
             fa, fq = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.fq")
             synth.write_fasta(fa, ch)
             reads, _ = synth.make_reads(ch, nreads, min(rlen, chrlen - 10), seed=seed0 * 104729 + case, sub_rate=float(rng.choice([0.0, 0.02, 0.05])), indel_read_frac=float(rng.choice([0.0, 0.2, 0.5])))
+            if split and min(rlen, chrlen - 10) >= 60:
+                import test_gpu_split as tgs
+                reads = [np.frombuffer(bytes(b).translate(bytes.maketrans(b"ACGTN", bytes([0, 1, 2, 3, 0]))), dtype=np.uint8) for _, b in tgs.chimeric_reads(ch, nreads, min(rlen, chrlen - 10), seed0 * 15485863 + case)]
             with open(fq, "wb") as f:
                 for i, r in enumerate(reads):
                     b = bytearray(synth.codes_to_ascii(r))
