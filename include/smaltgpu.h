@@ -36,6 +36,8 @@ enum {
 /* RMAP_FLAGS subset honoured on this path (same values as rmap.h:53-65). */
 enum {
   SMALTGPU_FLG_BEST = 0x02,
+  SMALTGPU_FLG_SPLIT = 0x08,     /* split reads: honoured by smaltgpu_map_pairs (second calls of both mates ahead of the pairing, rmap.c:2073-2097);
+                                  * the mapping calls themselves ignore it -- for single reads the two calls are smaltgpu_map_split */
   SMALTGPU_FLG_SEQBYSEQ = 0x10,
   SMALTGPU_FLG_NOSHRTINFO = 0x20,
   SMALTGPU_FLG_SENSITIVE = 0x80

@@ -172,7 +172,6 @@ int main(int argc, char **argv) {
   const char *prefix = argv[a], *readfil = argv[a + 1], *matefil = argc - a == 3 ? argv[a + 2] : nullptr;
   const bool paired = matefil != nullptr;
   if (paired && ins_min > ins_max) die("-j above -i");
-  if (paired && split) die("split reads of pairs (-p with two read files) are not supported by this program (use the bound `smalt map`, INTEGRATION.md)");
   if (nthreads < 1) { nthreads = (int)std::thread::hardware_concurrency(); if (nthreads > 16) nthreads = 16; if (nthreads < 1) nthreads = 1; }
 
   smaltgpu_report_opts ro;
@@ -255,7 +254,7 @@ int main(int argc, char **argv) {
   par.min_swatscor_below_max = d;
   if (d) par.rmapflg &= ~(uint32_t)SMALTGPU_FLG_BEST;
   if (exhaustive) par.rmapflg |= SMALTGPU_FLG_NOSHRTINFO | SMALTGPU_FLG_SENSITIVE;      // smalt.c:531-533
-  if (split) { par.rmapflg |= SMALTGPU_FLG_NOSHRTINFO | SMALTGPU_FLG_SENSITIVE; ro.outflags |= SMALTGPU_OUT_SPLIT; }      // smalt.c:507-511 (RMAPFLG_SPLIT: smaltgpu_map_split)
+  if (split) { par.rmapflg |= SMALTGPU_FLG_SPLIT | SMALTGPU_FLG_NOSHRTINFO | SMALTGPU_FLG_SENSITIVE; ro.outflags |= SMALTGPU_OUT_SPLIT; }      // smalt.c:507-511 (RMAPFLG_SPLIT: smaltgpu_map_split)
   par.min_basqval = (uint8_t)q;
   if (mincover < 1.01) { par.min_cover = 0; par.min_cover_frac = mincover; } else { par.min_cover = (uint32_t)mincover; par.min_cover_frac = 0.0; }   // smalt.c:1113-1126
   smaltgpu_pair_opts po;

@@ -29,6 +29,8 @@ struct BlockParams {
   const uint64_t *sop; int64_t nseq;        // sequence offsets
   const uint32_t *packed_host;              // host copy of the packed reference, or null when alignments cannot cross sequences
   int nthreads;
+  bool split = false;                       // RMAPFLG_SPLIT: mapSecondary for both mates ahead of the pairing (rmap.c:2073-2097)
+  int s = 0;                                // sampling step of the index (the stretch of a second call holds a word and a step)
 };
 enum RoundKind { ROUND_PLAIN = 0, ROUND_RESTRICTED = 1, ROUND_APPEND = 2, ROUND_FINE = 3 };
 struct Round {                              // one batch of mapping calls: read ids are 2 * pair + mate
@@ -37,6 +39,7 @@ struct Round {                              // one batch of mapping calls: read 
   const uint64_t *iv_off; const smaltgpu_interval *iv;      // ROUND_RESTRICTED, ROUND_FINE
   const int32_t *min_score;                                  // ROUND_FINE
   const int32_t *prev_max;                                   // ROUND_APPEND, ROUND_FINE: (max, second) per call
+  const uint32_t *seed_range = nullptr;                      // split reads (a ROUND_APPEND): (first, last) base the k-mer words of a call come from
 };
 
 // The tables of a block at rest: byte runs (Table::pack) in arenas, one arena per worker thread and post-call pass -- a pass only
@@ -274,6 +277,48 @@ struct PairBlock {
         nrounds[ROUND_FINE] += nd;
         if (!take(rdd, o, in, bp, [&](uint32_t, uint32_t, Table &, int) { return true; })) return false;
         host_ms[H_AFTER_D] += ck.lap();
+      }
+    }
+
+    // ---- split reads: a second call for the read and for the mate, k-mer words from the stretch the best alignment of the first read
+    //      segment leaves uncovered (mapSecondary, rmap.c:1435-1505; rmapPair calls it for both sets ahead of the pairing, :2073-2097)
+    if (bp.split) {
+      std::vector<uint8_t> wants((size_t)2 * n, 0);
+      std::vector<uint32_t> stretch((size_t)4 * n, 0);
+      std::vector<int32_t> pm((size_t)4 * n, 0);
+      spread(2 * n, nt, [&](uint32_t lo, uint32_t hi, int) {
+        Table tb;
+        for (uint32_t id = lo; id < hi; id++) {
+          if (plan[id >> 1].idle || !packed.size(id)) continue;
+          tb.unpack(packed.data(id), packed.size(id));
+          if (tb.by_score.empty() || !(tb.set_bits & smgpost::SET_SEGMENTED) || tb.segment_begin.size() < 2 || tb.segment_begin[1] <= tb.segment_begin[0]) continue;
+          const int32_t top = tb.by_segment[(size_t)tb.segment_begin[0]];
+          const uint32_t lo_q = tb.q_lo[(size_t)top], hi_q = tb.q_hi[(size_t)top], qlen = len_of(in, id);
+          if (hi_q > qlen || lo_q > hi_q || qlen < (uint32_t)bp.k) continue;
+          uint32_t a, b;
+          if ((uint64_t)lo_q + hi_q > qlen) { a = 0; b = lo_q > 1 ? lo_q - 2 : 0; } else { a = hi_q; b = qlen - 1; }
+          if ((uint64_t)a + (uint32_t)bp.k + (uint32_t)bp.s > (uint64_t)b + 1) continue;
+          wants[id] = 1; stretch[2 * (size_t)id] = a; stretch[2 * (size_t)id + 1] = b;
+          pm[2 * (size_t)id] = tb.score_max; pm[2 * (size_t)id + 1] = tb.score_2nd;
+        }
+      });
+      std::vector<uint32_t> ids_e, range_e;
+      std::vector<int32_t> pm_e;
+      for (uint32_t w = 0; w < 2; w++) {              // the reads, then the mates: a round holds at most one call per pair (the mapper's batch size)
+      ids_e.clear(); range_e.clear(); pm_e.clear();
+      for (uint32_t id = w; id < 2 * n; id += 2) if (wants[id]) {
+        ids_e.push_back(id); range_e.push_back(stretch[2 * (size_t)id]); range_e.push_back(stretch[2 * (size_t)id + 1]);
+        pm_e.push_back(pm[2 * (size_t)id]); pm_e.push_back(pm[2 * (size_t)id + 1]);
+      }
+      if (!ids_e.empty()) {
+        Round re{ROUND_APPEND, ids_e.data(), (uint32_t)ids_e.size(), nullptr, nullptr, nullptr, pm_e.data(), range_e.data()};
+        ck.lap();
+        if (!exec.map(re, &o, error)) return false;
+        ck.lap();
+        nrounds[ROUND_APPEND] += (uint32_t)ids_e.size();
+        if (!take(re, o, in, bp, [&](uint32_t, uint32_t, Table &, int) { return true; })) return false;
+        host_ms[H_AFTER_C] += ck.lap();
+      }
       }
     }
     return true;

@@ -80,6 +80,7 @@ struct DeviceExec {
     smaltgpu_callctx cx;
     memset(&cx, 0, sizeof(cx));
     cx.iv_off = rd.iv_off; cx.iv = rd.iv; cx.min_swatscor = rd.min_score; cx.prev_max = rd.prev_max; cx.fine_index = rd.kind == ROUND_FINE;
+    cx.seed_range = rd.seed_range;
     cx.raw_alignments = rd.kind == ROUND_APPEND || rd.kind == ROUND_FINE;      // these rounds append to tables that may hold alignments: Table::take_call compares
     int rv;
     if (resident) rv = smaltgpu_map_batch_ctx_resident(m, resident, rd.ids, rd.n, &par, &cx, o);
@@ -116,7 +117,8 @@ static int map_pairs(smaltgpu_mapper *m, const smaltgpu_resident_reads *resident
   bp.map = *par;
   bp.map.min_swatscor_below_max = 0;                       // MINSCOR_BELOW_MAX_BEST (rmap.c:87)
   bp.d_min = po->insert_min; bp.d_max = po->insert_max; bp.lib = po->library; bp.every_pair = po->every_pair != 0;
-  bp.k = ds.k; bp.sop = ds.sop; bp.nseq = ds.nseq;
+  bp.k = ds.k; bp.s = ds.s; bp.sop = ds.sop; bp.nseq = ds.nseq;
+  bp.split = (par->rmapflg & SMALTGPU_FLG_SPLIT) != 0;
   // alignments can cross sequence junctions only in concatenated mode: the pieces are scored against a host copy of the reference
   bp.packed_host = (par->rmapflg & SMALTGPU_FLG_SEQBYSEQ) ? nullptr : smaltgpu_index_packed_host(ix);
   if (!(par->rmapflg & SMALTGPU_FLG_SEQBYSEQ) && !bp.packed_host) return SMALTGPU_ENODEV;

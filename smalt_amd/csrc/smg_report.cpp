@@ -791,6 +791,28 @@ void sheet_add(PairSheet &sh, const Entry &e, const Table &A, const Table &B) {
   sh.links.push_back(ln);
 }
 
+// split reads: the best alignments of every read segment of a mate join its list as partial alignments unless they are there already
+// (resultSetAdd2ndaryResultsToReport, results.c:2250-2278, from resultSetAddPairToReport, resultpairs.c:1293-1311; an alignment the
+// report knows is ignored: reportAddMap, report.c:1676-1679)
+void sheet_add_partial(PairSheet &sh, int w, const Table &t) {
+  if (t.by_score.empty() || !(t.set_bits & smgpost::SET_SEGMENTED)) return;
+  std::vector<Ali> &v = sh.side[w];
+  for (int g = 0; g < t.nsegments && (size_t)g + 1 < t.segment_begin.size(); g++) {
+    int last = 0;
+    for (int k = t.segment_begin[(size_t)g]; k < t.segment_begin[(size_t)g + 1]; k++) {
+      const int row = t.by_segment[(size_t)k];
+      if (t.bits[(size_t)row] & smgpost::WITHHELD) continue;
+      if (t.score[(size_t)row] < last) break;
+      last = t.score[(size_t)row];
+      const Ali a = ali_of(t, row, t.quality[(size_t)row], MF_PAIRED | MF_PARTIAL | (w ? (uint32_t)MF_2NDMATE : 0u));
+      bool known = false;
+      for (const Ali &b : v)
+        if (a.ss == b.ss && a.se == b.se && a.sidx == b.sidx && a.qs == b.qs && a.qe == b.qe && (a.status & (MF_REVERSE | MF_2NDMATE)) == (b.status & (MF_REVERSE | MF_2NDMATE))) { known = true; break; }
+      if (!known) v.push_back(a);
+    }
+  }
+}
+
 struct PairJob {
   const smaltgpu_pairs *pairs;
   ReadCtx cx[2];
@@ -817,6 +839,7 @@ bool pair_entries(const PairJob &jb, uint32_t p, Table &A, Table &B, smgpairs::J
 bool pair_lines(std::string &o, const PairJob &jb, uint32_t p, const Table &A, const Table &B, const std::vector<Entry> &entries, PairSheet &sh) {
   sh.clear();
   for (const Entry &e : entries) sheet_add(sh, e, A, B);
+  if ((jb.op->outflags & SMALTGPU_OUT_BEST) && (jb.op->outflags & SMALTGPU_OUT_SPLIT)) { sheet_add_partial(sh, 0, A); sheet_add_partial(sh, 1, B); }
   auto line = [&](int w, const Ali &a, const PairSide *ps) { return print_line(o, jb.cx[w], p, a, ps); };
   for (int w = 0; w < 2; w++) sh.printed[w].assign(sh.side[w].size(), 0);
   for (const PairSheet::Link &ln : sh.links) {                       // reportWrite (report.c:1758-1867): the pairs first ...

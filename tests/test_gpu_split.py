@@ -269,3 +269,69 @@ def test_map_split_leaves_the_set_the_reference_leaves(entry, oracle_built, tmp_
         mp.close()
         L.smaltgpu_post_free(post)
         gix.close()
+
+
+def chimeric_pairs(tmp, nchr, chrlen, npairs, rlen, seed):
+    """read pairs (fragments of 300 +- 30 bases) of which two in five carry a mate whose tail (or head) comes from somewhere else"""
+    from smalt_amd import synth
+    ch = synth.make_reference(nchr, chrlen, seed=seed, repeat_frac=0.2, n_fam=2, cons_len=400, divergence=0.03)
+    fa = os.path.join(tmp, "ref.fa")
+    synth.write_fasta(fa, ch)
+    r1, r2, _ = synth.make_pairs(ch, npairs, rlen, seed=seed + 1, insert_mean=300, insert_sd=30, sub_rate=0.02, indel_read_frac=0.2)
+    rng = np.random.default_rng(seed + 2)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    fqs = []
+    for which, reads in ((1, r1), (2, r2)):
+        fq = os.path.join(tmp, "reads_%d.fq" % which)
+        with open(fq, "wb") as f:
+            for i, r in enumerate(reads):
+                b = bytearray(synth.codes_to_ascii(r))
+                if (i + which) % 5 < 2 and len(b) > 80:                 # a stretch from elsewhere, either strand
+                    cut = int(rng.integers(30, len(b) - 30))
+                    c = int(rng.integers(0, len(ch)))
+                    p = int(rng.integers(0, len(ch[c]) - len(b)))
+                    alien = synth.codes_to_ascii(ch[c][p:p + len(b) - cut])
+                    if rng.random() < 0.5:
+                        alien = alien.translate(comp)[::-1]
+                    b = b[:cut] + bytearray(alien) if rng.random() < 0.5 else bytearray(alien) + b[len(b) - cut:]
+                u = rng.random()
+                if u < 0.03:
+                    b = b[:int(rng.integers(5, 16))]                    # around the word length
+                elif u < 0.06:
+                    b = bytearray(synth.codes_to_ascii(rng.integers(0, 4, size=len(b), dtype=np.uint8)))
+                if rng.random() < 0.05 and len(b) > 4:
+                    b[int(rng.integers(0, len(b)))] = ord("N")
+                q = bytes(33 + int(x) for x in rng.integers(5, 41, size=len(b)))
+                f.write(b"@p%d/%d\n" % (i, which) + bytes(b) + b"\n+\n" + q + b"\n")
+        fqs.append(fq)
+    return fa, fqs
+
+
+@pytest.mark.skipif(not os.path.exists(SMALT), reason="reference binary not built (make -C oracle ref)")
+@pytest.mark.parametrize("k,s,nchr,chrlen,rlen,opts", [
+    (13, 6, 3, 300_000, 150, ["-f", "cigar", "-i", "500"]),
+    (11, 3, 2, 200_000, 120, ["-f", "sam", "-i", "600", "-j", "50", "-q", "10"]),
+    (13, 4, 3, 200_000, 200, ["-f", "ssaha", "-i", "500", "-r", "-1"]),
+    (13, 6, 600, 2_000, 100, ["-f", "sam:nohead", "-i", "500"]),                 # concatenated mode
+    (13, 6, 3, 300_000, 150, ["-f", "cigar", "-i", "500", "-l", "mp", "-m", "30"]),
+])
+def test_smaltgpu_map_prints_what_smalt_map_prints_for_split_read_pairs(k, s, nchr, chrlen, rlen, opts, tmp_path):
+    """rmapPair with RMAPFLG_SPLIT (rmap.c:2073-2097): after its rounds a second call for the read and for the mate, then the pairing;
+    the partial alignments of both mates follow the pair's lines (resultpairs.c:1293-1311)"""
+    tmp = str(tmp_path)
+    if "-r" not in opts:
+        opts = opts + ["-r", "3"]
+    fa, fqs = chimeric_pairs(tmp, nchr, chrlen, 1200, rlen, seed=k * 1000 + s * 10 + nchr + 5)
+    pre = os.path.join(tmp, "idx")
+    subprocess.run([SMALT, "index", "-k", str(k), "-s", str(s), pre, fa], check=True, capture_output=True)
+    out_ref, out_gpu = os.path.join(tmp, "ref.out"), os.path.join(tmp, "gpu.out")
+    subprocess.run([SMALT, "map", "-p"] + opts + ["-o", out_ref, pre] + fqs, check=True, capture_output=True)
+    a = [ln for ln in open(out_ref).read().split("\n") if not ln.startswith("@PG")]
+    partial = sum(1 for ln in a if ln.startswith("cigar:P") or ln.startswith("alignment:P") or (len(ln.split("\t")) > 1 and ln.split("\t")[1].isdigit() and int(ln.split("\t")[1]) & 0x100))
+    assert partial >= 200, partial
+    for extra in (["-B", "300"], ["-B", "4000", "-n", "2"]):
+        r = subprocess.run([PROG, "-p"] + opts + extra + ["-o", out_gpu, pre] + fqs, capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        b = [ln for ln in open(out_gpu).read().split("\n") if not ln.startswith("@PG")]
+        diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
+        assert not diff and len(a) == len(b), (len(a), len(b), diff[:3])
