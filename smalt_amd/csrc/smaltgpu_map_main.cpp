@@ -50,7 +50,7 @@ void usage() {
           "  -y <num>   minimum identity (fraction of the read if <= 1, else bases)\n"
           "  -c <num>   minimum k-mer cover (fraction of the read if <= 1, else bases)\n"
           "  -x         more sensitive search (all seeds, deeper candidate lists)\n"
-          "  -p         split reads (single reads): a second alignment for the part of a read its best alignment leaves uncovered\n"
+          "  -p         split reads: a second alignment for the part of a read (or mate) its best alignment leaves uncovered\n"
           "  -q <int>   base quality threshold for k-mer words\n"
           "  -S <spec>  alignment scores, e.g. match=1,subst=-2,gapopen=-4,gapext=-3 (the default; any subset)\n"
           "  -n <int>   host threads for parsing, post-processing and formatting (default: up to 16)\n"
@@ -60,7 +60,7 @@ void usage() {
           "  -i <int>   maximum insert size of read pairs (default 500); -j <int> minimum insert size (default 0)\n"
           "  -l <lib>   pair library: pe (default) | mp | pp\n"
           "with two read files the reads are mapped as pairs (read i of the first with read i of the second file);\n"
-          "-w, -a, insert-size histograms (-g) and split reads of PAIRS go through the bound reference program (INTEGRATION.md)\n");
+          "-w, -a and insert-size histograms (-g) go through the bound reference program (INTEGRATION.md)\n");
   exit(2);
 }
 

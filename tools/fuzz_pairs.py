@@ -56,6 +56,25 @@ def main():
                 tmp = os.environ["FUZZ_KEEP"]
                 os.makedirs(tmp, exist_ok=True)
             fa, fqs = t._pair_data(tmp, nchr, chrlen, npairs, rlen, seed=seed0 * 7919 + case, rep=0.0 if concat else float(rng.choice([0.1, 0.3, 0.5])), ins=(mean, sd))
+            if os.environ.get("FUZZ_SPLIT"):          # split reads (-p): two mates in five get a stretch from somewhere else, either strand
+                opts = ["-p"] + opts
+                seqs = [x.split(b"\n", 1)[1].replace(b"\n", b"") for x in open(fa, "rb").read().split(b">")[1:]]
+                comp4 = bytes.maketrans(b"ACGT", b"TGCA")
+                for which, fq in enumerate(fqs):
+                    recs = open(fq, "rb").read().split(b"\n")
+                    for i in range(0, len(recs) - 3, 4):
+                        b = recs[i + 1]
+                        if (i // 4 + which) % 5 < 2 and len(b) > 70:
+                            cut = int(rng.integers(25, len(b) - 25))
+                            sq = seqs[int(rng.integers(0, len(seqs)))]
+                            if len(sq) <= len(b):
+                                continue
+                            p = int(rng.integers(0, len(sq) - len(b)))
+                            alien = sq[p:p + len(b) - cut]
+                            if rng.random() < 0.5:
+                                alien = alien.translate(comp4)[::-1]
+                            recs[i + 1] = (b[:cut] + alien) if rng.random() < 0.5 else (alien + b[len(b) - cut:])
+                    open(fq, "wb").write(b"\n".join(recs))
             if lib != "pe":               # the generator makes FR pairs: turn the mates as the library type expects
                 comp = bytes.maketrans(b"ACGTacgtN", b"TGCAtgcaN")
                 recs = open(fqs[1], "rb").read().split(b"\n")
