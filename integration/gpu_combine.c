@@ -46,8 +46,8 @@ struct CombSlot {
   smaltgpu_mapper *mp; uint32_t cap_reads, cap_len;
   char *bases, *quals; uint64_t *off; size_t basecap;
   /* merged per-read context of a paired round */
-  uint64_t *iv_off; smaltgpu_interval *iv; int32_t *minsw, *prevmax; uint32_t *tot;
-  size_t cap_ivoff, cap_iv, cap_minsw, cap_prevmax, cap_tot;
+  uint64_t *iv_off; smaltgpu_interval *iv; int32_t *minsw, *prevmax; uint32_t *tot, *seedrange;
+  size_t cap_ivoff, cap_iv, cap_minsw, cap_prevmax, cap_tot, cap_seedrange;
 };
 /* ONE queue of pending worker blocks for all devices -- the reference's workers pull blocks from one FIFO (threads.c:548);
  * here whichever device has a free mapper slot takes the next cohort, so a device that got repeat-rich reads does not
@@ -128,6 +128,7 @@ static void run_batch(struct CombSlot *d, const smaltgpu_index *ix, CombReq **re
       if ((c0->iv_off && (grow((void **)&d->iv_off, &d->cap_ivoff, (size_t)ntot + 1, sizeof(uint64_t)) || grow((void **)&d->iv, &d->cap_iv, niv + 1, sizeof(smaltgpu_interval)))) ||
           (c0->minsw && grow((void **)&d->minsw, &d->cap_minsw, (size_t)ntot + 1, sizeof(int32_t))) ||
           (c0->prevmax && grow((void **)&d->prevmax, &d->cap_prevmax, 2 * (size_t)ntot + 2, sizeof(int32_t))) ||
+          (c0->seedrange && grow((void **)&d->seedrange, &d->cap_seedrange, 2 * (size_t)ntot + 2, sizeof(uint32_t))) ||
           (c0->kind == GPUCOMB_TOTALS && grow((void **)&d->tot, &d->cap_tot, (size_t)ntot + 1, sizeof(uint32_t)))) rv = SMALTGPU_ENOMEM;
       else {
         for (i = 0, k = 0, niv = 0; i < nreq; i++) {
@@ -141,13 +142,15 @@ static void run_batch(struct CombSlot *d, const smaltgpu_index *ix, CombReq **re
             }
             if (c->minsw) d->minsw[k] = c->minsw[j];
             if (c->prevmax) { d->prevmax[2 * k] = c->prevmax[2 * j]; d->prevmax[2 * k + 1] = c->prevmax[2 * j + 1]; }
+            if (c->seedrange) { d->seedrange[2 * k] = c->seedrange[2 * j]; d->seedrange[2 * k + 1] = c->seedrange[2 * j + 1]; }
           }
         }
         if (c0->iv_off) { d->iv_off[k] = niv; ctx.iv_off = d->iv_off; ctx.iv = d->iv; }
         if (c0->minsw) ctx.min_swatscor = d->minsw;
         if (c0->prevmax) ctx.prev_max = d->prevmax;
+        if (c0->seedrange) ctx.seed_range = d->seedrange;
         ctx.fine_index = c0->kind == GPUCOMB_FINE;
-        ctx.raw_alignments = c0->kind == GPUCOMB_APPEND || c0->kind == GPUCOMB_FINE;      /* these append to sets that hold alignments: resultSetAppendRaw compares */
+        ctx.raw_alignments = c0->kind == GPUCOMB_APPEND || c0->kind == GPUCOMB_FINE || c0->kind == GPUCOMB_SPLIT;      /* these append to sets that hold alignments: resultSetAppendRaw compares */
         if (c0->kind == GPUCOMB_TOTALS) {
           rv = smaltgpu_hit_totals(d->mp, (const uint8_t *)d->bases, has_qual ? (const uint8_t *)d->quals : NULL, d->off, ntot, reqs[0]->par, d->tot);
           for (i = 0, k = 0; i < nreq && !rv; i++) { memcpy(reqs[i]->ctx->tot_out, d->tot + k, (size_t)reqs[i]->n * sizeof(uint32_t)); k += reqs[i]->n; }

@@ -14,12 +14,13 @@ typedef struct {              /* results of one request, owned by the caller (bu
 /* A request that belongs to one of rmapPair's rounds (integration/rmap_gpu.c: rmapGpuPairBatch) carries the per-read context
  * of include/smaltgpu.h's smaltgpu_callctx, indexed like its reads; only requests of the same kind form a batch. */
 enum { GPUCOMB_PLAIN = 0, GPUCOMB_TOTALS = 1 /* smaltgpu_hit_totals into tot_out */, GPUCOMB_APPEND = 2 /* unrestricted, running maxima */,
-       GPUCOMB_RESTRICTED = 3, GPUCOMB_FINE = 4 };
+       GPUCOMB_RESTRICTED = 3, GPUCOMB_FINE = 4, GPUCOMB_SPLIT = 5 /* as APPEND, k-mer words from a stretch of the read (mapSecondary) */ };
 typedef struct {
   int kind;
   const uint64_t *iv_off; const smaltgpu_interval *iv;     /* RESTRICTED, FINE */
   const int32_t *minsw;                                    /* FINE */
-  const int32_t *prevmax;                                  /* APPEND, FINE */
+  const int32_t *prevmax;                                  /* APPEND, FINE, SPLIT */
+  const uint32_t *seedrange;                               /* SPLIT: (first, last) base per read */
   uint32_t *tot_out;                                       /* TOTALS: n hit totals */
 } GpuCombCtx;
 

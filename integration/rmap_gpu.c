@@ -416,9 +416,19 @@ static int gpuStage(int slot, SeqFastq *const *sq, int ns)
 /* One round: reads sq[0..ns) through the library with the round's per-read context.  By default the rounds of all worker
  * threads meet in the shared queue (gpu_combine.c: requests of the same kind form one batch on a shared mapper);
  * SMALTGPU_NO_COMBINE gives the worker its own mapper.  kind GPUCOMB_TOTALS fills tot_out instead of out. */
+static int gpuPairRoundRange(ErrMsg *errmsgp, int slot, SeqFastq *const *sq, int ns, const smaltgpu_params *par, int kind,
+                             const uint64_t *iv_off, const smaltgpu_interval *iv, const int32_t *minsw, const int32_t *prevmax,
+                             const uint32_t *seedrange, uint32_t *tot_out, smaltgpu_batch_out *out);
 static int gpuPairRound(ErrMsg *errmsgp, int slot, SeqFastq *const *sq, int ns, const smaltgpu_params *par, int kind,
                         const uint64_t *iv_off, const smaltgpu_interval *iv, const int32_t *minsw, const int32_t *prevmax,
                         uint32_t *tot_out, smaltgpu_batch_out *out)
+{
+  return gpuPairRoundRange(errmsgp, slot, sq, ns, par, kind, iv_off, iv, minsw, prevmax, NULL, tot_out, out);
+}
+/* seedrange (kind GPUCOMB_SPLIT): per read the stretch its k-mer words come from */
+static int gpuPairRoundRange(ErrMsg *errmsgp, int slot, SeqFastq *const *sq, int ns, const smaltgpu_params *par, int kind,
+                             const uint64_t *iv_off, const smaltgpu_interval *iv, const int32_t *minsw, const int32_t *prevmax,
+                             const uint32_t *seedrange, uint32_t *tot_out, smaltgpu_batch_out *out)
 {
   int i, has_qual;
   size_t tot = 0;
@@ -430,7 +440,7 @@ static int gpuPairRound(ErrMsg *errmsgp, int slot, SeqFastq *const *sq, int ns, 
     GpuCombCtx cc;
     char emsg[256] = "";
     memset(&cc, 0, sizeof(cc));
-    cc.kind = kind; cc.iv_off = iv_off; cc.iv = iv; cc.minsw = minsw; cc.prevmax = prevmax; cc.tot_out = tot_out;
+    cc.kind = kind; cc.iv_off = iv_off; cc.iv = iv; cc.minsw = minsw; cc.prevmax = prevmax; cc.seedrange = seedrange; cc.tot_out = tot_out;
     const int crv = gpuCombineSubmitCtx(g_ndev, (const smaltgpu_index *const *)g_ixdev, g_map[slot].bases, has_qual ? g_map[slot].quals : NULL, g_map[slot].off,
                                         (uint32_t)ns, par, kind == GPUCOMB_PLAIN ? NULL : &cc, &g_map[slot].comb, emsg, sizeof(emsg));
     if (crv) {
@@ -447,7 +457,8 @@ static int gpuPairRound(ErrMsg *errmsgp, int slot, SeqFastq *const *sq, int ns, 
       smaltgpu_callctx ctx;
       memset(&ctx, 0, sizeof(ctx));
       ctx.iv_off = iv_off; ctx.iv = iv; ctx.min_swatscor = minsw; ctx.prev_max = prevmax; ctx.fine_index = kind == GPUCOMB_FINE;
-      ctx.raw_alignments = kind == GPUCOMB_APPEND || kind == GPUCOMB_FINE;
+      ctx.raw_alignments = kind == GPUCOMB_APPEND || kind == GPUCOMB_FINE || kind == GPUCOMB_SPLIT;
+      ctx.seed_range = seedrange;
       rv = smaltgpu_map_batch_ctx(g_map[slot].mp, (const uint8_t *)g_map[slot].bases, has_qual ? (const uint8_t *)g_map[slot].quals : NULL,
                                   g_map[slot].off, (uint32_t)ns, par, &ctx, out);
       if (SMALTGPU_IS_READ_ERROR(rv) && out->nreads == (uint32_t)ns) rv = 0;      /* gpuPairTake reports the read */
@@ -482,7 +493,8 @@ int rmapGpuPairBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, SeqFast
 {
   int i, slot, ns, errcode = ERRCODE_SUCCESS;
   uint32_t rlen, *tot = NULL;
-  const UCHAR ktup = hashTableGetKtupLen(htp, NULL);
+  UCHAR nskip = 0;
+  const UCHAR ktup = hashTableGetKtupLen(htp, &nskip);
   short mismatchscor, gapinitscor, gapextscor, matchscor;
   smaltgpu_params par;
   smaltgpu_batch_out o;
@@ -664,6 +676,36 @@ int rmapGpuPairBatch(ErrMsg *errmsgp, RMap *rmp, SeqFastq *const *reads, SeqFast
       if ((errcode = gpuPairRound(errmsgp, slot, rsq, nd, &par, GPUCOMB_FINE, iv_off, iv, minsw, prevmax, NULL, &o))) return errcode;
       for (i = 0; i < nd; i++) if ((errcode = gpuPairTake(errmsgp, rmp, pairs + sel[i], which[i], &o, i, max_depth, scormtxp, ssp, codecp))) return errcode;
     }
+  }
+  /* ---- split reads (rmap.c:2073-2097): mapSecondary for the read, then for the mate, of every pair -- k-mer words from the stretch
+   *      the best alignment of the first read segment leaves uncovered (rmap.c:1459-1481), appended to the mate's set ---- */
+  if (rmapflg & RMAPFLG_SPLIT) {
+    uint32_t *stretch = malloc((size_t)2 * n * sizeof(uint32_t) + 8);
+    int w;
+    if (!stretch) ERRMSGNO(errmsgp, ERRCODE_NOMEM);
+    for (w = 0; w < 2; w++) {
+      for (i = 0, ns = 0; i < n; i++) {
+        GpuPair *pp = pairs + i;
+        const Result *rp;
+        SEQLEN_t qs, qe, qlen;
+        if (pp->skip || pp->on_cpu) continue;
+        if (resultSetGetResultInSegment(&rp, 0, 0, pp->rs[w]) != ERRCODE_SUCCESS) continue;      /* nothing aligned: mapSecondary keeps silent */
+        if (resultGetData(&qs, &qe, NULL, NULL, NULL, NULL, NULL, rp)) continue;
+        (void)seqFastqGetConstSequence(pp->sq[w], &qlen, NULL);
+        if (qe > qlen || qs > qe) { free(stretch); ERRMSGNO(errmsgp, ERRCODE_ASSERT); }
+        if (qs + qe > qlen) { qe = (qs > 1) ? qs - 2 : 0; qs = 0; } else { qs = qe; qe = qlen - 1; }
+        if (qs + ktup + nskip > qe + 1 || qlen < ktup) continue;
+        sel[ns] = i; which[ns] = (unsigned char)w;
+        stretch[2 * ns] = qs; stretch[2 * ns + 1] = qe;
+        prevmax[2 * ns] = resultSetGetMaxSwat(pp->rs[w], &prevmax[2 * ns + 1]);
+        ns++;
+      }
+      if (!ns) continue;
+      for (i = 0; i < ns; i++) rsq[i] = pairs[sel[i]].sq[which[i]];
+      if ((errcode = gpuPairRoundRange(errmsgp, slot, rsq, ns, &par, GPUCOMB_SPLIT, NULL, NULL, NULL, prevmax, stretch, NULL, &o))) { free(stretch); return errcode; }
+      for (i = 0; i < ns; i++) if ((errcode = gpuPairTake(errmsgp, rmp, pairs + sel[i], which[i], &o, i, max_depth, scormtxp, ssp, codecp))) { free(stretch); return errcode; }
+    }
+    free(stretch);
   }
   g_map[slot].npairs = n;
   free(sel); free(which); free(tot); free(iv_off); free(iv); free(minsw); free(prevmax); free(all); free(rsq);

@@ -4,7 +4,7 @@
  * smalt.c registers it with the thread pool, by a version that sends the whole block through the GPU path in one batch
  * (integration/rmap_gpu.c: rmapGpuBatch) and then runs the reference's own per-read tail -- post-processing and report
  * (smalt.c:1172-1185) -- read by read.  A block of read PAIRS goes through rmapPair's rounds on the GPU (rmapGpuPairBatch),
- * pairing and report pair by pair.  Complexity weighting (-w) and split reads of pairs (-p with two read files) keep the reference's own worker. */
+ * pairing and report pair by pair.  Complexity weighting (-w) keeps the reference's own worker. */
 #include "threads.h"
 static int smaltgpu_threadsSetTask(uint8_t task_typ, short n_threads, THREAD_INITF *initf, const void *initargp, THREAD_PROCF *procf,
                                    THREAD_CLEANF *cleanf, THREAD_CHECKF *checkf, THREAD_CMPF *cmpf, size_t argsz);
@@ -41,8 +41,8 @@ static int processArgBlockGpu(ErrMsg *errmsgp,
 
   n = blockp->n_iobf;
   if (n < 1) return ERRCODE_SUCCESS;
-  /* not on the GPU path: complexity weighting, and split reads of PAIRS (rmap.c:2073); split single reads: rmapGpuBatch -> smaltgpu_map_split */
-  if ((macop->rmapflg & RMAPFLG_CMPLXW) || macop->tupcovmin < 0 || ((macop->rmapflg & RMAPFLG_SPLIT) && blockp->iobfp[0].isPaired))
+  /* not on the GPU path: complexity weighting (split reads: rmapGpuBatch -> smaltgpu_map_split, pairs: a round of second calls in rmapGpuPairBatch) */
+  if ((macop->rmapflg & RMAPFLG_CMPLXW) || macop->tupcovmin < 0)
     return processArgBlock(errmsgp,
 #ifdef THREADS_DEBUG
                            readno,

@@ -335,3 +335,16 @@ def test_smaltgpu_map_prints_what_smalt_map_prints_for_split_read_pairs(k, s, nc
         b = [ln for ln in open(out_gpu).read().split("\n") if not ln.startswith("@PG")]
         diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
         assert not diff and len(a) == len(b), (len(a), len(b), diff[:3])
+    # the reference's own program bound to the library: the second calls are one more round of rmapGpuPairBatch (integration/rmap_gpu.c)
+    if os.path.exists(SMALT_GPU):
+        env = dict(os.environ, SMALTGPU_INDEX_PREFIX=pre)
+        for extra, more in (([], {}), (["-n", "3", "-O"], {"SMALTGPU_BLOCK_READS": "256"}), ([], {"SMALTGPU_NO_COMBINE": "1"})):
+            if extra and opts[opts.index("-r") + 1] != "-1":
+                continue                          # worker threads share one random generator: only without draws
+            r = subprocess.run([SMALT_GPU, "map", "-p"] + opts + extra + ["-o", out_gpu, pre] + fqs, capture_output=True, env=dict(env, **more))
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            b = [ln for ln in open(out_gpu).read().split("\n") if not ln.startswith("@PG")]
+            diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
+            assert not diff and len(a) == len(b), ("bound program", extra, more, len(a), len(b), diff[:3])
+        env.pop("SMALTGPU_INDEX_PREFIX")           # ... through the library: without the index prefix the bound program cannot map
+        assert subprocess.run([SMALT_GPU, "map", "-p"] + opts + ["-o", out_gpu, pre] + fqs, capture_output=True, env=env).returncode != 0
