@@ -1241,9 +1241,11 @@ __device__ inline int band_track_rows(const Band &bp, PW q, PW win, int match, i
   return best;
 }
 
-// The traceback of traceback_scalar (row-major directions) run by the whole wave in lock step: every value it walks
-// on is the same in all lanes and is handed to the scalar unit (readfirstlane), so the walk costs a few vector
-// instructions per step (the loads) instead of forty on a single lane; the alignment string is written by lane 0.
+// The traceback of traceback_scalar (row-major directions) run by the whole wave: the walk's state is the same in all lanes and
+// lives on the scalar unit (readfirstlane); the alignment string is written by lane 0.  A stretch of diagonal steps is taken in
+// ONE round: lane k looks at the cell k steps up the diagonal (its direction byte, reference and read base), a ballot finds where
+// the stretch ends and where it holds non-matches, and the string operations of the whole stretch are put together from those two
+// masks -- an alignment of a 150-base read with three mismatches takes about eight rounds instead of 150 dependent steps.
 __device__ inline int traceback_uniform(uint8_t *ds, uint32_t dscap, int *qs, int *rs, const Band &bp, const uint8_t *dir,
                                         int max_i, int max_j, int max_scor, const uint8_t *q, const uint8_t *win,
                                         int tb_match, int tb_mismatch, int gi, int ge) {
@@ -1254,34 +1256,50 @@ __device__ inline int traceback_uniform(uint8_t *ds, uint32_t dscap, int *qs, in
   int n = 0, checksum = 0, nmatch = 0, rv = 0;
   bool gap_open = false;
   const bool writer = threadIdx.x == 0;
-  const int cap = (int)dscap;
-#define SMG_PUTU(cnt, typ) { if (n + 2 >= cap) { rv = -2; break; } if (writer) ds[n] = (uint8_t)((cnt) + ((typ) << DIFF_TYPSHIFT)); n++; }
-  do {
-    while (i >= s_left && j >= q_left) {
-      const uint8_t dv = dir[off], wv = win[i], qv = q[j];     // three independent loads, one wait
+  const int cap = (int)dscap, lane = (int)threadIdx.x;
+  // (on overflow the walk goes on without writing: the caller only sees the code)
+#define SMG_PUTU(cnt, typ) { if (n + 2 >= cap) rv = -2; else { if (writer) ds[n] = (uint8_t)((cnt) + ((typ) << DIFF_TYPSHIFT)); n++; } }
+  while (i >= s_left && j >= q_left && !rv) {
+    const int room = (i - s_left < j - q_left ? i - s_left : j - q_left) + 1;       // cells up this diagonal inside the matrix
+    const bool in = lane < room;
+    uint8_t dv = 0, wv = 0, qv = 0;
+    if (in) { dv = dir[off - lane * bw]; wv = win[i - lane]; qv = q[j - lane]; }
+    const unsigned long long off_dia = __ballot(!in || dv != (uint8_t)DIR_DIA);
+    const int run = off_dia ? (int)__builtin_ctzll(off_dia) : 64;
+    if (run == 0) {                                    // the cell itself: a gap step, or the end of the path
       const int d = SMG_U(dv);
       if (!d) break;
-      if (d == (int)DIR_DIA) {
-        const int rbc = SMG_U(wv) & 7, qcc = SMG_U(qv) & 7;
-        const int sc = (rbc >= 4 || qcc >= 4) ? 0 : (rbc == qcc ? tb_match : tb_mismatch);
-        if (sc > 0) {
-          if (nmatch > (int)DIFF_MAXMISMATCH) { SMG_PUTU(DIFF_MAXMISMATCH, DIFF_M) nmatch -= DIFF_MAXMISMATCH; }
-          else nmatch++;
-        } else { SMG_PUTU(nmatch, DIFF_S) nmatch = 0; }
-        checksum += sc;
-        gap_open = false;
-        off -= bw; i--; j--;
-        continue;
-      }
       if (gap_open) checksum -= ge; else { checksum -= gi; gap_open = true; }
       if (d & (int)DIR_COL) { SMG_PUTU(nmatch, DIFF_D) nmatch = 0; off -= bw - 1; i--; continue; }
       if (!(d & (int)DIR_ROW)) { rv = -1; break; }
       SMG_PUTU(nmatch, DIFF_I) nmatch = 0; off--; j--;
+      continue;
     }
-    if (rv) break;
-    SMG_PUTU(nmatch, DIFF_S)
-    SMG_PUTU(0, DIFF_M)
-  } while (0);
+    const int rbc = wv & 7, qcc = qv & 7;
+    const int sc = (rbc >= 4 || qcc >= 4) ? 0 : (rbc == qcc ? tb_match : tb_mismatch);
+    const unsigned long long inrun = run == 64 ? ~0ull : ((1ull << run) - 1ull);
+    unsigned long long stops = __ballot(sc <= 0) & inrun;            // steps that close a run of matches (substitution or a code without score)
+    const unsigned long long minus = __ballot(sc < 0) & inrun;
+    checksum += (run - (int)__builtin_popcountll(stops)) * tb_match + (int)__builtin_popcountll(minus) * tb_mismatch;
+    int pos = 0;
+    for (;;) {
+      const int nxt = stops ? (int)__builtin_ctzll(stops) : run;
+      int m = nxt - pos;                               // matching steps up to the next stop: the counter saturates as in the step-by-step walk
+      while (m > 0) {
+        const int space = (int)DIFF_MAXMISMATCH + 1 - nmatch;
+        if (m <= space) { nmatch += m; m = 0; }
+        else { m -= space + 1; SMG_PUTU(DIFF_MAXMISMATCH, DIFF_M) nmatch = 1; }
+      }
+      if (nxt == run) break;
+      SMG_PUTU(nmatch, DIFF_S) nmatch = 0;
+      stops &= stops - 1ull;
+      pos = nxt + 1;
+    }
+    gap_open = false;
+    off -= run * bw; i -= run; j -= run;
+  }
+  if (!rv) { SMG_PUTU(nmatch, DIFF_S) }
+  if (!rv) { SMG_PUTU(0, DIFF_M) }
 #undef SMG_PUTU
 #undef SMG_U
   if (rv) return rv;
