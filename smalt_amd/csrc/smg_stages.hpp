@@ -1180,18 +1180,30 @@ __device__ inline int band_track_wave(const Band &bp, PW q, PW win, int match, i
 // per row (16 VALU for the scan) instead of two anti-diagonal steps with half the lanes idle: 2.4 x fewer instructions
 // per band cell than band_track_wave.  Results (scores, direction bytes, first maximum) are those of band_track_wave.
 // exclusive prefix maximum over the wave; INT_MIN is the identity, so the DPP moves fold into the v_max instructions
+// LANES: how many lanes can hold a live value (16, 32 or 64): a band of up to 16 diagonals needs no step across DPP rows
+template <int LANES = 64>
 __device__ inline int dpp_scan_max_excl(int x) {
   const int neg = (int)0x80000000;
   x = max(x, __builtin_amdgcn_update_dpp(neg, x, 0x111 /* row_shr:1 */, 0xf, 0xf, false));
   x = max(x, __builtin_amdgcn_update_dpp(neg, x, 0x112 /* row_shr:2 */, 0xf, 0xf, false));
   x = max(x, __builtin_amdgcn_update_dpp(neg, x, 0x114 /* row_shr:4 */, 0xf, 0xf, false));
   x = max(x, __builtin_amdgcn_update_dpp(neg, x, 0x118 /* row_shr:8 */, 0xf, 0xf, false));
-  x = max(x, __builtin_amdgcn_update_dpp(neg, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false));
-  x = max(x, __builtin_amdgcn_update_dpp(neg, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
+  if (LANES > 16) x = max(x, __builtin_amdgcn_update_dpp(neg, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false));
+  if (LANES > 32) x = max(x, __builtin_amdgcn_update_dpp(neg, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
   return __builtin_amdgcn_update_dpp(neg, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
+template <class PW, class PD, int LANES>
+__device__ inline int band_track_rows_n(const Band &bp, PW q, PW win, int match, int mismatch, int gi, int ge, PD dir, int *max_i, int *max_j);
 template <class PW = const uint8_t *, class PD = uint8_t *>
 __device__ inline int band_track_rows(const Band &bp, PW q, PW win, int match, int mismatch, int gi, int ge,
+                                      PD dir, int *max_i, int *max_j) {
+  const int bw = __builtin_amdgcn_readfirstlane(bp.band_width);        // (wave-uniform: one instance of the row loop runs)
+  if (bw <= 16) return band_track_rows_n<PW, PD, 16>(bp, q, win, match, mismatch, gi, ge, dir, max_i, max_j);
+  if (bw <= 32) return band_track_rows_n<PW, PD, 32>(bp, q, win, match, mismatch, gi, ge, dir, max_i, max_j);
+  return band_track_rows_n<PW, PD, 64>(bp, q, win, match, mismatch, gi, ge, dir, max_i, max_j);
+}
+template <class PW, class PD, int LANES>
+__device__ inline int band_track_rows_n(const Band &bp, PW q, PW win, int match, int mismatch, int gi, int ge,
                                       PD dir, int *max_i, int *max_j) {
   const int lane = (int)threadIdx.x;
   const int nrows = __builtin_amdgcn_readfirstlane(bp.s_len - bp.s_left), l = bp.l_edge, bw = bp.band_width;
@@ -1201,17 +1213,18 @@ __device__ inline int band_track_rows(const Band &bp, PW q, PW win, int match, i
   const int gel = ge * lane - gi, gel1 = ge * (lane - 1);
   int Hd = 0, Eown = 0;
   int best = 0, bi = 0, bj = 0;
-  // codes of the next row are loaded a row ahead (the read offset clamped into the read: inactive cells do not use it)
-  int rbn = win[bp.s_left] & 7;
+  // the read code of the next row is loaded a row ahead (the read offset clamped into the read: inactive cells do not use it); the
+  // reference codes of 64 rows sit in one register, lane r holding row (ip & ~63) + r, and reach the row's cells by v_readlane
+  int wrow = 0;
   int qn = q[d < 0 ? 0 : (d > qhi ? qhi : d)] & 7;
   PD dp = dir + lane;
   for (int ip = 0; ip < nrows; ip++, dp += bw) {
     const int j = d + ip;
     const bool act = inband && j >= bp.q_left && j <= qhi;
-    const int rb = rbn, qc = qn;
+    if (!(ip & 63)) { const int r = ip + lane; wrow = win[bp.s_left + (r < nrows ? r : nrows - 1)] & 7; }
+    const int rb = __builtin_amdgcn_readlane(wrow, ip & 63), qc = qn;
     {
-      const int jn = j + 1, in = ip + 1 < nrows ? ip + 1 : ip;
-      rbn = win[bp.s_left + in] & 7;
+      const int jn = j + 1;
       qn = q[jn < 0 ? 0 : (jn > qhi ? qhi : jn)] & 7;
     }
     const int Ein = __builtin_amdgcn_update_dpp(0, Eown, 0x130 /* wave_shl:1: the lane above */, 0xf, 0xf, false);
@@ -1219,7 +1232,7 @@ __device__ inline int band_track_rows(const Band &bp, PW q, PW win, int match, i
     const int Hin = Hd + w;
     const int e = Ein > 0 ? Ein : 0;
     const int src = (act && Hin > e && Hin > gi) ? Hin + gel : (int)0x80000000;
-    int px = dpp_scan_max_excl(src);
+    int px = dpp_scan_max_excl<LANES>(src);
     px = px > NEG ? px : NEG;
     int F = px - gel1;
     F = F > 0 ? F : 0;
