@@ -569,6 +569,8 @@ def main():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if os.environ.get("SMALT_BENCH_DRYRUN"):   # tests/test_shard_gloo.py: launcher, rendezvous and the shared cursor without a device
         dealer = shard.BatchDealer(23, static=args.static_shards)
+        if world > 1:
+            dist.barrier()                              # as ahead of the timed region of the real run: no rank deals before all are there
         dealer.start("dry")
         got = []
         while True:
@@ -576,6 +578,7 @@ def main():
             if j is None:
                 break
             got.append(j)
+            time.sleep(0.003)                           # a sub-batch takes time: the other ranks get their turn
         parts = shard.gather_in_rank_order(got)
         # ... and the guided dealing of the N > 1 job: every read of a 1 000 003-read job exactly once, pieces of 4096 .. 65536
         dealer2 = shard.BatchDealer(1, static=args.static_shards)
