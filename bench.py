@@ -670,6 +670,8 @@ def main():
         print("[bench] setup: reference+index %.1f s (index construction on the device %.1f ms), reads %.1f s" % (t_idx, build_ms, setup_s - t_idx), file=sys.stderr, flush=True)
 
     par = gix.default_params()
+    if os.environ.get("SMALT_BENCH_EXHAUSTIVE"):      # diagnostic, not the BASELINE metric: `smalt map -x` (every seed, deeper candidate lists)
+        par.rmapflg |= api.FLG_NOSHRTINFO | api.FLG_SENSITIVE
     sub = min(args.sub_batch, per_gpu)
     os.environ.setdefault("SMALTGPU_CANDS_PER_READ", "768")
     mappers = [api.Mapper(gix, sub, args.read_len) for _ in range(max(1, args.streams))]

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--native-repeat", type=int, default=1, help="single-end: run smaltgpu-map this many times on the large file (run-to-run spread)")
     ap.add_argument("--native-gap", type=float, default=0.0, help="seconds to wait before each smaltgpu-map run (the driver clears freed device memory in the background)")
+    ap.add_argument("--extra", default="", help="more options for all three programs, e.g. --extra=-p (split reads) or --extra='-x -c 0.3'")
     ap.add_argument("--paired", action="store_true", help="BASELINE configs[2]: read PAIRS (FR, fragments N(300,30), -i 500); --reads counts pairs, rates are pairs/s")
     a = ap.parse_args()
     import torch
@@ -84,7 +85,7 @@ def main():
         def run(binary, nthr, fq, out, env=None):
             t = time.time()
             inputs = [fq, fq + ".mates"] if a.paired else [fq]
-            r = subprocess.run([binary, "map", "-n", str(nthr), "-O", "-r", "-1", "-f", "cigar"] + (["-i", "500"] if a.paired else []) + ["-o", out, prefix] + inputs,
+            r = subprocess.run([binary, "map"] + a.extra.split() + ["-n", str(nthr), "-O", "-r", "-1", "-f", "cigar"] + (["-i", "500"] if a.paired else []) + ["-o", out, prefix] + inputs,
                                capture_output=True, env=env)
             if r.returncode:
                 keep_failure(binary, nthr, r)
@@ -110,8 +111,8 @@ def main():
         if a.paired:
             # the same job by smaltgpu-map on the two files: libsmaltgpu only (ingest, rmapPair's rounds, pairing, report)
             prog = os.path.join(ROOT, "smalt_amd", "smaltgpu-map")
-            subprocess.run([prog, "-r", "-1", "-i", "500", "-f", "cigar", "-n", str(a.threads), "-o", os.path.join(tmp, "n0.cig"), prefix, small, small + ".mates"], capture_output=True)
-            r = subprocess.run([prog, "-r", "-1", "-i", "500", "-f", "cigar", "-n", str(a.threads), "-o", os.path.join(tmp, "n1.cig"), prefix, gpu_fq, gpu_fq + ".mates"],
+            subprocess.run([prog] + a.extra.split() + ["-r", "-1", "-i", "500", "-f", "cigar", "-n", str(a.threads), "-o", os.path.join(tmp, "n0.cig"), prefix, small, small + ".mates"], capture_output=True)
+            r = subprocess.run([prog] + a.extra.split() + ["-r", "-1", "-i", "500", "-f", "cigar", "-n", str(a.threads), "-o", os.path.join(tmp, "n1.cig"), prefix, gpu_fq, gpu_fq + ".mates"],
                                capture_output=True, env=dict(os.environ, SMALTGPU_MAP_VERBOSE="1"))
             if r.returncode:
                 keep_failure(prog, a.threads, r)
@@ -127,12 +128,12 @@ def main():
             prog = os.path.join(ROOT, "smalt_amd", "smaltgpu-map")
             # once on the small file first: the first large device allocations after this script freed its 3 Gbp arrays are slow
             # (2 s per mapper, against 15 ms in a run of the program on its own: tools/run_native.sh)
-            subprocess.run([prog, "-r", "-1", "-f", "cigar", "-n", str(a.threads), "-o", os.path.join(tmp, "n0.cig"), prefix, small], capture_output=True)
+            subprocess.run([prog] + a.extra.split() + ["-r", "-1", "-f", "cigar", "-n", str(a.threads), "-o", os.path.join(tmp, "n0.cig"), prefix, small], capture_output=True)
             runs = []
             for rep in range(max(1, a.native_repeat)):
                 if a.native_gap > 0:
                     time.sleep(a.native_gap)
-                r = subprocess.run([prog, "-r", "-1", "-f", "cigar", "-n", str(a.threads), "-o", os.path.join(tmp, "n1.cig"), prefix, gpu_fq], capture_output=True,
+                r = subprocess.run([prog] + a.extra.split() + ["-r", "-1", "-f", "cigar", "-n", str(a.threads), "-o", os.path.join(tmp, "n1.cig"), prefix, gpu_fq], capture_output=True,
                                    env=dict(os.environ, SMALTGPU_MAP_VERBOSE="1"))
                 if r.returncode:
                     keep_failure(prog, a.threads, r)
@@ -151,7 +152,7 @@ def main():
         identical = c[:ncmp] == g[:ncmp]
         cpu_rate = (a.cpu_reads - nsmall) / max(t_c1 - t_c0, 1e-6)
         gpu_rate = (a.reads - nsmall) / max(t_g1 - t_g0, 1e-6)
-        print(json.dumps({"what": "whole program `smalt map`, %s/s with the index load removed" % ("read pairs" if a.paired else "reads"), "paired": a.paired, "threads_cpu": a.threads, "threads_gpu_bound": gthreads,
+        print(json.dumps({"what": "whole program `smalt map`, %s/s with the index load removed" % ("read pairs" if a.paired else "reads"), "paired": a.paired, "extra_options": a.extra, "threads_cpu": a.threads, "threads_gpu_bound": gthreads,
                           "cpu_reads_per_s": cpu_rate, "gpu_bound_reads_per_s": gpu_rate, "speedup": gpu_rate / cpu_rate,
                           # the binding's own clock from "index resident" to exit (FASTQ input, mapping, output): free of the start-up noise
                           # that the difference of two program runs above carries
