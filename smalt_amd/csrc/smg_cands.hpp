@@ -178,7 +178,8 @@ SMG_HD inline int strand_cands(StrandWork<IT> &w, uint32_t n, bool is_reverse, b
     if (n <= 256) wave_sort_u64_reg<4>(w.dat, n);       // few hits of a restricted call: ten round trips to HBM with the network in memory)
     else if (n <= 512) wave_sort_u64_reg<8>(w.dat, n);
     else wave_sort_u64_reg<16>(w.dat, n);
-  } else wave_sort_u64(w.dat, n);
+  } else if (!StrandWork<IT>::L) wave_sort_u64_chunked(w.dat, n);                  // longer runs in HBM (exhaustive search): chunks of 1024 keys in registers
+  else wave_sort_u64(w.dat, n);
 #else
   wave_sort_u64(w.dat, n);
 #endif

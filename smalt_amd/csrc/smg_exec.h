@@ -242,6 +242,111 @@ __device__ inline void wave_sort_u64_reg(P a, uint32_t n) {
   for (int r = 0; r < E; r++) { const uint32_t i = (uint32_t)E * lane + (uint32_t)r; if (i < n) a[i] = v[r]; }
   __syncthreads();
 }
+
+// Runs of more than 1024 keys in HBM (the exhaustive search: every seed of a strand in a repeat): wave_sort_u64 over global
+// memory pays a round trip per stage -- 105 of them for 16 384 keys.  Here every chunk of 1024 keys is sorted in registers, and of
+// the later merges only the comparators that span chunks run in memory (the mirror step and the half-cleaners with j >= 1024);
+// the rest of each merge, j = 512 .. 1, stays inside a chunk and runs in registers again: about ten passes over the memory
+// and five register passes per chunk for 16 384 keys.  Same network, same +inf convention for the keys beyond n.
+template <bool MERGE, class P>
+__device__ inline void sort_chunk_1024(P a, uint32_t base, uint32_t n) {
+  constexpr int E = 16;
+  const uint32_t lane = threadIdx.x;
+  uint64_t v[E];
+#pragma unroll
+  for (int r = 0; r < E; r++) { const uint32_t idx = base + (uint32_t)E * lane + (uint32_t)r; v[r] = idx < n ? a[idx] : ~0ull; }
+#pragma unroll
+  for (int k = MERGE ? 2048 : 2; k <= (MERGE ? 2048 : 1024); k <<= 1) {
+    if (!MERGE) {
+      if (k <= E) {
+#pragma unroll
+        for (int r = 0; r < E; r++) {
+          const int q = r ^ (k - 1);
+          if (r < q) { const uint64_t x = v[r], y = v[q]; const bool sw = x > y; v[r] = sw ? y : x; v[q] = sw ? x : y; }
+        }
+      } else {
+        const int m = k / E - 1;
+        const bool lower = (lane & (uint32_t)(k / (2 * E))) == 0;
+        uint64_t pv[E];
+#pragma unroll
+        for (int r = 0; r < E; r++) pv[r] = shfl_xor_u64(v[E - 1 - r], m);
+#pragma unroll
+        for (int r = 0; r < E; r++) { const bool take = lower ? (pv[r] < v[r]) : (pv[r] > v[r]); v[r] = take ? pv[r] : v[r]; }
+      }
+    }
+#pragma unroll
+    for (int j = k / 4; j >= 1; j >>= 1) {
+      if (j < E) {
+#pragma unroll
+        for (int r = 0; r < E; r++) {
+          if (!(r & j)) { const uint64_t x = v[r], y = v[r | j]; const bool sw = x > y; v[r] = sw ? y : x; v[r | j] = sw ? x : y; }
+        }
+      } else {
+        const int m = j / E;
+        const bool lower = (lane & (uint32_t)m) == 0;
+#pragma unroll
+        for (int r = 0; r < E; r++) { const uint64_t o = shfl_xor_u64(v[r], m); const bool take = lower ? (o < v[r]) : (o > v[r]); v[r] = take ? o : v[r]; }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < E; r++) { const uint32_t idx = base + (uint32_t)E * lane + (uint32_t)r; if (idx < n) a[idx] = v[r]; }
+}
+
+template <class P>
+__device__ __noinline__ void wave_sort_u64_chunked(P a, uint32_t n) {
+  constexpr uint32_t C = 1024;
+  for (uint32_t base = 0; base < n; base += C) sort_chunk_1024<false>(a, base, n);
+  __threadfence_block();
+  __syncthreads();
+  uint32_t np = C;
+  while (np < n) np <<= 1;
+  for (uint32_t k = 2 * C; k <= np; k <<= 1) {
+    const uint32_t h = k >> 1;
+    {                                                           // mirror step (pairs i with its mirror image in the block of k)
+      const uint32_t tmax = (n / k) * h + ((n % k) < h ? (n % k) : h);
+      for (uint32_t t0 = 0; t0 < tmax; t0 += 4 * SMG_NLANES) {
+        uint32_t ii[4], pp[4];
+        uint64_t x[4], y[4];
+        bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t t = t0 + (uint32_t)u * SMG_NLANES + SMG_LANE;
+          const uint32_t blk = t / h, off = t % h;
+          ii[u] = blk * k + off; pp[u] = blk * k + (k - 1 - off);
+          on[u] = t < tmax && pp[u] < n;
+          if (on[u]) { x[u] = a[ii[u]]; y[u] = a[pp[u]]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (on[u] && x[u] > y[u]) { a[ii[u]] = y[u]; a[pp[u]] = x[u]; }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    for (uint32_t j = h >> 1; j >= C; j >>= 1) {                // half-cleaners that span chunks
+      const uint32_t tmax = (n / (2 * j)) * j + ((n % (2 * j)) < j ? (n % (2 * j)) : j);
+      for (uint32_t t0 = 0; t0 < tmax; t0 += 4 * SMG_NLANES) {
+        uint32_t ii[4];
+        uint64_t x[4], y[4];
+        bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t t = t0 + (uint32_t)u * SMG_NLANES + SMG_LANE;
+          ii[u] = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          on[u] = t < tmax && (ii[u] | j) < n;
+          if (on[u]) { x[u] = a[ii[u]]; y[u] = a[ii[u] | j]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (on[u] && x[u] > y[u]) { a[ii[u]] = y[u]; a[ii[u] | j] = x[u]; }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    for (uint32_t base = 0; base < n; base += C) sort_chunk_1024<true>(a, base, n);      // j = 512 .. 1 inside the chunks
+    __threadfence_block();
+    __syncthreads();
+  }
+}
 #endif
 
 }  // namespace smg
