@@ -248,31 +248,50 @@ __device__ inline void wave_sort_u64_reg(P a, uint32_t n) {
 // the later merges only the comparators that span chunks run in memory (the mirror step and the half-cleaners with j >= 1024);
 // the rest of each merge, j = 512 .. 1, stays inside a chunk and runs in registers again: about ten passes over the memory
 // and five register passes per chunk for 16 384 keys.  Same network, same +inf convention for the keys beyond n.
+// MERGE = false: the chunk's keys in any order -> sorted (the full network; loads in the order that coalesces, lane l ends up
+// with the logical elements 16 l .. 16 l + 15).  MERGE = true: only the half-cleaners j = 512 .. 1 of a larger merge; here register
+// r of lane l holds element 64 r + l, so that loads and stores coalesce: j >= 64 pairs registers of one lane, j < 64 lanes.
 template <bool MERGE, class P>
 __device__ inline void sort_chunk_1024(P a, uint32_t base, uint32_t n) {
   constexpr int E = 16;
   const uint32_t lane = threadIdx.x;
   uint64_t v[E];
 #pragma unroll
-  for (int r = 0; r < E; r++) { const uint32_t idx = base + (uint32_t)E * lane + (uint32_t)r; v[r] = idx < n ? a[idx] : ~0ull; }
+  for (int r = 0; r < E; r++) { const uint32_t idx = base + (uint32_t)r * 64u + lane; v[r] = idx < n ? a[idx] : ~0ull; }
+  if (MERGE) {
 #pragma unroll
-  for (int k = MERGE ? 2048 : 2; k <= (MERGE ? 2048 : 1024); k <<= 1) {
-    if (!MERGE) {
-      if (k <= E) {
+    for (int j = 512; j >= 64; j >>= 1) {
 #pragma unroll
-        for (int r = 0; r < E; r++) {
-          const int q = r ^ (k - 1);
-          if (r < q) { const uint64_t x = v[r], y = v[q]; const bool sw = x > y; v[r] = sw ? y : x; v[q] = sw ? x : y; }
-        }
-      } else {
-        const int m = k / E - 1;
-        const bool lower = (lane & (uint32_t)(k / (2 * E))) == 0;
-        uint64_t pv[E];
-#pragma unroll
-        for (int r = 0; r < E; r++) pv[r] = shfl_xor_u64(v[E - 1 - r], m);
-#pragma unroll
-        for (int r = 0; r < E; r++) { const bool take = lower ? (pv[r] < v[r]) : (pv[r] > v[r]); v[r] = take ? pv[r] : v[r]; }
+      for (int r = 0; r < E; r++) {
+        if (!(r & (j / 64))) { const uint64_t x = v[r], y = v[r | (j / 64)]; const bool sw = x > y; v[r] = sw ? y : x; v[r | (j / 64)] = sw ? x : y; }
       }
+    }
+#pragma unroll
+    for (int j = 32; j >= 1; j >>= 1) {
+      const bool lower = (lane & (uint32_t)j) == 0;
+#pragma unroll
+      for (int r = 0; r < E; r++) { const uint64_t o = shfl_xor_u64(v[r], j); const bool take = lower ? (o < v[r]) : (o > v[r]); v[r] = take ? o : v[r]; }
+    }
+#pragma unroll
+    for (int r = 0; r < E; r++) { const uint32_t idx = base + (uint32_t)r * 64u + lane; if (idx < n) a[idx] = v[r]; }
+    return;
+  }
+#pragma unroll
+  for (int k = 2; k <= 1024; k <<= 1) {
+    if (k <= E) {
+#pragma unroll
+      for (int r = 0; r < E; r++) {
+        const int q = r ^ (k - 1);
+        if (r < q) { const uint64_t x = v[r], y = v[q]; const bool sw = x > y; v[r] = sw ? y : x; v[q] = sw ? x : y; }
+      }
+    } else {
+      const int m = k / E - 1;
+      const bool lower = (lane & (uint32_t)(k / (2 * E))) == 0;
+      uint64_t pv[E];
+#pragma unroll
+      for (int r = 0; r < E; r++) pv[r] = shfl_xor_u64(v[E - 1 - r], m);
+#pragma unroll
+      for (int r = 0; r < E; r++) { const bool take = lower ? (pv[r] < v[r]) : (pv[r] > v[r]); v[r] = take ? pv[r] : v[r]; }
     }
 #pragma unroll
     for (int j = k / 4; j >= 1; j >>= 1) {
