@@ -84,7 +84,7 @@ class ReportOpts(C.Structure):         # smaltgpu_report_opts
 
 FMT_CIGAR, FMT_SAM, FMT_SSAHA = 0, 1, 2
 REP_SOFTCLIP, REP_HEADER, REP_XMISMATCH = 0x02, 0x04, 0x08
-OUT_BEST, OUT_SINGLE, OUT_RANDSEL = 0x01, 0x02, 0x08
+OUT_BEST, OUT_SINGLE, OUT_SPLIT, OUT_RANDSEL = 0x01, 0x02, 0x04, 0x08
 
 
 class PairOpts(C.Structure):           # smaltgpu_pair_opts

@@ -3,7 +3,8 @@
 does with them under RMAPFLG_SPLIT (`smalt map -p`) -- `oracle/_ref/refdump -s -p -n`: one block per mapSingleRead call (the read's
 own call, then mapSecondary's with k-mer words from the stretch the best alignment leaves uncovered, rmap.c:1435-1505), each with
 its arguments (`MS`), stage state, the alignments it added (`RS`, `RX`) and the set as resultSetSortAndAssignSequence leaves it
-(`PS`, `RF`, `SO`, `SS`, `SG`); behind the `PE` line the set as rmapSingle returns it.  Writes manifest_split.json.
+(`PS`, `RF`, `SO`, `SS`, `SG`); behind the `PE` line the set as rmapSingle returns it; and what `smalt map -p -r -1` prints for the
+reads (`<tag>.split_cigar.out.gz`, `.split_sam.out.gz`).  Writes manifest_split.json.
 Data only; runs in the build container (needs `make -C oracle ref`), not run by the tests.
 
     python tests/golden/make_golden_split.py
@@ -42,6 +43,12 @@ def main():
                     g.write(open(src, "rb").read())
             with gzip.GzipFile(os.path.join(HERE, tag + ".refdump.txt.gz"), "wb", mtime=0) as g:
                 g.write(dump)
+            # what the reference program prints for the same reads (tests/test_split_report.py: the report of split reads on the CPU)
+            for fmt in ("cigar", "sam"):
+                out = os.path.join(d, "o." + fmt)
+                subprocess.run([os.path.join(REF, "smalt"), "map", "-p", "-r", "-1", "-f", fmt] + opts.split() + ["-o", out, pre, fq], check=True, capture_output=True)
+                with gzip.GzipFile(os.path.join(HERE, "%s.split_%s.out.gz" % (tag, fmt)), "wb", mtime=0) as g:
+                    g.write(open(out, "rb").read())
             text = dump.decode()
             e = dict(tag=tag, k=k, s=s, opts=opts, nreads=nreads, calls=text.count("\nMS "), second_calls=text.count("\nMS 1 "), dump_lines=dump.count(b"\n"))
             man.append(e)
