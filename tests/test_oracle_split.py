@@ -32,3 +32,48 @@ def test_oracle_replays_both_calls_of_split_reads(entry, oracle_built, tmp_path)
     finally:
         om.close()
         ol.lib().or_index_free(oix)
+
+
+@pytest.fixture(scope="session")
+def split_check(tmp_path_factory):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-s", "-C", os.path.join(root, "smalt_amd", "csrc")], check=True)
+    exe = str(tmp_path_factory.mktemp("sc") / "split_check")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-pthread", "-o", exe, os.path.join(root, "tests", "hostemu", "split_check.cpp"),
+                    "-L" + os.path.join(root, "smalt_amd"), "-lsmaltgpu", "-Wl,-rpath," + os.path.join(root, "smalt_amd"), "-Wl,-rpath-link,/opt/rocm/lib"], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("entry", sr.MANIFEST, ids=[e["tag"] for e in sr.MANIFEST])
+def test_split_runner_on_replayed_calls_leaves_the_reference_sets(entry, split_check, oracle_built, tmp_path):
+    """the product's split-read runner (smalt_amd/csrc/smg_split.hpp) without a device: tests/hostemu/split_check.cpp feeds it the
+    alignments the reference's calls added; it must ask for the second call exactly where the reference made one (with the running
+    maxima the reference passed) and leave the reference's sets -- rows, mapping probabilities, sorted and per-segment order"""
+    import subprocess
+    fx = sr.load_fixture(entry, tmp_path)
+    import gzip
+    import os
+    import golden_util as gu
+    dump = str(tmp_path / "dump.txt")
+    with gzip.open(os.path.join(gu.GOLD, entry["tag"] + ".refdump.txt.gz"), "rb") as g, open(dump, "wb") as f:
+        f.write(g.read())
+    seqinfo = str(tmp_path / "seqinfo.txt")
+    with open(seqinfo, "w") as o:
+        for nm, sq in zip(fx["names"], fx["seqs"]):
+            o.write("%s %d\n" % (nm, len(sq)))
+    for threads in (1, 3):
+        r = subprocess.run([split_check, dump, fx["fq"], seqinfo, "k=%d" % entry["k"], "s=%d" % entry["s"], "threads=%d" % threads], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-1500:]
+        got = [ln for ln in r.stdout.split("\n") if ln]
+        want = []
+        for R in fx["dump"]:
+            want += R["post_final"]
+        assert len(got) == len(want), (len(got), len(want))
+        for i, (x, y) in enumerate(zip(got, want)):
+            if x.startswith("RF"):                     # the probability to the last bit: compare as numbers, the rest as text
+                fx_, fy = x.split(), y.split()
+                assert fx_[:5] == fy[:5] and float(fx_[5]) == float(fy[5]) and fx_[6:] == fy[6:], (i, x, y)
+            else:
+                assert x == y, (i, x, y)
